@@ -1,0 +1,9 @@
+"""cclqr — MI355X-native batched LQR rollout behind ConstrainedControl.jl's LQR / TrackingLQR / Mechanism surface.
+
+The directory name carries a dot, so import it through `__graft_entry__.load_package()` (registers it as `cclqr`).
+Arithmetic on the hot path happens only in csrc/ (HIP, through the C-ABI of include/cclqr.h); this package is
+the host-side mirror of the reference's plugin interface and never falls back to a CPU implementation.
+"""
+from .mechanism import (Body, Box, EqualityConstraint, MechTables, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, RotY, RotZ,
+                        getid, one_quaternion, qconj, qmul, setJointPosition, setPosition, setVelocity, vrotate)
+from . import examples

@@ -1,0 +1,108 @@
+"""The reference's example mechanisms (= the BASELINE.json configs) rebuilt through the host mirror.
+Every number below is read from the cited script; nothing else of the scripts is reproduced."""
+import numpy as np
+
+from .mechanism import (Box, EqualityConstraint, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, setPosition)
+
+EX = np.array([1.0, 0.0, 0.0])
+EY = np.array([0.0, 1.0, 0.0])
+
+
+def pendulum(θ0=np.pi - 0.4):
+    """examples/lqr_pendulum.jl:8-41 — Box(0.1,0.1,1,1) on a revolute about x, p2=[0,0,0.5]; setpoint RotX(π), xd=[0,0,0.5];
+    Q[7,7]=1000, Q[10,10]=100, R=1, horizon Inf."""
+    p2 = np.array([0.0, 0.0, 0.5])
+    origin = Origin()
+    link1 = Box(0.1, 0.1, 1.0, 1.0)
+    joint = EqualityConstraint(Revolute(origin, link1, EX, p2=p2))
+    mech = Mechanism(origin, [link1], [joint])
+    setPosition(origin, link1, p2=p2, Δq=Quaternion(RotX(θ0)))
+    Q = [np.zeros((12, 12))]
+    Q[0][6, 6] = 1000.0
+    Q[0][9, 9] = 100.0
+    R = [np.ones((1, 1))]
+    xd = [np.array([0.0, 0.0, 0.5])]
+    qd = [Quaternion(RotX(np.pi))]
+    return dict(mech=mech, bodies=[link1], joints=[joint], Q=Q, R=R, xd=xd, qd=qd, ctrl=[joint], horizon=np.inf, tend=10.0)
+
+
+def cartpole_n(n=1, y0=0.5, φ0=None):
+    """examples/lqr_cartpole.jl:8-44 (n=1) and examples/lqr_cartpole_n_pendulum.jl:8-53 (N links):
+    cart Box(0.1,0.5,0.1,0.5) on Prismatic(origin,cart,ey); poles Box(0.1,0.1,1,1) on revolutes about ex;
+    xd = [0,0,0] and [0,0,i-0.5]; Q = I12 per body, R = 1, horizon 10 s."""
+    p2 = np.array([0.0, 0.0, 0.5])
+    if φ0 is None:
+        φ0 = [0.2] + [0.0] * (n - 1)
+    origin = Origin()
+    cart = Box(0.1, 0.5, 0.1, 0.5)
+    poles = [Box(0.1, 0.1, 1.0, 1.0) for _ in range(n)]
+    bodies = [cart] + poles
+    joints = [EqualityConstraint(Prismatic(origin, cart, EY)), EqualityConstraint(Revolute(cart, poles[0], EX, p2=-p2))]
+    for i in range(1, n):
+        joints.append(EqualityConstraint(Revolute(poles[i - 1], poles[i], EX, p1=p2, p2=-p2)))
+    mech = Mechanism(origin, bodies, joints, g=-9.81)
+    place_cartpole(mech, y0, φ0)
+    xd = [np.zeros(3)] + [np.array([0.0, 0.0, i + 0.5]) for i in range(n)]
+    Q = [np.eye(12) for _ in range(n + 1)]
+    R = [np.ones((1, 1))]
+    return dict(mech=mech, bodies=bodies, joints=joints, Q=Q, R=R, xd=xd, qd=None, ctrl=[joints[0]], horizon=10.0, tend=10.0)
+
+
+def place_cartpole(mech, y0, φ):
+    """setPosition! sequence of lqr_cartpole_n_pendulum.jl:39-43: relative angles φ[i] between consecutive links"""
+    p2 = np.array([0.0, 0.0, 0.5])
+    b = mech.bodies
+    setPosition(mech.origin, b[0], Δx=[0.0, y0, 0.0])
+    setPosition(b[0], b[1], p2=-p2, Δq=Quaternion(RotX(φ[0])))
+    for i in range(2, len(b)):
+        setPosition(b[i - 1], b[i], p1=p2, p2=-p2, Δq=Quaternion(RotX(φ[i - 1])))
+
+
+def cartpole_states(n, y0, φ):
+    """batch of initial states z0[n_inst][n+1][13] for the N-link cartpole, zero velocities (8d 'Synthetic inputs')"""
+    y0 = np.atleast_1d(np.asarray(y0, dtype=np.float64))
+    φ = np.asarray(φ, dtype=np.float64).reshape(len(y0), n)
+    ninst = len(y0)
+    z = np.zeros((ninst, n + 1, 13))
+    z[:, :, 3] = 1.0
+    z[:, 0, 1] = y0
+    ang = np.cumsum(φ, axis=1)                      # absolute angle of link i about x
+    s, c = np.sin(ang), np.cos(ang)
+    # joint of link i sits at the top of link i-1 (cart: its COM); COM is 0.5 along the link's z axis
+    jy, jz = y0.copy(), np.zeros(ninst)
+    for i in range(n):
+        # R(RotX(a)) [0,0,0.5] = [0, -0.5 sin a, 0.5 cos a]
+        z[:, i + 1, 0] = 0.0
+        z[:, i + 1, 1] = jy - 0.5 * s[:, i]
+        z[:, i + 1, 2] = jz + 0.5 * c[:, i]
+        z[:, i + 1, 3] = np.cos(ang[:, i] / 2)
+        z[:, i + 1, 4] = np.sin(ang[:, i] / 2)
+        jy = jy - s[:, i]
+        jz = jz + c[:, i]
+    return z
+
+
+def triple_cartpole():
+    """examples/trackingLQR_triple_cartpole.jl:11-45,64-73: cart + 3 poles hanging (p2 = +[0,0,0.5] on the child side,
+    p1 = -p2 on the parent side), Δt = 0.01; Q entries (2,2)=10,(5,5)=1 on the cart, (7,7)=40,(10,10)=1 on each pole; R = 0.1."""
+    p2 = np.array([0.0, 0.0, 0.5])
+    origin = Origin()
+    cart = Box(0.1, 0.5, 0.1, 0.5)
+    poles = [Box(0.1, 0.1, 1.0, 1.0) for _ in range(3)]
+    joints = [EqualityConstraint(Prismatic(origin, cart, EY)), EqualityConstraint(Revolute(cart, poles[0], EX, p2=p2)),
+              EqualityConstraint(Revolute(poles[0], poles[1], EX, p1=-p2, p2=p2)),
+              EqualityConstraint(Revolute(poles[1], poles[2], EX, p1=-p2, p2=p2))]
+    bodies = [cart] + poles
+    mech = Mechanism(origin, bodies, joints, g=-9.81, Δt=0.01)
+    setPosition(origin, cart, Δx=[0.0, 0.0, 0.0])
+    setPosition(cart, poles[0], p2=p2, Δq=Quaternion(RotX(0.0)))
+    setPosition(poles[0], poles[1], p1=-p2, p2=p2, Δq=Quaternion(RotX(0.0)))
+    setPosition(poles[1], poles[2], p1=-p2, p2=p2, Δq=Quaternion(RotX(0.0)))
+    Q = [np.zeros((12, 12)) for _ in range(4)]
+    Q[0][1, 1] = 10.0
+    Q[0][4, 4] = 1.0
+    for i in (1, 2, 3):
+        Q[i][6, 6] = 40.0
+        Q[i][9, 9] = 1.0
+    R = [np.ones((1, 1)) * 0.1]
+    return dict(mech=mech, bodies=bodies, joints=joints, Q=Q, R=R, ctrl=[joints[0]], fric=np.array([0.1, 0.1, 0.1, 0.1]), noise_scale=2.0)

@@ -1,0 +1,268 @@
+"""Host-side description of a mechanism: the subset of ConstrainedDynamics' data model the
+reference's LQR path touches.  Names follow the Julia call sites:
+
+    Origin{Float64}()                              examples/lqr_cartpole.jl:20
+    Box(x, y, z, m)                                examples/lqr_cartpole.jl:21-22
+    EqualityConstraint(Prismatic(origin, cart, ey))            :25
+    EqualityConstraint(Revolute(cart, pole, ex; p2=-p2))       :26
+    Mechanism(origin, links, constraints, g=-9.81[, Δt=0.01])  :32
+    setPosition!(origin, cart, Δx=[0;0.5;0])                   :33   -> setPosition(...)
+    setPosition!(cart, pole, p2=-p2, Δq=Quaternion(RotX(0.2))) :34
+    getid.(links)                                              :41
+
+This is description only (no dynamics arithmetic): it flattens to the `cclqr_mech_desc` tables the
+C-ABI takes (include/cclqr.h).  Bodies get ids 1..Nb, joints Nb+1..Nb+Ne (as implied by
+geteqconstraint(mechanism, 6..8) with Nb = 4, examples/trackingLQR_triple_cartpole.jl:109-111).
+"""
+import math
+
+import numpy as np
+
+REVOLUTE, PRISMATIC = 0, 1
+
+
+# ------------------------------------------------------------------ quaternions (scalar first)
+def Quaternion(*a):
+    """Quaternion(RotX(θ)) / Quaternion(s, x, y, z) / Quaternion([s,x,y,z])"""
+    if len(a) == 1:
+        q = np.asarray(a[0], dtype=np.float64).reshape(4)
+    else:
+        q = np.asarray(a, dtype=np.float64).reshape(4)
+    return q.copy()
+
+
+def one_quaternion():
+    return np.array([1.0, 0.0, 0.0, 0.0])
+
+
+def RotX(t):
+    return np.array([math.cos(t / 2), math.sin(t / 2), 0.0, 0.0])
+
+
+def RotY(t):
+    return np.array([math.cos(t / 2), 0.0, math.sin(t / 2), 0.0])
+
+
+def RotZ(t):
+    return np.array([math.cos(t / 2), 0.0, 0.0, math.sin(t / 2)])
+
+
+def qmul(a, b):
+    s1, v1, s2, v2 = a[0], a[1:], b[0], b[1:]
+    return np.concatenate([[s1 * s2 - v1 @ v2], s1 * v2 + s2 * v1 + np.cross(v1, v2)])
+
+
+def qconj(a):
+    return np.array([a[0], -a[1], -a[2], -a[3]])
+
+
+def vrotate(p, q):
+    p = np.asarray(p, dtype=np.float64)
+    return qmul(qmul(q, np.concatenate([[0.0], p])), qconj(q))[1:]
+
+
+def rpy_quaternion(r, p, y):
+    """URDF fixed-axis roll-pitch-yaw -> quaternion (Rz(y) Ry(p) Rx(r))"""
+    return qmul(RotZ(y), qmul(RotY(p), RotX(r)))
+
+
+# ------------------------------------------------------------------ components
+class State:
+    def __init__(self):
+        self.xc = np.zeros(3)
+        self.qc = one_quaternion()
+        self.vc = np.zeros(3)
+        self.ωc = np.zeros(3)
+
+    @property
+    def wc(self):
+        return self.ωc
+
+
+class Origin:
+    def __init__(self, name="origin"):
+        self.id = 0
+        self.name = name
+        self.state = State()
+
+
+class Body:
+    def __init__(self, m, J, name=""):
+        self.m = float(m)
+        self.J = np.asarray(J, dtype=np.float64).reshape(3, 3)
+        self.id = -1
+        self.name = name
+        self.state = State()
+
+
+def Box(x, y, z, m, name=""):
+    """Box(x,y,z,m): J = m/12 diag(y²+z², x²+z², x²+y²)  (SURVEY 8a-bis 'Box inertia')"""
+    J = m / 12.0 * np.diag([y * y + z * z, x * x + z * z, x * x + y * y])
+    return Body(m, J, name)
+
+
+class _Joint:
+    def __init__(self, kind, body1, body2, axis, p1=None, p2=None, qoffset=None):
+        self.kind = kind
+        self.body1, self.body2 = body1, body2
+        self.axis = np.asarray(axis, dtype=np.float64).reshape(3)
+        self.p1 = np.zeros(3) if p1 is None else np.asarray(p1, dtype=np.float64).reshape(3)
+        self.p2 = np.zeros(3) if p2 is None else np.asarray(p2, dtype=np.float64).reshape(3)
+        self.qoffset = one_quaternion() if qoffset is None else Quaternion(qoffset)
+
+
+def Revolute(body1, body2, axis, p1=None, p2=None, qoffset=None):
+    return _Joint(REVOLUTE, body1, body2, axis, p1, p2, qoffset)
+
+
+def Prismatic(body1, body2, axis, p1=None, p2=None, qoffset=None):
+    return _Joint(PRISMATIC, body1, body2, axis, p1, p2, qoffset)
+
+
+class EqualityConstraint:
+    def __init__(self, joint, name=""):
+        self.joint = joint
+        self.parentid = None
+        self.childid = None
+        self.id = -1
+        self.name = name
+
+    def __len__(self):
+        return 5  # Revolute and Prismatic both remove 5 DoF
+
+
+def getid(c):
+    return c.id
+
+
+class MechTables:
+    """flat tables = cclqr_mech_desc (include/cclqr.h)"""
+
+    def __init__(self, nb, ne, dt, g, mass, inertia, parent, child, type, p1, p2, axis, qoff):
+        self.nb, self.ne, self.dt, self.g = int(nb), int(ne), float(dt), float(g)
+        self.mass = np.ascontiguousarray(mass, dtype=np.float64).reshape(nb)
+        self.inertia = np.ascontiguousarray(inertia, dtype=np.float64).reshape(nb, 9)
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32).reshape(ne)
+        self.child = np.ascontiguousarray(child, dtype=np.int32).reshape(ne)
+        self.type = np.ascontiguousarray(type, dtype=np.int32).reshape(ne)
+        self.p1 = np.ascontiguousarray(p1, dtype=np.float64).reshape(ne, 3)
+        self.p2 = np.ascontiguousarray(p2, dtype=np.float64).reshape(ne, 3)
+        self.axis = np.ascontiguousarray(axis, dtype=np.float64).reshape(ne, 3)
+        self.qoff = np.ascontiguousarray(qoff, dtype=np.float64).reshape(ne, 4)
+
+    @property
+    def mx(self):
+        return 12 * self.nb
+
+    @property
+    def ml(self):
+        return 5 * self.ne
+
+
+class Mechanism:
+    """Mechanism(origin, bodies, eqconstraints; g=-9.81, Δt=0.01)"""
+
+    def __init__(self, origin, bodies, eqconstraints, g=-9.81, dt=None, **kw):
+        if "Δt" in kw:
+            dt = kw.pop("Δt")
+        if kw:
+            raise TypeError("unexpected keyword(s): %s" % list(kw))
+        self.origin = origin
+        self.bodies = list(bodies)
+        self.eqconstraints = list(eqconstraints)
+        self.g = float(g)
+        self.Δt = 0.01 if dt is None else float(dt)
+        nb = len(self.bodies)
+        for i, b in enumerate(self.bodies):
+            b.id = i + 1
+        for j, e in enumerate(self.eqconstraints):
+            e.id = nb + j + 1
+            e.parentid = e.joint.body1.id
+            e.childid = e.joint.body2.id
+        self._byname = {e.name: e for e in self.eqconstraints if e.name}
+        self.tables()  # validates the topology
+
+    @property
+    def dt(self):
+        return self.Δt
+
+    def geteqconstraint(self, id_or_name):
+        if isinstance(id_or_name, str):
+            return self._byname[id_or_name]
+        return self.eqconstraints[int(id_or_name) - len(self.bodies) - 1]
+
+    def getbody(self, id):
+        return self.bodies[int(id) - 1]
+
+    def joint_index(self, eqcid):
+        j = int(eqcid) - len(self.bodies) - 1
+        if not 0 <= j < len(self.eqconstraints):
+            raise IndexError("no equality constraint with id %r" % (eqcid,))
+        return j
+
+    def tables(self):
+        nb, ne = len(self.bodies), len(self.eqconstraints)
+        if ne != nb:
+            raise ValueError("only tree mechanisms with one 1-DoF joint per body are supported (Nb=%d, Ne=%d); "
+                             "closed loops (lqr_deltabot.jl) are out of scope" % (nb, ne))
+        parent = [e.joint.body1.id - 1 for e in self.eqconstraints]
+        child = [e.joint.body2.id - 1 for e in self.eqconstraints]
+        if sorted(child) != list(range(nb)):
+            raise ValueError("every body must be the child of exactly one joint")
+        return MechTables(nb, ne, self.Δt, self.g, [b.m for b in self.bodies], [b.J.reshape(9) for b in self.bodies], parent, child,
+                          [e.joint.kind for e in self.eqconstraints], [e.joint.p1 for e in self.eqconstraints],
+                          [e.joint.p2 for e in self.eqconstraints], [e.joint.axis for e in self.eqconstraints],
+                          [e.joint.qoffset for e in self.eqconstraints])
+
+    def state(self):
+        """current body states as z[nb][13] = x(3) q(4) v(3) ω(3)"""
+        z = np.zeros((len(self.bodies), 13))
+        for i, b in enumerate(self.bodies):
+            z[i, 0:3], z[i, 3:7], z[i, 7:10], z[i, 10:13] = b.state.xc, b.state.qc, b.state.vc, b.state.ωc
+        return z
+
+    def set_state(self, z):
+        z = np.asarray(z, dtype=np.float64).reshape(len(self.bodies), 13)
+        for i, b in enumerate(self.bodies):
+            b.state.xc, b.state.qc, b.state.vc, b.state.ωc = z[i, 0:3].copy(), z[i, 3:7].copy(), z[i, 7:10].copy(), z[i, 10:13].copy()
+
+
+def setPosition(body1, body2=None, p1=None, p2=None, Δx=None, Δq=None, x=None, q=None):
+    """setPosition!(body; x, q)  /  setPosition!(body1, body2; p1, p2, Δx, Δq):
+    q2 = q1 ⊗ Δq ; x2 = x1 + R(q1)(p1 + Δx) − R(q2) p2      (cross-checked there)"""
+    if body2 is None:
+        if x is not None:
+            body1.state.xc = np.asarray(x, dtype=np.float64).reshape(3).copy()
+        if q is not None:
+            body1.state.qc = Quaternion(q)
+        return
+    p1 = np.zeros(3) if p1 is None else np.asarray(p1, dtype=np.float64)
+    p2 = np.zeros(3) if p2 is None else np.asarray(p2, dtype=np.float64)
+    Δx = np.zeros(3) if Δx is None else np.asarray(Δx, dtype=np.float64)
+    Δq = one_quaternion() if Δq is None else Quaternion(Δq)
+    q1, x1 = body1.state.qc, body1.state.xc
+    q2 = qmul(q1, Δq)
+    body2.state.qc = q2
+    body2.state.xc = x1 + vrotate(p1 + Δx, q1) - vrotate(p2, q2)
+
+
+def setVelocity(body, v=None, ω=None, **kw):
+    """setVelocity!(body; v, ω) — defaults zero both (examples/trackingLQR_triple_cartpole.jl:144-147)"""
+    if "w" in kw:
+        ω = kw["w"]
+    body.state.vc = np.zeros(3) if v is None else np.asarray(v, dtype=np.float64).reshape(3).copy()
+    body.state.ωc = np.zeros(3) if ω is None else np.asarray(ω, dtype=np.float64).reshape(3).copy()
+
+
+def setJointPosition(mech, eqc, θ):
+    """setPosition!(mech, eqc, [θ]) for a 1-DoF joint (examples/lqr_sawyer.jl:11-14): place the child
+    relative to its parent at joint coordinate θ (angle for Revolute, offset for Prismatic); descendants
+    are re-placed by calling this in root-to-leaf order."""
+    j = eqc.joint
+    θ = float(np.asarray(θ).reshape(-1)[0])
+    a = j.axis / np.linalg.norm(j.axis)
+    if j.kind == REVOLUTE:
+        dq = qmul(np.concatenate([[math.cos(θ / 2)], math.sin(θ / 2) * a]), j.qoffset)
+        setPosition(j.body1, j.body2, p1=j.p1, p2=j.p2, Δq=dq)
+    else:
+        setPosition(j.body1, j.body2, p1=j.p1, p2=j.p2, Δx=θ * a, Δq=j.qoffset)
