@@ -7,3 +7,6 @@ the host-side mirror of the reference's plugin interface and never falls back to
 from .mechanism import (Body, Box, EqualityConstraint, MechTables, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, RotY, RotZ,
                         getid, one_quaternion, qconj, qmul, setJointPosition, setPosition, setVelocity, vrotate)
 from . import examples
+from . import _capi
+from . import dist
+from .lqr import LQR, Controller, OpenLoop, Storage, TrackingLQR, simulate

@@ -1,0 +1,212 @@
+"""ctypes binding of libcclqr.so (include/cclqr.h).  There is no fallback: if the HIP library is missing or a
+call fails, this raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcclqr.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+OK, EINVAL, ESINGULAR, ENOCONV, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+_ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQR_ENOCONV", EHIP: "CCLQR_EHIP", EUNSUPPORTED: "CCLQR_EUNSUPPORTED"}
+
+EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
+           "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
+           "cclqr_rollout_dev", "cclqr_rollout_geometry"]
+
+
+class CclqrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_ERRNAME.get(code, "?"), code, msg))
+        self.code = code
+
+
+class MechDesc(C.Structure):
+    _fields_ = [("nb", C.c_int32), ("ne", C.c_int32), ("dt", C.c_double), ("g", C.c_double),
+                ("mass", _dp), ("inertia", _dp), ("parent", _ip), ("child", _ip), ("type", _ip),
+                ("p1", _dp), ("p2", _dp), ("axis", _dp), ("qoff", _dp)]
+
+
+class CtrlDesc(C.Structure):
+    _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
+                ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """load libcclqr.so; raises if it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libcclqr.so is missing at %s: the HIP extension must be built (no CPU fallback exists)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.cclqr_last_error.restype = C.c_char_p
+        for name in EXPORTS[1:]:
+            getattr(L, name).restype = C.c_int   # a missing export raises here: the library must implement all of include/cclqr.h
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise CclqrError(rc, lib().cclqr_last_error().decode())
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().cclqr_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(dev):
+    check(lib().cclqr_set_device(C.c_int32(dev)))
+
+
+class MechHandle:
+    """cclqr_mech*: device-resident mechanism tables"""
+
+    def __init__(self, tables):
+        t = tables
+        self.tables = t
+        self._arrs = [f64(t.mass), f64(t.inertia), i32(t.parent), i32(t.child), i32(t.type), f64(t.p1), f64(t.p2), f64(t.axis), f64(t.qoff)]
+        a = self._arrs
+        self.desc = MechDesc(t.nb, t.ne, t.dt, t.g, _d(a[0]), _d(a[1]), _i(a[2]), _i(a[3]), _i(a[4]), _d(a[5]), _d(a[6]), _d(a[7]), _d(a[8]))
+        self.ptr = C.c_void_p()
+        check(lib().cclqr_mech_create(C.byref(self.desc), C.byref(self.ptr)))
+
+    def geometry(self):
+        lanes, ldsb = C.c_int32(0), C.c_int32(0)
+        check(lib().cclqr_rollout_geometry(self.ptr, C.byref(lanes), C.byref(ldsb)))
+        return lanes.value, ldsb.value
+
+    def close(self):
+        if self.ptr:
+            lib().cclqr_mech_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CtrlHandle:
+    """cclqr_ctrl*: device-resident controller tables"""
+
+    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0):
+        nb = mech.tables.nb
+        cj = i32(ctrl_joint).reshape(-1)
+        mu = len(cj)
+        if zd is None:
+            zd = np.zeros((1, nb, 13))
+            zd[:, :, 3] = 1.0
+        zd = f64(zd).reshape(-1, nb, 13)
+        nsp = zd.shape[0]
+        Fd = f64(np.zeros((nsp, mu)) if Fd is None else Fd).reshape(nsp, mu)
+        K = None if K is None else f64(K).reshape(-1, mu, 12 * nb)
+        fric = None if fric is None else f64(fric).reshape(nb)
+        self._arrs = [cj, K, zd, Fd, fric]
+        self.mu, self.N, self.nsp = mu, int(N), nsp
+        self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0], int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale))
+        self.ptr = C.c_void_p()
+        check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
+
+    def close(self):
+        if self.ptr:
+            lib().cclqr_ctrl_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
+    """host-pointer rollout: returns (zT, traj or None, status)"""
+    nb = mech.tables.nb
+    z0 = f64(z0).reshape(-1, nb, 13)
+    n = z0.shape[0]
+    traj = np.zeros((n, steps, nb, 13)) if record else None
+    zT = np.zeros_like(z0)
+    status = np.zeros(n, dtype=np.int32)
+    noise = None if noise is None else f64(noise).reshape(n, steps)
+    check(lib().cclqr_rollout(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
+                              _i(status)))
+    return zT, traj, status
+
+
+def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0):
+    """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous"""
+    vp = lambda p: C.c_void_p(int(p)) if p else None
+    check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
+                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
+
+
+def linearize(mech, zd, ctrl_joint, Fd=None):
+    """batched linearsystem: zd [nk][nb][13] -> A [nk][mx][mx], Bu, Bl, G"""
+    t = mech.tables
+    zd = f64(zd).reshape(-1, t.nb, 13)
+    nk = zd.shape[0]
+    cj = i32(ctrl_joint).reshape(-1)
+    mu, mx, ml = len(cj), 12 * t.nb, 5 * t.ne
+    Fd = f64(np.zeros((nk, mu)) if Fd is None else Fd).reshape(nk, mu)
+    A, Bu, Bl, G = np.zeros((nk, mx, mx)), np.zeros((nk, mx, mu)), np.zeros((nk, mx, ml)), np.zeros((nk, ml, mx))
+    check(lib().cclqr_linearize(mech.ptr, C.c_int32(nk), _d(zd), C.c_int32(mu), _i(cj), _d(Fd), _d(A), _d(Bu), _d(Bl), _d(G)))
+    return A, Bu, Bl, G
+
+
+def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5):
+    """batched dlqr: A [nprob][mx][mx] (or [mx][mx]) -> K [nprob][N-1][mu][mx], kbreak [nprob]"""
+    A = f64(A)
+    single = A.ndim == 2
+    mx = A.shape[-1]
+    A = A.reshape(-1, mx, mx)
+    nprob = A.shape[0]
+    Bu = f64(Bu).reshape(nprob, mx, -1)
+    mu = Bu.shape[2]
+    Bl = f64(Bl).reshape(nprob, mx, -1)
+    ml = Bl.shape[2]
+    G = f64(G).reshape(nprob, ml, mx)
+    Q, R = f64(Q).reshape(mx, mx), f64(R).reshape(mu, mu)
+    K = np.zeros((nprob, max(N - 1, 0), mu, mx))
+    kb = np.zeros(nprob, dtype=np.int32)
+    check(lib().cclqr_riccati(C.c_int32(nprob), C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl), _d(G), _d(Q), _d(R),
+                              C.c_int32(N), C.c_double(tol), _d(K), _i(kb)))
+    return (K[0], int(kb[0])) if single else (K, kb)
+
+
+def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5):
+    t = mech.tables
+    cj = i32(ctrl_joint).reshape(-1)
+    mu, mx = len(cj), 12 * t.nb
+    zd = f64(zd).reshape(N, t.nb, 13)
+    Fd = f64(Fd).reshape(N, mu)
+    K = np.zeros((N - 1, mu, mx))
+    kb = C.c_int32(0)
+    check(lib().cclqr_riccati_tracking(mech.ptr, C.c_int32(mu), _i(cj), _d(zd), _d(Fd), _d(f64(Q).reshape(mx, mx)), _d(f64(R).reshape(mu, mu)),
+                                       C.c_int32(N), C.c_double(tol), _d(K), C.byref(kb)))
+    return K, kb.value

@@ -1,0 +1,278 @@
+// capi.hip -- the extern "C" boundary of libcclqr.so (include/cclqr.h).  Host-side work here is limited to
+// validation, index permutations (user body order <-> breadth-first link order) and device memory plumbing;
+// every piece of hot-path arithmetic runs in the HIP kernels.
+#include "../../include/cclqr.h"
+#include "cclqr_internal.h"
+#include "cclqr_tables.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace cclqr;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                         \
+    do {                                                                                                  \
+        hipError_t e_ = (x);                                                                              \
+        if (e_ != hipSuccess) return fail(CCLQR_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+extern "C" const char* cclqr_last_error(void) { return g_err.c_str(); }
+extern "C" int cclqr_version(void) { return 100; }
+extern "C" int cclqr_device_count(int32_t* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(CCLQR_EHIP, hipGetErrorString(e)); }
+    *n = c;
+    return CCLQR_OK;
+}
+extern "C" int cclqr_set_device(int32_t dev) { HIPCHK(hipSetDevice(dev)); return CCLQR_OK; }
+
+extern "C" int cclqr_mech_create(const cclqr_mech_desc* d, cclqr_mech** out) {
+    if (!d || !out) return fail(CCLQR_EINVAL, "null argument");
+    cclqr_mech* m = new cclqr_mech();
+    std::string err;
+    int rc = build_mech_tables(d, m, err);
+    if (rc != CCLQR_OK) { delete m; return fail(rc, err); }
+    hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->dev, sizeof(MechDev));
+    if (e == hipSuccess) e = hipMemcpy(m->dev, &m->host, sizeof(MechDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete m; return fail(CCLQR_EHIP, std::string("mechanism upload: ") + hipGetErrorString(e)); }
+    *out = m;
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_mech_destroy(cclqr_mech* m) {
+    if (!m) return CCLQR_OK;
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, cclqr_ctrl** out) {
+    if (!m || !d || !out) return fail(CCLQR_EINVAL, "null argument");
+    CtrlHostTables T;
+    std::string err;
+    int rc = build_ctrl_tables(m, d, T, err);
+    if (rc != CCLQR_OK) return fail(rc, err);
+    cclqr_ctrl* c = new cclqr_ctrl();
+    memset(c, 0, sizeof(*c));
+    c->nb = m->nb;
+    hipError_t e = hipMalloc((void**)&c->zd_dev, T.zd.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(c->zd_dev, T.zd.data(), T.zd.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !T.K.empty()) {
+        e = hipMalloc((void**)&c->K_dev, T.K.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(c->K_dev, T.K.data(), T.K.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !T.Fd.empty()) {
+        e = hipMalloc((void**)&c->Fd_dev, T.Fd.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(c->Fd_dev, T.Fd.data(), T.Fd.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    c->host = T.H;
+    c->host.K = c->K_dev; c->host.zd = c->zd_dev; c->host.Fd = c->Fd_dev;
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dev, sizeof(CtrlDev));
+    if (e == hipSuccess) e = hipMemcpy(c->dev, &c->host, sizeof(CtrlDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cclqr_ctrl_destroy(c); return fail(CCLQR_EHIP, std::string("controller upload: ") + hipGetErrorString(e)); }
+    *out = c;
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
+    if (!c) return CCLQR_OK;
+    if (c->K_dev) (void)hipFree(c->K_dev);
+    if (c->zd_dev) (void)hipFree(c->zd_dev);
+    if (c->Fd_dev) (void)hipFree(c->Fd_dev);
+    if (c->dev) (void)hipFree(c->dev);
+    delete c;
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
+    if (!m) return fail(CCLQR_EINVAL, "null argument");
+    if (lanes) *lanes = rollout_lanes_per_instance(m->nb);
+    if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb);
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                                 double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
+                                 void* stream) {
+    if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
+    if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
+    if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
+    if (rollout_lds_bytes(m->nb) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    RolloutArgs a;
+    a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = noise;
+    a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status;
+    HIPCHK(launch_rollout(a, m->nb, (hipStream_t)stream));
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                             const double* noise, double* traj, double* zT, int32_t* status) {
+    if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
+    const size_t nz = (size_t)13 * m->nb;
+    double *dz0 = nullptr, *dzT = nullptr, *dtraj = nullptr, *dnoise = nullptr;
+    int32_t* dst = nullptr;
+    int rc = CCLQR_OK;
+    hipError_t e = hipMalloc((void**)&dz0, n_inst * nz * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dzT, n_inst * nz * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dst, n_inst * sizeof(int32_t));
+    if (e == hipSuccess && traj) e = hipMalloc((void**)&dtraj, n_inst * steps * nz * sizeof(double));
+    if (e == hipSuccess && noise) e = hipMalloc((void**)&dnoise, (size_t)n_inst * steps * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dz0, z0, n_inst * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && noise) e = hipMemcpy(dnoise, noise, (size_t)n_inst * steps * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        // noise is indexed by the absolute step k-1: shift the base so that k0 maps to column 0 of the caller's array
+        const double* nbase = dnoise ? dnoise - (k0 - 1) : nullptr;
+        rc = cclqr_rollout_dev(m, c, n_inst, steps, k0, dz0, nullptr, nbase, steps, dtraj, dzT, dst, nullptr);
+        if (rc == CCLQR_OK) e = hipDeviceSynchronize();
+    }
+    if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(zT, dzT, n_inst * nz * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == CCLQR_OK && e == hipSuccess && traj) e = hipMemcpy(traj, dtraj, n_inst * steps * nz * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == CCLQR_OK && e == hipSuccess && status) e = hipMemcpy(status, dst, n_inst * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dz0); (void)hipFree(dzT); (void)hipFree(dst); (void)hipFree(dtraj); (void)hipFree(dnoise);
+    if (rc != CCLQR_OK) return rc;
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("rollout: ") + hipGetErrorString(e));
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
+                               double* A, double* Bu, double* Bl, double* G) {
+    if (!m || !zd || !A || !Bl || !G || (mu > 0 && (!ctrl_joint || !Bu))) return fail(CCLQR_EINVAL, "null argument");
+    if (nk < 0 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
+    if (nk == 0) return CCLQR_OK;
+    const int nb = m->nb;
+    const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb;
+    if (linearize_lds_bytes(nb) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = m->dev; a.nk = nk; a.mu = mu;
+    for (int i = 0; i < mu; i++) {
+        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nb) return fail(CCLQR_EINVAL, "controlled joint out of range");
+        a.cj[i] = m->link_of_joint[ctrl_joint[i]];
+    }
+    double *dzd = nullptr, *dFd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
+    int* dst = nullptr;
+    std::vector<int> st(nk);
+    hipError_t e = hipMalloc((void**)&dzd, nk * nz * sizeof(double));
+    if (e == hipSuccess && Fd && mu > 0) e = hipMalloc((void**)&dFd, (size_t)nk * mu * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dA, nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBl, nk * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dG, nk * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dst, nk * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
+    a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
+    if (e == hipSuccess) e = launch_linearize(a, nb, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(A, dA, nk * mx * mx * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mu > 0) e = hipMemcpy(Bu, dBu, nk * mx * mu * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(Bl, dBl, nk * mx * ml * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(G, dG, nk * ml * mx * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nk * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(dzd); (void)hipFree(dFd); (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG); (void)hipFree(dst);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("linearize: ") + hipGetErrorString(e));
+    for (int k = 0; k < nk; k++)
+        if (st[k] <= 0) return fail(CCLQR_ENOCONV, "Newton did not converge at the setpoint of knot " + std::to_string(k));
+    return CCLQR_OK;
+}
+
+// shared tail of the two dlqr entry points: run the recursion on device-resident (A,Bu,Bl,G), download K and kbreak
+static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varying, double tol, const double* dA, const double* dBu,
+                       const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak) {
+    const size_t nK = (size_t)nprob * (N > 1 ? N - 1 : 0) * mu * mx;
+    double *dQ = nullptr, *dR = nullptr, *dK = nullptr, *dwork = nullptr;
+    int *dkb = nullptr, *dst = nullptr;
+    std::vector<int> st(nprob), kb(nprob);
+    const size_t wd = ric_work_doubles(mx, mu, ml);
+    hipError_t e = hipMalloc((void**)&dQ, (size_t)mx * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dK, (nK + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dwork, (size_t)nprob * wd * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dkb, nprob * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&dst, nprob * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dQ, Q, (size_t)mx * mx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && mu > 0) e = hipMemcpy(dR, R, (size_t)mu * mu * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dK, 0, (nK + 1) * sizeof(double));
+    RicArgs a;
+    a.nprob = nprob; a.mx = mx; a.mu = mu; a.ml = ml; a.N = N; a.time_varying = time_varying; a.tol = tol;
+    a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.Q = dQ; a.R = dR; a.K = dK; a.kbreak = dkb; a.status = dst; a.work = dwork;
+    if (e == hipSuccess) e = launch_riccati(a, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && nK) e = hipMemcpy(K, dK, nK * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(kb.data(), dkb, nprob * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nprob * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dK); (void)hipFree(dwork); (void)hipFree(dkb); (void)hipFree(dst);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati: ") + hipGetErrorString(e));
+    for (int p = 0; p < nprob; p++) {
+        if (kbreak) kbreak[p] = kb[p];
+        if (st[p] != 0) return fail(CCLQR_ESINGULAR, "G*Bl or M is singular in problem " + std::to_string(p));
+    }
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double* A, const double* Bu, const double* Bl,
+                             const double* G, const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
+    if (!A || !Q || (mu > 0 && (!Bu || !R)) || (ml > 0 && (!Bl || !G)) || !K) return fail(CCLQR_EINVAL, "null argument");
+    if (nprob < 1 || mx < 1 || mu < 0 || ml < 0 || N < 1) return fail(CCLQR_EINVAL, "bad sizes");
+    double *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
+    const size_t np = nprob;
+    hipError_t e = hipMalloc((void**)&dA, np * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (np * mx * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBl, (np * mx * ml + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dG, (np * ml * mx + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dA, A, np * mx * mx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && mu > 0) e = hipMemcpy(dBu, Bu, np * mx * mu * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ml > 0) e = hipMemcpy(dBl, Bl, np * mx * ml * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ml > 0) e = hipMemcpy(dG, G, np * ml * mx * sizeof(double), hipMemcpyHostToDevice);
+    int rc = CCLQR_OK;
+    if (e == hipSuccess) rc = run_riccati(nprob, mx, mu, ml, N, 0, tol, dA, dBu, dBl, dG, Q, R, K, kbreak);
+    (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati upload: ") + hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int32_t* ctrl_joint, const double* zd, const double* Fd,
+                                      const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
+    if (!m || !zd || !Q || !K || (mu > 0 && (!ctrl_joint || !R))) return fail(CCLQR_EINVAL, "null argument");
+    if (N < 2 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "bad sizes");
+    const int nb = m->nb, nk = N - 1;
+    const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb;
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = m->dev; a.nk = nk; a.mu = mu;
+    for (int i = 0; i < mu; i++) {
+        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nb) return fail(CCLQR_EINVAL, "controlled joint out of range");
+        a.cj[i] = m->link_of_joint[ctrl_joint[i]];
+    }
+    double *dzd = nullptr, *dFd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
+    int* dst = nullptr;
+    std::vector<int> st(nk);
+    // knots 1..N-1 (lqr_tracking.jl:87-88): linearise all of them in one launch, keep the matrices on the device
+    hipError_t e = hipMalloc((void**)&dzd, nk * nz * sizeof(double));
+    if (e == hipSuccess && Fd && mu > 0) e = hipMalloc((void**)&dFd, (size_t)nk * mu * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dA, nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dBl, nk * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dG, nk * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dst, nk * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
+    a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
+    if (e == hipSuccess) e = launch_linearize(a, nb, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nk * sizeof(int), hipMemcpyDeviceToHost);
+    int rc = CCLQR_OK;
+    if (e == hipSuccess) {
+        for (int k = 0; k < nk && rc == CCLQR_OK; k++)
+            if (st[k] <= 0) rc = fail(CCLQR_ENOCONV, "Newton did not converge at the setpoint of knot " + std::to_string(k));
+        if (rc == CCLQR_OK) rc = run_riccati(1, (int)mx, mu, (int)ml, N, 1, tol, dA, dBu, dBl, dG, Q, R, K, kbreak);
+    }
+    (void)hipFree(dzd); (void)hipFree(dFd); (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG); (void)hipFree(dst);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati_tracking: ") + hipGetErrorString(e));
+    return rc;
+}

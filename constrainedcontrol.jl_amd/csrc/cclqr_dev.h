@@ -1,0 +1,514 @@
+// cclqr_dev.h -- device-side data model and the per-lane "phase" functions of the rollout kernel.
+//
+// Execution model (DESIGN.md "rollout kernel"): one mechanism instance is owned by a group of G lanes
+// (G = 16/32/64) of ONE wavefront; all per-instance data lives in LDS; a step is a sequence of phases,
+// each phase a set of independent tasks spread over the group's lanes, separated by wave barriers.
+// Lane t < nb permanently owns link t (= body t and the joint that hangs it off its parent), so the
+// link's constants and per-step invariants stay in that lane's registers.
+//
+// The linear solve is NOT the reference's generic 6x6/5x5 tree LDU: bodies are eliminated first in
+// closed form (D_b = blkdiag(m/dt I, D_R 3x3)), which leaves a block-tridiagonal 5x5 system in the
+// multipliers along each chain.  Same linear system, same solution up to rounding.
+//
+// Every function here is __host__ __device__ so tests/emu can run the identical arithmetic serially
+// on the CPU (test infrastructure only; the product never executes these on the host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define CCLQR_MAXL 32          // links per mechanism supported by the device path
+#define HD __host__ __device__ __forceinline__
+
+namespace cclqr {
+
+// ---- mechanism tables in device memory (internal link order = breadth-first from the origin) ----
+struct MechDev {
+    int nb;
+    double dt, g;
+    int parent[CCLQR_MAXL];   // parent link, -1 = origin
+    int childl[CCLQR_MAXL];   // the single child link (forest of chains), -1 = leaf
+    int rotmask[CCLQR_MAXL];  // bit r set: constraint row r is a rotational row
+    int type[CCLQR_MAXL];     // 0 revolute, 1 prismatic
+    int perm[CCLQR_MAXL];     // user body index of link l
+    int jperm[CCLQR_MAXL];    // user joint index of link l's joint
+    double m[CCLQR_MAXL], J[CCLQR_MAXL][9];
+    double p1[CCLQR_MAXL][3], p2[CCLQR_MAXL][3], axis[CCLQR_MAXL][3], qoc[CCLQR_MAXL][4]; // qoc = conj(qoffset)
+    double sel[CCLQR_MAXL][5][3]; // row r of the joint = sel[r] . (translational | rotational 3-vector)
+};
+
+// ---- controller tables in device memory ----
+struct CtrlDev {
+    int mu, nK, N, nsp;       // N <= 0: infinite horizon
+    int cj[CCLQR_MAXL];       // controlled links (internal index)
+    const double* K;          // [nK][mu][12 nb], columns in internal link order
+    const double* zd;         // [nsp][nb][13] internal link order
+    const double* Fd;         // [nsp][mu]
+    double fric[CCLQR_MAXL];  // viscous joint friction per link
+    int has_fric;
+    double noise_scale;
+};
+
+// ---- LDS layout of one instance (offsets in doubles) ----
+struct Lay {
+    int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, DZ, total;
+};
+#define BLK 31   // stride of a 5x6 block (30 used; odd stride keeps ds_read_b64 conflict-free across lanes)
+HD Lay make_layout(int nb) {
+    Lay L; int o = 0;
+    L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;
+    L.LAM = o; o += 5 * nb;  L.LT = o; o += 5 * nb;  L.DS = o; o += 6 * nb;  L.DL = o; o += 5 * nb;
+    L.XQ = o; o += 7 * nb;   L.NB = o; o += 9 * nb;  L.DINV = o; o += 9 * nb; L.DTM = o; o += nb;
+    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nb;   L.R = o; o += 5 * nb;
+    L.GKA = o; o += BLK * nb; L.GKB = o; o += BLK * nb; L.GVA = o; o += BLK * nb; L.GVB = o; o += BLK * nb;
+    L.SJJ = o; o += 25 * nb; L.SJP = o; o += 25 * nb; L.SPJ = o; o += 25 * nb;
+    L.UJ = o; o += nb;
+    L.DZ = L.GVA;            // control error aliases the (dead at control time) Gv storage: 12 nb <= 31 nb
+    L.total = o | 1;         // odd instance stride
+    return L;
+}
+
+// ---- per-lane registers that persist across phases ----
+struct LaneRegs {
+    // link constants (lane t < nb owns link t)
+    double m, J[9], p1[3], p2[3], sel[5][3], qoc[4], axis[3];
+    int parent, childl, rotmask, type;
+    // per-step invariants of the owned body: cT = m(-v/dt + ezg) - F ; cR = -(sq1 I - [w1]x) J w1 - 2 tau
+    double cT[3], cR[3];
+};
+
+// ------------------------------------------------------------------ small algebra
+HD void qmul(const double* a, const double* b, double* o) {
+    double s = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    o[0] = s; o[1] = x; o[2] = y; o[3] = z;
+}
+HD void rotmat(const double* q, double* R) {
+    double s = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = s * s + x * x - y * y - z * z; R[1] = 2 * (x * y - s * z); R[2] = 2 * (x * z + s * y);
+    R[3] = 2 * (x * y + s * z); R[4] = s * s - x * x + y * y - z * z; R[5] = 2 * (y * z - s * x);
+    R[6] = 2 * (x * z - s * y); R[7] = 2 * (y * z + s * x); R[8] = s * s - x * x - y * y + z * z;
+}
+HD void mv3(const double* R, const double* p, double* o) {   // o = R p
+    double a = R[0] * p[0] + R[1] * p[1] + R[2] * p[2], b = R[3] * p[0] + R[4] * p[1] + R[5] * p[2],
+           c = R[6] * p[0] + R[7] * p[1] + R[8] * p[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+HD void mtv3(const double* R, const double* p, double* o) {  // o = R' p
+    double a = R[0] * p[0] + R[3] * p[1] + R[6] * p[2], b = R[1] * p[0] + R[4] * p[1] + R[7] * p[2],
+           c = R[2] * p[0] + R[5] * p[1] + R[8] * p[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+HD void cross3(const double* a, const double* b, double* o) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+HD void mm3(const double* A, const double* B, double* C) {   // C = A B (3x3 row major)
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+HD void mtm3(const double* A, const double* B, double* C) {  // C = A' B
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+HD void inv3(const double* A, double* Ai) {
+    double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+    double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
+    Ai[0] = c0 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = c1 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// ------------------------------------------------------------------ link constants -> lane registers
+HD void lane_load_consts(LaneRegs& r, const MechDev* M, int l) {
+    r.m = M->m[l];
+    for (int i = 0; i < 9; i++) r.J[i] = M->J[l][i];
+    for (int i = 0; i < 3; i++) { r.p1[i] = M->p1[l][i]; r.p2[i] = M->p2[l][i]; r.axis[i] = M->axis[l][i]; }
+    for (int i = 0; i < 4; i++) r.qoc[i] = M->qoc[l][i];
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 3; j++) r.sel[i][j] = M->sel[l][i][j];
+    r.parent = M->parent[l]; r.childl = M->childl[l]; r.rotmask = M->rotmask[l]; r.type = M->type[l];
+    for (int i = 0; i < 3; i++) { r.cT[i] = 0; r.cR[i] = 0; }
+}
+
+// ------------------------------------------------------------------ joint: g and d g/d(x, phi) for both bodies
+// translational  R(qa)'(xb + R(qb) p2 - xa) - p1 ; rotational vec(qa^-1 qb qoff^-1); rows picked by sel/rotmask.
+// Ba/Bb (5x6 row major, row stride 6): [dg/dx * sx , (dg/dphi) * Nside]  where N = 3x3 (nullptr = identity)
+HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const double* xb, const double* qb, bool has_a,
+                   double sx, const double* Na, const double* Nb, double* g, double* Ba, double* Bb) {
+    double Ra[9], Rb[9], rp[3], w[3], RaTw[3], gT[3];
+    rotmat(qa, Ra); rotmat(qb, Rb);
+    mv3(Rb, r.p2, rp);
+    for (int i = 0; i < 3; i++) w[i] = xb[i] + rp[i] - xa[i];
+    mtv3(Ra, w, RaTw);
+    for (int i = 0; i < 3; i++) gT[i] = RaTw[i] - r.p1[i];
+    double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
+    qmul(qac, qb, rel);
+    qmul(rel, r.qoc, e);
+    // child side 3x3s:  XT_b = Ra' ; PT_b = -2 Ra' Rb [p2]x ; PR_b = V L(rel) R(qoc) V'
+    double RaTRb[9], PTb[9], PRb[9];
+    mtm3(Ra, Rb, RaTRb);
+    {   // M [p]x : column c of M[p]x = M (e_c-th column of [p]x);  [p]x = [0 -pz py; pz 0 -px; -py px 0]
+        const double* p = r.p2;
+        for (int i = 0; i < 3; i++) {
+            double a = RaTRb[i * 3], b = RaTRb[i * 3 + 1], c = RaTRb[i * 3 + 2];
+            PTb[i * 3 + 0] = -2.0 * (b * p[2] - c * p[1]);
+            PTb[i * 3 + 1] = -2.0 * (c * p[0] - a * p[2]);
+            PTb[i * 3 + 2] = -2.0 * (a * p[1] - b * p[0]);
+        }
+    }
+    {   // rows 1..3, cols 1..3 of L(rel) R(qoc)
+        double s = rel[0], x = rel[1], y = rel[2], z = rel[3];
+        double os = r.qoc[0], ox = r.qoc[1], oy = r.qoc[2], oz = r.qoc[3];
+        // L(rel) rows 1..3: [x s -z y; y z s -x; z -y x s] ; R(qoc) cols 1..3: [-ox -oy -oz; os oz -oy; -oz os ox; oy -ox os]
+        double Lr[3][4] = {{x, s, -z, y}, {y, z, s, -x}, {z, -y, x, s}};
+        double Rc[4][3] = {{-ox, -oy, -oz}, {os, oz, -oy}, {-oz, os, ox}, {oy, -ox, os}};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) PRb[i * 3 + j] = Lr[i][0] * Rc[0][j] + Lr[i][1] * Rc[1][j] + Lr[i][2] * Rc[2][j] + Lr[i][3] * Rc[3][j];
+    }
+    // parent side 3x3s: XT_a = -Ra' ; PT_a = 2 [Ra'w]x ; PR_a = -(e_s I - [e_v]x)
+    double PTa[9] = {0, -2 * RaTw[2], 2 * RaTw[1], 2 * RaTw[2], 0, -2 * RaTw[0], -2 * RaTw[1], 2 * RaTw[0], 0};
+    double PRa[9] = {-e[0], -e[3], e[2], e[3], -e[0], -e[1], -e[2], e[1], -e[0]};
+    for (int row = 0; row < 5; row++) {
+        bool rot = (r.rotmask >> row) & 1;
+        double s0 = r.sel[row][0], s1 = r.sel[row][1], s2 = r.sel[row][2];
+        double vT = s0 * gT[0] + s1 * gT[1] + s2 * gT[2];
+        double vR = s0 * e[1] + s1 * e[2] + s2 * e[3];
+        g[row] = rot ? vR : vT;
+        double xb3[3], pb3[3], pa3[3];
+        for (int c = 0; c < 3; c++) {
+            // sel' Ra'  = (Ra sel)' : component c = sum_i sel[i] Ra[c][i]
+            double xt = s0 * Ra[c * 3] + s1 * Ra[c * 3 + 1] + s2 * Ra[c * 3 + 2];
+            xb3[c] = rot ? 0.0 : xt;
+            double ptb = s0 * PTb[c] + s1 * PTb[3 + c] + s2 * PTb[6 + c];
+            double prb = s0 * PRb[c] + s1 * PRb[3 + c] + s2 * PRb[6 + c];
+            pb3[c] = rot ? prb : ptb;
+            double pta = s0 * PTa[c] + s1 * PTa[3 + c] + s2 * PTa[6 + c];
+            double pra = s0 * PRa[c] + s1 * PRa[3 + c] + s2 * PRa[6 + c];
+            pa3[c] = rot ? pra : pta;
+        }
+        for (int c = 0; c < 3; c++) {
+            Bb[row * 6 + c] = xb3[c] * sx;
+            Ba[row * 6 + c] = has_a ? -xb3[c] * sx : 0.0;
+            double nb_ = Nb ? (pb3[0] * Nb[c] + pb3[1] * Nb[3 + c] + pb3[2] * Nb[6 + c]) : pb3[c];
+            double na_ = Na ? (pa3[0] * Na[c] + pa3[1] * Na[3 + c] + pa3[2] * Na[6 + c]) : pa3[c];
+            Bb[row * 6 + 3 + c] = nb_;
+            Ba[row * 6 + 3 + c] = has_a ? na_ : 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ phases (t = lane index inside the group)
+static const double QID_[4] = {1.0, 0.0, 0.0, 0.0};
+
+// C1: control error of link t into DZ (order x, v, qtilde, w: lqr.jl:92-95) and passive friction into UJ
+HD void ph_control_error(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, const CtrlDev* C, const double* zd) {
+    if (t >= nb) return;
+    const double* z = L + Y.Z + 13 * t;
+    const double* d = zd + 13 * t;
+    double qdc[4] = {d[3], -d[4], -d[5], -d[6]}, qe[4];
+    qmul(qdc, z + 3, qe);   // qd \ q : raw vector part, no sign fix, no factor 2 (lqr.jl:101-102)
+    double* dz = L + Y.DZ + 12 * t;
+    for (int i = 0; i < 3; i++) {
+        dz[i] = z[i] - d[i]; dz[3 + i] = z[7 + i] - d[7 + i]; dz[6 + i] = qe[1 + i]; dz[9 + i] = z[10 + i] - d[10 + i];
+    }
+    double u = 0.0;
+    if (C->has_fric && C->fric[t] != 0.0) {   // trackingLQR_triple_cartpole.jl:93-101
+        int a = r.parent;
+        double rel;
+        if (r.type == 0) {
+            rel = r.axis[0] * z[10] + r.axis[1] * z[11] + r.axis[2] * z[12];
+            if (a >= 0) { const double* za = L + Y.Z + 13 * a; rel -= r.axis[0] * za[10] + r.axis[1] * za[11] + r.axis[2] * za[12]; }
+        } else {
+            double dv[3], dva[3], Ra[9];
+            const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
+            for (int i = 0; i < 3; i++) dv[i] = z[7 + i] - (za ? za[7 + i] : 0.0);
+            rotmat(za ? za + 3 : QID_, Ra);
+            mtv3(Ra, dv, dva);
+            rel = r.axis[0] * dva[0] + r.axis[1] * dva[1] + r.axis[2] * dva[2];
+        }
+        u = -C->fric[t] * rel;
+    }
+    L[Y.UJ + t] = u;
+}
+
+// C2: partial dot product  sum_{t, t+G, ...} K[i][.] * DZ[.]  (caller reduces over the group)
+HD double ph_gain_partial(int t, int G, int nb, const Lay& Y, const double* L, const double* Krow) {
+    double s = 0.0;
+    for (int c = t; c < 12 * nb; c += G) s += Krow[c] * L[Y.DZ + c];
+    return s;
+}
+
+// F1: joint inputs -> force/torque on the owned body, per-step invariants, solution guess (SURVEY 8a-bis 'Joint input')
+HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M) {
+    if (t >= nb) return;
+    const double dt = M->dt;
+    const double* z = L + Y.Z + 13 * t;
+    double F[3] = {0, 0, 0}, tau[3] = {0, 0, 0};
+    double Rb[9];
+    rotmat(z + 3, Rb);
+    double u = L[Y.UJ + t];
+    if (u != 0.0) {   // own joint: this body is the child
+        double Ra[9], f[3] = {r.axis[0] * u, r.axis[1] * u, r.axis[2] * u}, fw[3], fb[3];
+        rotmat(r.parent >= 0 ? L + Y.Z + 13 * r.parent + 3 : QID_, Ra);
+        mv3(Ra, f, fw); mtv3(Rb, fw, fb);
+        if (r.type == 1) { double c[3]; cross3(r.p2, fb, c); for (int i = 0; i < 3; i++) { F[i] += fw[i]; tau[i] += c[i]; } }
+        else for (int i = 0; i < 3; i++) tau[i] += fb[i];
+    }
+    int c = r.childl;
+    if (c >= 0) {     // child joint: this body is the parent
+        double uc = L[Y.UJ + c];
+        if (uc != 0.0) {
+            double f[3] = {M->axis[c][0] * uc, M->axis[c][1] * uc, M->axis[c][2] * uc};
+            if (M->type[c] == 1) {
+                double fw[3], cr[3];
+                mv3(Rb, f, fw); cross3(M->p1[c], f, cr);
+                for (int i = 0; i < 3; i++) { F[i] -= fw[i]; tau[i] -= cr[i]; }
+            } else for (int i = 0; i < 3; i++) tau[i] -= f[i];
+        }
+    }
+    const double* v1 = z + 7; const double* w1 = z + 10;
+    double sq1 = sqrt(4.0 / (dt * dt) - (w1[0] * w1[0] + w1[1] * w1[1] + w1[2] * w1[2]));
+    double Jw1[3], c1[3];
+    mv3(r.J, w1, Jw1); cross3(w1, Jw1, c1);
+    for (int i = 0; i < 3; i++) {
+        r.cT[i] = r.m * (-v1[i] / dt + (i == 2 ? -M->g : 0.0)) - F[i];
+        r.cR[i] = -(sq1 * Jw1[i] - c1[i]) - 2.0 * tau[i];
+        L[Y.S + 6 * t + i] = v1[i]; L[Y.S + 6 * t + 3 + i] = w1[i];
+    }
+    L[Y.DTM + t] = dt / r.m;
+}
+
+// F2: constraint Jacobians at the current knot (force mapping G_k)
+HD void ph_knot_jac(int t, int nb, const Lay& Y, double* L, const LaneRegs& r) {
+    if (t >= nb) return;
+    int a = r.parent;
+    const double X0[3] = {0, 0, 0};
+    const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
+    const double* zb = L + Y.Z + 13 * t;
+    double g[5];
+    joint_eval(r, za ? za : X0, za ? za + 3 : QID_, zb, zb + 3, a >= 0, 1.0, nullptr, nullptr, g, L + Y.GKA + BLK * t, L + Y.GKB + BLK * t);
+}
+
+// E1: body t at the trial solution s: next pose, N, dynamics residual (without G'lambda), D_R^-1
+HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt, int s_off) {
+    if (t >= nb) return;
+    const double* z = L + Y.Z + 13 * t;
+    const double* s = L + s_off + 6 * t;
+    const double* w2 = s + 3;
+    double* xq = L + Y.XQ + 7 * t;
+    for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
+    double sq2 = sqrt(4.0 / (dt * dt) - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
+    double wb[4] = {0.5 * dt * sq2, 0.5 * dt * w2[0], 0.5 * dt * w2[1], 0.5 * dt * w2[2]};
+    qmul(z + 3, wb, xq + 3);
+    double Jw2[3], c2[3];
+    mv3(r.J, w2, Jw2); cross3(w2, Jw2, c2);
+    double* d = L + Y.D + 6 * t;
+    for (int i = 0; i < 3; i++) { d[i] = r.m * s[i] / dt + r.cT[i]; d[3 + i] = sq2 * Jw2[i] + c2[i] + r.cR[i]; }
+    // D_R = (sq2 I + [w2]x) J - [J w2]x - (J w2) w2'/sq2
+    double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2}, SJ[9], Dr[9];
+    mm3(S, r.J, SJ);
+    double isq = 1.0 / sq2;
+    double Sj[9] = {0, -Jw2[2], Jw2[1], Jw2[2], 0, -Jw2[0], -Jw2[1], Jw2[0], 0};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Dr[i * 3 + j] = SJ[i * 3 + j] - Sj[i * 3 + j] - Jw2[i] * w2[j] * isq;
+    inv3(Dr, L + Y.DINV + 9 * t);
+    // N = (dt^2/4)(sq2 I - [w2]x + w2 w2'/sq2):  d phi+ = N d w+
+    double* N = L + Y.NB + 9 * t;
+    double k = 0.25 * dt * dt;
+    N[0] = k * (sq2 + w2[0] * w2[0] * isq); N[1] = k * (w2[2] + w2[0] * w2[1] * isq);  N[2] = k * (-w2[1] + w2[0] * w2[2] * isq);
+    N[3] = k * (-w2[2] + w2[1] * w2[0] * isq); N[4] = k * (sq2 + w2[1] * w2[1] * isq); N[5] = k * (w2[0] + w2[1] * w2[2] * isq);
+    N[6] = k * (w2[1] + w2[2] * w2[0] * isq);  N[7] = k * (-w2[0] + w2[2] * w2[1] * isq); N[8] = k * (sq2 + w2[2] * w2[2] * isq);
+}
+
+// E2: joint t at the next knot: g and G_v = [X dt, Phi N]
+HD void ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt) {
+    if (t >= nb) return;
+    int a = r.parent;
+    const double X0[3] = {0, 0, 0};
+    const double* pa = (a >= 0) ? L + Y.XQ + 7 * a : nullptr;
+    const double* pb = L + Y.XQ + 7 * t;
+    joint_eval(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, dt, (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * t,
+               L + Y.G + 5 * t, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
+}
+
+// E3: d -= G_k' lambda (lambda at lam_off) and partial sum of squares of the residual entries this lane touches
+HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M, int lam_off) {
+    double acc = 0.0;
+    for (int e = t; e < 6 * nb; e += G) {
+        int b = e / 6, c = e - 6 * b;
+        const double* Gb = L + Y.GKB + BLK * b;
+        const double* lb = L + lam_off + 5 * b;
+        double s = Gb[c] * lb[0] + Gb[6 + c] * lb[1] + Gb[12 + c] * lb[2] + Gb[18 + c] * lb[3] + Gb[24 + c] * lb[4];
+        int ch = M->childl[b];
+        if (ch >= 0) {
+            const double* Ga = L + Y.GKA + BLK * ch;
+            const double* lc = L + lam_off + 5 * ch;
+            s += Ga[c] * lc[0] + Ga[6 + c] * lc[1] + Ga[12 + c] * lc[2] + Ga[18 + c] * lc[3] + Ga[24 + c] * lc[4];
+        }
+        double d = L[Y.D + e] - s;
+        L[Y.D + e] = d;
+        acc += d * d;
+    }
+    for (int e = t; e < 5 * nb; e += G) { double g = L[Y.G + e]; acc += g * g; }
+    return acc;
+}
+
+// S1: W = G_v D^-1 in place (rows of both sides): [Gv_x * dt/m , Gv_phi * D_R^-1]
+HD void ph_schur_w(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    for (int e = t; e < 10 * nb; e += G) {
+        int j = e / 10, rr = e - 10 * j, side = rr / 5, row = rr - 5 * side;
+        int body = side ? j : M->parent[j];
+        if (body < 0) continue;
+        double* w = L + (side ? Y.GVB : Y.GVA) + BLK * j + 6 * row;
+        double dtm = L[Y.DTM + body];
+        const double* Di = L + Y.DINV + 9 * body;
+        double a = w[3], b = w[4], c = w[5];
+        w[0] *= dtm; w[1] *= dtm; w[2] *= dtm;
+        w[3] = a * Di[0] + b * Di[3] + c * Di[6];
+        w[4] = a * Di[1] + b * Di[4] + c * Di[7];
+        w[5] = a * Di[2] + b * Di[5] + c * Di[8];
+    }
+}
+
+HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+
+// S2: Schur complement blocks and right-hand side
+//   S_jj = W_b Gk_b' + W_a Gk_a' ; S_jp = W_a(j) Gk_b(p)' ; S_pj = W_b(p) Gk_a(j)' ; r_j = g_j - W_b d_b - W_a d_a
+HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    for (int e = t; e < 25 * nb; e += G) {
+        int j = e / 25, rc = e - 25 * j, row = rc / 5, col = rc - 5 * row;
+        int p = M->parent[j];
+        const double* Wb = L + Y.GVB + BLK * j + 6 * row;
+        double s = dot6(Wb, L + Y.GKB + BLK * j + 6 * col);
+        if (p >= 0) {
+            const double* Wa = L + Y.GVA + BLK * j + 6 * row;
+            s += dot6(Wa, L + Y.GKA + BLK * j + 6 * col);
+            L[Y.SJP + e] = dot6(Wa, L + Y.GKB + BLK * p + 6 * col);
+            L[Y.SPJ + e] = dot6(L + Y.GVB + BLK * p + 6 * row, L + Y.GKA + BLK * j + 6 * col);
+        }
+        L[Y.SJJ + e] = s;
+    }
+    for (int e = t; e < 5 * nb; e += G) {
+        int j = e / 5, row = e - 5 * j;
+        int p = M->parent[j];
+        double s = L[Y.G + e] - dot6(L + Y.GVB + BLK * j + 6 * row, L + Y.D + 6 * j);
+        if (p >= 0) s -= dot6(L + Y.GVA + BLK * j + 6 * row, L + Y.D + 6 * p);
+        L[Y.R + e] = s;
+    }
+}
+
+// S3a: eliminate link l into its parent (lanes t < 5, each owns one row).  LU (no pivoting; S is SPD-like) of S_ll is
+// computed redundantly by the 5 lanes; lane t keeps row t of the packed LU (unit L, reciprocal diagonal) in lu[5].
+HD void ph_tri_fwd(int t, int l, const Lay& Y, double* L, const MechDev* M, double* lu) {
+    if (t >= 5) return;
+    double A[25];
+    for (int i = 0; i < 25; i++) A[i] = L[Y.SJJ + 25 * l + i];
+    for (int k = 0; k < 5; k++) {
+        double inv = 1.0 / A[k * 5 + k];
+        A[k * 5 + k] = inv;
+        for (int i = k + 1; i < 5; i++) {
+            double f = A[i * 5 + k] * inv;
+            A[i * 5 + k] = f;
+            for (int j = k + 1; j < 5; j++) A[i * 5 + j] -= f * A[k * 5 + j];
+        }
+    }
+    for (int j = 0; j < 5; j++) lu[j] = A[t * 5 + j];
+    int p = M->parent[l];
+    if (p < 0) return;
+    // row t of T = S_pl S_ll^-1:  x U = b (columns ascending), then y L = x (columns descending)
+    double x[5];
+    for (int c = 0; c < 5; c++) {
+        double s = L[Y.SPJ + 25 * l + 5 * t + c];
+        for (int k = 0; k < c; k++) s -= x[k] * A[k * 5 + c];
+        x[c] = s * A[c * 5 + c];
+    }
+    for (int c = 4; c >= 0; c--) {
+        double s = x[c];
+        for (int k = c + 1; k < 5; k++) s -= x[k] * A[k * 5 + c];
+        x[c] = s;
+    }
+    const double* Slp = L + Y.SJP + 25 * l;
+    for (int c = 0; c < 5; c++)
+        L[Y.SJJ + 25 * p + 5 * t + c] -= x[0] * Slp[c] + x[1] * Slp[5 + c] + x[2] * Slp[10 + c] + x[3] * Slp[15 + c] + x[4] * Slp[20 + c];
+    const double* rl = L + Y.R + 5 * l;
+    L[Y.R + 5 * p + t] -= x[0] * rl[0] + x[1] * rl[1] + x[2] * rl[2] + x[3] * rl[3] + x[4] * rl[4];
+}
+// S3b: store the packed LU of link l (lane t writes row t)
+HD void ph_tri_store(int t, int l, const Lay& Y, double* L, const double* lu) {
+    if (t >= 5) return;
+    for (int j = 0; j < 5; j++) L[Y.SJJ + 25 * l + 5 * t + j] = lu[j];
+}
+// S3c: back substitution for link l (root to leaf): dl_l = S_ll^-1 (r_l - S_lp dl_p); lane t writes component t
+HD void ph_tri_bwd(int t, int l, const Lay& Y, double* L, const MechDev* M) {
+    if (t >= 5) return;
+    double A[25], b[5];
+    for (int i = 0; i < 25; i++) A[i] = L[Y.SJJ + 25 * l + i];
+    int p = M->parent[l];
+    for (int i = 0; i < 5; i++) {
+        double s = L[Y.R + 5 * l + i];
+        if (p >= 0) {
+            const double* Sr = L + Y.SJP + 25 * l + 5 * i;
+            const double* dp = L + Y.DL + 5 * p;
+            s -= Sr[0] * dp[0] + Sr[1] * dp[1] + Sr[2] * dp[2] + Sr[3] * dp[3] + Sr[4] * dp[4];
+        }
+        b[i] = s;
+    }
+    for (int i = 1; i < 5; i++)
+        for (int k = 0; k < i; k++) b[i] -= A[i * 5 + k] * b[k];
+    for (int i = 4; i >= 0; i--) {
+        for (int k = i + 1; k < 5; k++) b[i] -= A[i * 5 + k] * b[k];
+        b[i] *= A[i * 5 + i];
+    }
+    L[Y.DL + 5 * l + t] = b[t];
+}
+
+// S4: ds_b = D_b^-1 (d_b + sum_j Gk_jb' dl_j)
+HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    for (int e = t; e < 6 * nb; e += G) {
+        int b = e / 6, c = e - 6 * b;
+        int ch = M->childl[b];
+        double tv[3];
+        int c0 = (c < 3) ? c : 3, n = (c < 3) ? 1 : 3;
+        for (int q = 0; q < n; q++) {
+            int cc = c0 + q;
+            const double* Gb = L + Y.GKB + BLK * b;
+            const double* lb = L + Y.DL + 5 * b;
+            double s = L[Y.D + 6 * b + cc] + Gb[cc] * lb[0] + Gb[6 + cc] * lb[1] + Gb[12 + cc] * lb[2] + Gb[18 + cc] * lb[3] + Gb[24 + cc] * lb[4];
+            if (ch >= 0) {
+                const double* Ga = L + Y.GKA + BLK * ch;
+                const double* lc = L + Y.DL + 5 * ch;
+                s += Ga[cc] * lc[0] + Ga[6 + cc] * lc[1] + Ga[12 + cc] * lc[2] + Ga[18 + cc] * lc[3] + Ga[24 + cc] * lc[4];
+            }
+            tv[q] = s;
+        }
+        if (c < 3) L[Y.DS + e] = tv[0] * L[Y.DTM + b];
+        else {
+            const double* Di = L + Y.DINV + 9 * b + 3 * (c - 3);
+            L[Y.DS + e] = Di[0] * tv[0] + Di[1] * tv[1] + Di[2] * tv[2];
+        }
+    }
+}
+
+// T1: trial point  st = s - alpha ds ; lt = lam - alpha dl ; returns partial ||(ds, dl)||^2
+HD double ph_trial(int t, int G, int nb, const Lay& Y, double* L, double alpha) {
+    double acc = 0.0;
+    for (int e = t; e < 6 * nb; e += G) { double d = L[Y.DS + e]; L[Y.ST + e] = L[Y.S + e] - alpha * d; acc += d * d; }
+    for (int e = t; e < 5 * nb; e += G) { double d = L[Y.DL + e]; L[Y.LT + e] = L[Y.LAM + e] - alpha * d; acc += d * d; }
+    return acc;
+}
+HD void ph_accept(int t, int G, int nb, const Lay& Y, double* L) {
+    for (int e = t; e < 6 * nb; e += G) L[Y.S + e] = L[Y.ST + e];
+    for (int e = t; e < 5 * nb; e += G) L[Y.LAM + e] = L[Y.LT + e];
+}
+// U1: state update from the accepted solution (XQ holds its next pose)
+HD void ph_update(int t, int nb, const Lay& Y, double* L) {
+    if (t >= nb) return;
+    double* z = L + Y.Z + 13 * t;
+    for (int i = 0; i < 7; i++) z[i] = L[Y.XQ + 7 * t + i];
+    for (int i = 0; i < 6; i++) z[7 + i] = L[Y.S + 6 * t + i];
+}
+
+}  // namespace cclqr

@@ -1,0 +1,71 @@
+// cclqr_internal.h -- host-side handles and kernel launch arguments shared by the translation units of libcclqr.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "cclqr_dev.h"
+
+#define CCLQR_ESINGULAR_ (-2)
+
+namespace cclqr {
+
+struct RolloutArgs {
+    const MechDev* M;
+    const CtrlDev* C;
+    int64_t n_inst;
+    int steps, k0;
+    const double* z0;     // [n_inst][nb][13] user body order
+    double* lam;          // [n_inst][5 nb] internal order, or null
+    const double* noise;  // [n_inst][noise_stride] or null
+    int64_t noise_stride;
+    double* traj;         // [n_inst][steps][nb][13] or null
+    double* zT;           // [n_inst][nb][13]
+    int* status;          // [n_inst] or null
+};
+
+int rollout_lanes_per_instance(int nb);
+size_t rollout_lds_bytes(int nb);
+hipError_t launch_rollout(const RolloutArgs& a, int nb, hipStream_t stream);
+
+struct LinArgs {
+    const MechDev* M;
+    int nk, mu;
+    int cj[CCLQR_MAXL];      // controlled links (internal)
+    const double* zd;        // [nk][nb][13] internal link order
+    const double* Fd;        // [nk][mu]
+    double *A, *Bu, *Bl, *G; // [nk][...] internal link order
+    int* status;             // [nk]
+};
+size_t linearize_lds_bytes(int nb);
+hipError_t launch_linearize(const LinArgs& a, int nb, hipStream_t stream);
+
+struct RicArgs {
+    int nprob, mx, mu, ml, N;
+    int time_varying;        // 1: A,Bu,Bl,G are [N-1][...] per problem (knot k uses index k-1)
+    double tol;
+    const double *A, *Bu, *Bl, *G, *Q, *R;
+    double* K;               // [nprob][N-1][mu][mx]
+    int* kbreak;             // [nprob]
+    int* status;             // [nprob]
+    double* work;            // [nprob][ric_work_doubles]
+};
+size_t ric_work_doubles(int mx, int mu, int ml);
+hipError_t launch_riccati(const RicArgs& a, hipStream_t stream);
+
+}  // namespace cclqr
+
+// opaque handles of include/cclqr.h
+struct cclqr_mech {
+    cclqr::MechDev host;       // internal link order
+    cclqr::MechDev* dev;
+    int nb;
+    int link_of_body[CCLQR_MAXL];   // user body  -> internal link
+    int link_of_joint[CCLQR_MAXL];  // user joint -> internal link (= link of its child body)
+    int device;
+};
+struct cclqr_ctrl {
+    cclqr::CtrlDev host;
+    cclqr::CtrlDev* dev;
+    double *K_dev, *zd_dev, *Fd_dev;
+    int nb;
+};

@@ -1,0 +1,120 @@
+// cclqr_tables.h -- host-only: validation of a cclqr_mech_desc / cclqr_ctrl_desc and the index permutations between the
+// caller's body/joint numbering and the kernels' breadth-first link order.  No dynamics arithmetic happens here.
+#pragma once
+#include "../../include/cclqr.h"
+#include "cclqr_internal.h"
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace cclqr {
+
+// two unit rows orthogonal to the unit axis (same deterministic choice as the oracle; any basis gives the same trajectory)
+static inline void orth_rows(const double* a, double* V12) {
+    int e = 0;
+    double best = fabs(a[0]);
+    for (int i = 1; i < 3; i++) if (fabs(a[i]) < best) { best = fabs(a[i]); e = i; }
+    double v1[3] = {0, 0, 0};
+    v1[e] = 1.0;
+    double d = a[e];
+    for (int i = 0; i < 3; i++) v1[i] -= d * a[i];
+    double n = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+    for (int i = 0; i < 3; i++) v1[i] /= n;
+    V12[0] = v1[0]; V12[1] = v1[1]; V12[2] = v1[2];
+    V12[3] = a[1] * v1[2] - a[2] * v1[1]; V12[4] = a[2] * v1[0] - a[0] * v1[2]; V12[5] = a[0] * v1[1] - a[1] * v1[0];
+}
+
+
+// fills m->host, m->nb, m->link_of_*; returns CCLQR_OK or an error code with a message in err
+static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std::string& err) {
+    const int nb = d->nb;
+    if (nb < 1 || d->ne != nb) { err = "need ne == nb >= 1 (tree with one 1-DoF joint per body)"; return CCLQR_EINVAL; }
+    if (nb > CCLQR_MAXL) { err = "more than 32 bodies"; return CCLQR_EUNSUPPORTED; }
+    if (!(d->dt > 0)) { err = "dt must be positive"; return CCLQR_EINVAL; }
+    std::vector<int> pj(nb, -1), nchild(nb, 0);
+    for (int j = 0; j < nb; j++) {
+        int a = d->parent[j], b = d->child[j];
+        if (b < 0 || b >= nb || a < -1 || a >= nb || a == b) { err = "joint references a body out of range"; return CCLQR_EINVAL; }
+        if (pj[b] != -1) { err = "a body is the child of two joints (closed loop)"; return CCLQR_EUNSUPPORTED; }
+        pj[b] = j;
+        if (a >= 0) nchild[a]++;
+        if (d->type[j] != CCLQR_REVOLUTE && d->type[j] != CCLQR_PRISMATIC) { err = "unknown joint type"; return CCLQR_EINVAL; }
+    }
+    for (int b = 0; b < nb; b++)
+        if (nchild[b] > 1) { err = "a body with more than one child joint (branching tree) is not supported yet"; return CCLQR_EUNSUPPORTED; }
+    std::vector<int> bfs;
+    for (int j = 0; j < nb; j++) if (d->parent[j] == -1) bfs.push_back(d->child[j]);
+    for (size_t h = 0; h < bfs.size(); h++)
+        for (int j = 0; j < nb; j++) if (d->parent[j] == bfs[h]) bfs.push_back(d->child[j]);
+    if ((int)bfs.size() != nb) { err = "mechanism is not a tree rooted at the origin"; return CCLQR_EINVAL; }
+
+    memset(&m->host, 0, sizeof(MechDev));
+    m->nb = nb;
+    MechDev& H = m->host;
+    H.nb = nb; H.dt = d->dt; H.g = d->g;
+    for (int l = 0; l < nb; l++) m->link_of_body[bfs[l]] = l;
+    for (int l = 0; l < nb; l++) {
+        int b = bfs[l], j = pj[b];
+        m->link_of_joint[j] = l;
+        H.perm[l] = b;
+        H.jperm[l] = j;
+        H.parent[l] = d->parent[j] >= 0 ? m->link_of_body[d->parent[j]] : -1;
+        H.childl[l] = -1;
+        H.type[l] = d->type[j];
+        H.m[l] = d->mass[b];
+        for (int i = 0; i < 9; i++) H.J[l][i] = d->inertia[9 * b + i];
+        double ax[3] = {d->axis[3 * j], d->axis[3 * j + 1], d->axis[3 * j + 2]};
+        double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        if (n == 0.0 || !(H.m[l] > 0)) { err = "zero joint axis or non-positive mass"; return CCLQR_EINVAL; }
+        for (int i = 0; i < 3; i++) { ax[i] /= n; H.axis[l][i] = ax[i]; H.p1[l][i] = d->p1[3 * j + i]; H.p2[l][i] = d->p2[3 * j + i]; }
+        H.qoc[l][0] = d->qoff[4 * j];
+        for (int i = 1; i < 4; i++) H.qoc[l][i] = -d->qoff[4 * j + i];
+        double V12[6];
+        orth_rows(ax, V12);
+        const int nt = (d->type[j] == CCLQR_REVOLUTE) ? 3 : 2;   // Revolute = Translational3 + Rotational2, Prismatic = Translational2 + Rotational3
+        H.rotmask[l] = 0;
+        for (int r = 0; r < 5; r++) {
+            bool rot = r >= nt;
+            int q = rot ? r - nt : r, nrows = rot ? 5 - nt : nt;
+            if (rot) H.rotmask[l] |= 1 << r;
+            for (int i = 0; i < 3; i++) H.sel[l][r][i] = (nrows == 3) ? (i == q ? 1.0 : 0.0) : V12[3 * q + i];
+        }
+    }
+    for (int l = 0; l < nb; l++) if (H.parent[l] >= 0) H.childl[H.parent[l]] = l;
+    return CCLQR_OK;
+}
+
+// host images of the controller tables in internal link order (K columns, setpoints, controlled links, friction)
+struct CtrlHostTables {
+    CtrlDev H;
+    std::vector<double> K, zd, Fd;
+};
+static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* d, CtrlHostTables& T, std::string& err) {
+    const int nb = m->nb, mx = 12 * nb;
+    if (d->mu < 0 || d->mu > nb) { err = "Missmatched length for constraints"; return CCLQR_EINVAL; }
+    if (d->nsp < 1 || !d->zd) { err = "Missmatched length for bodies"; return CCLQR_EINVAL; }
+    if (d->K && d->nK < 1) { err = "gain table without entries"; return CCLQR_EINVAL; }
+    CtrlDev& H = T.H;
+    memset(&H, 0, sizeof(H));
+    H.mu = d->mu; H.nK = d->K ? d->nK : 0; H.N = d->N; H.nsp = d->nsp; H.noise_scale = d->noise_scale;
+    for (int i = 0; i < d->mu; i++) {
+        int j = d->ctrl_joint[i];
+        if (j < 0 || j >= nb) { err = "controlled joint out of range"; return CCLQR_EINVAL; }
+        H.cj[i] = m->link_of_joint[j];
+    }
+    if (d->fric)
+        for (int j = 0; j < nb; j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
+    T.zd.resize((size_t)d->nsp * nb * 13);
+    for (int s = 0; s < d->nsp; s++)
+        for (int l = 0; l < nb; l++) memcpy(&T.zd[((size_t)s * nb + l) * 13], d->zd + ((size_t)s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
+    if (d->K) {
+        T.K.resize((size_t)d->nK * d->mu * mx);
+        for (size_t row = 0; row < (size_t)d->nK * d->mu; row++)
+            for (int l = 0; l < nb; l++) memcpy(&T.K[row * mx + 12 * l], d->K + row * mx + 12 * m->host.perm[l], 12 * sizeof(double));
+    }
+    if (d->Fd && d->mu > 0) T.Fd.assign(d->Fd, d->Fd + (size_t)d->nsp * d->mu);
+    return CCLQR_OK;
+}
+
+}  // namespace cclqr

@@ -1,0 +1,119 @@
+// rollout.hip -- the LQR-controlled rollout kernel (simulate! + control_lqr!/control_trackinglqr! fused),
+// persistent over the whole horizon: state, multipliers and all Jacobian blocks of an instance stay in LDS;
+// HBM sees one state load, one gain row per step, one trajectory row per step (if recorded) and the final state.
+//
+// Replaces: ConstrainedDynamics.simulate!/newton! as driven by the reference (examples/lqr_cartpole.jl:44) with
+//           control_lqr! (src/control/lqr.jl:89-139) / control_trackinglqr! (src/control/lqr_tracking.jl:46-71).
+#include "cclqr_dev.h"
+#include "cclqr_internal.h"
+#include "cclqr_newton.h"
+
+namespace cclqr {
+
+template <int G>
+__global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, t = lane % G, grp = lane / G;
+    const int64_t inst = (int64_t)blockIdx.x * (64 / G) + grp;
+    const bool valid = inst < a.n_inst;
+    const MechDev* M = a.M;
+    const CtrlDev* C = a.C;
+    const int nb = M->nb;
+    const double dt = M->dt;
+    const Lay Y = make_layout(nb);
+    double* L = lds + grp * Y.total;
+    const int nz = 13 * nb;
+
+    LaneRegs r;
+    lane_load_consts(r, M, t < nb ? t : 0);
+
+    if (valid) {
+        for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = a.z0[inst * nz + M->perm[l] * 13 + c]; }
+        for (int e = t; e < 5 * nb; e += G) L[Y.LAM + e] = (a.lam && a.k0 > 1) ? a.lam[inst * 5 * nb + e] : 0.0;
+    } else {
+        for (int e = t; e < Y.total; e += G) L[e] = 0.0;
+        for (int e = t; e < nb; e += G) L[Y.Z + 13 * e + 3] = 1.0;
+    }
+    __syncthreads();
+
+    int worst = 0;
+    bool bad = false;
+    for (int kk = 0; kk < a.steps; kk++) {
+        const int k = a.k0 + kk;
+        if (a.traj && valid)
+            for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.traj[((size_t)inst * a.steps + kk) * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
+
+        // ---------------- feedback law (lqr.jl:89-139 / lqr_tracking.jl:46-71)
+        const bool gate = (C->N <= 0) || (k < C->N);
+        const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
+        const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
+        if (gate && valid) ph_control_error(t, nb, Y, L, r, C, C->zd + (size_t)ksp * nz);
+        else if (t < nb) L[Y.UJ + t] = 0.0;
+        __syncthreads();
+        if (gate) {
+            for (int i = 0; i < C->mu; i++) {
+                double part = 0.0;
+                if (C->K && valid) part = ph_gain_partial(t, G, nb, Y, L, C->K + ((size_t)kidx * C->mu + i) * 12 * nb);
+                double s = group_sum<G>(part);
+                if (t == 0 && valid) {
+                    double u = (C->Fd ? C->Fd[(size_t)ksp * C->mu + i] : 0.0) - s;
+                    if (a.noise && C->noise_scale != 0.0) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
+                    L[Y.UJ + C->cj[i]] += u;
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------- per-step invariants
+        ph_forces(t, nb, Y, L, r, M);
+        ph_knot_jac(t, nb, Y, L, r);
+        __syncthreads();
+
+        // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
+        bool done = false;
+        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid, &done);
+        if (valid) { if (!done) bad = true; if (its > worst) worst = its; }
+        if (valid) ph_update(t, nb, Y, L);
+        __syncthreads();
+    }
+    if (valid) {
+        for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.zT[inst * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
+        if (a.lam) for (int e = t; e < 5 * nb; e += G) a.lam[inst * 5 * nb + e] = L[Y.LAM + e];
+        if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
+    }
+}
+
+int rollout_lanes_per_instance(int nb) { return nb <= 4 ? 16 : (nb <= 8 ? 32 : 64); }
+
+size_t rollout_lds_bytes(int nb) {
+    int G = rollout_lanes_per_instance(nb);
+    return (size_t)(64 / G) * make_layout(nb).total * sizeof(double);
+}
+
+hipError_t launch_rollout(const RolloutArgs& a, int nb, hipStream_t stream) {
+    const int G = rollout_lanes_per_instance(nb);
+    const int per_wg = 64 / G;
+    const size_t lds = rollout_lds_bytes(nb);
+    const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
+    if (grid == 0) return hipSuccess;
+    hipError_t e;
+    switch (G) {
+        case 16:
+            e = hipFuncSetAttribute((const void*)rollout_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(rollout_kernel<16>, dim3(grid), dim3(64), lds, stream, a);
+            break;
+        case 32:
+            e = hipFuncSetAttribute((const void*)rollout_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(rollout_kernel<32>, dim3(grid), dim3(64), lds, stream, a);
+            break;
+        default:
+            e = hipFuncSetAttribute((const void*)rollout_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(rollout_kernel<64>, dim3(grid), dim3(64), lds, stream, a);
+            break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cclqr

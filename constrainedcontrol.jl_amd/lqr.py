@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's controllers.  Same constructor arguments, same assertions, same field
+meaning; the arithmetic (linearsystem, dlqr, simulate!) runs in HIP through the C-ABI (include/cclqr.h).
+
+    LQR(mechanism, bodyids, eqcids, Q, R, horizon; xd, vd, qd, ωd, Fτd)            src/control/lqr.jl:49-66
+    LQR(A, Bu, Bλ, G, Q, R, horizon, eqcids, xd, vd, qd, ωd, Fτd, Δt)              src/control/lqr.jl:17-47
+    TrackingLQR(mechanism, storage, Fτ, eqcids, Q, R)                                src/control/lqr_tracking.jl:17-43
+    simulate!(mechanism, tend | storage, controller; record)                         e.g. examples/lqr_cartpole.jl:44
+    Storage{T}(steps, Nb)                                                            examples/trackingLQR_triple_cartpole.jl:50-51
+
+What is new relative to the reference (which has no batch API): simulate(..., z0=batch) rolls out n_inst
+independent instances at once; custom `controlfunction`s cannot run on the device and are rejected.
+"""
+import math
+
+import numpy as np
+
+from . import _capi
+from .mechanism import Mechanism, one_quaternion
+
+
+def _blockdiag(blocks):
+    n = sum(b.shape[0] for b in blocks)
+    M = np.zeros((n, n))
+    o = 0
+    for b in blocks:
+        k = b.shape[0]
+        M[o:o + k, o:o + k] = b
+        o += k
+    return M
+
+
+def _pack_setpoint(nb, xd, vd, qd, ωd):
+    z = np.zeros((nb, 13))
+    for i in range(nb):
+        z[i, 0:3] = np.asarray(xd[i], dtype=np.float64).reshape(3)
+        z[i, 3:7] = np.asarray(qd[i], dtype=np.float64).reshape(4)
+        z[i, 7:10] = np.asarray(vd[i], dtype=np.float64).reshape(3)
+        z[i, 10:13] = np.asarray(ωd[i], dtype=np.float64).reshape(3)
+    return z
+
+
+def _device_mech(mechanism):
+    h = getattr(mechanism, "_cclqr_handle", None)
+    if h is None or not h.ptr:
+        h = _capi.MechHandle(mechanism.tables())
+        mechanism._cclqr_handle = h
+    return h
+
+
+class Controller:
+    """abstract type owned by ConstrainedDynamics (lqr.jl:3 `<: Controller`)"""
+
+
+class LQR(Controller):
+    """LQR{T,N,NK}: K[k][i] (1 x NK rows), xd, vd, qd, ωd, eqcids, Fτd   (lqr.jl:3-15)"""
+
+    def __init__(self, mechanism, bodyids, eqcids, Q, R, horizon, xd=None, vd=None, qd=None, ωd=None, Fτd=None, controlfunction=None, **kw):
+        if "wd" in kw:
+            ωd = kw.pop("wd")
+        if "Ftd" in kw:
+            Fτd = kw.pop("Ftd")
+        if kw:
+            raise TypeError("unexpected keyword(s): %s" % list(kw))
+        if controlfunction is not None:
+            raise NotImplementedError("custom controlfunction (lqr.jl:56) cannot run on the device; the friction/noise law of "
+                                      "examples/trackingLQR_triple_cartpole.jl is available through simulate(..., fric=, noise=)")
+        if not isinstance(mechanism, Mechanism):
+            raise TypeError("LQR(mechanism, bodyids, eqcids, Q, R, horizon; ...)")
+        nb = len(mechanism.bodies)
+        z3 = [np.zeros(3) for _ in range(nb)]
+        xd = z3 if xd is None else xd                       # lqr.jl:51-55 defaults
+        vd = z3 if vd is None else vd
+        qd = [one_quaternion() for _ in range(nb)] if qd is None else qd
+        ωd = z3 if ωd is None else ωd
+        Fτd = [np.zeros(1) for _ in range(len(eqcids))] if Fτd is None else Fτd
+        # lqr.jl:59-60
+        assert len(bodyids) == len(Q) == len(xd) == len(vd) == len(qd) == len(ωd) == nb, "Missmatched length for bodies"
+        assert len(eqcids) == len(R) == len(Fτd), "Missmatched length for constraints"
+        order = [int(b) - 1 for b in bodyids]
+        if sorted(order) != list(range(nb)):
+            raise ValueError("bodyids must name every body exactly once")
+        # state blocks follow the order of `bodyids`; the device works in mechanism body order
+        inv = np.argsort(order)
+        Q = [np.asarray(Q[i], dtype=np.float64) for i in inv]
+        xd, vd, qd, ωd = ([a[i] for i in inv] for a in (xd, vd, qd, ωd))
+        self.mechanism = mechanism
+        self.eqcids = [int(e) for e in eqcids]
+        self.ctrl_joints = [mechanism.joint_index(e) for e in self.eqcids]
+        self.xd, self.vd, self.qd, self.ωd = xd, vd, qd, ωd
+        self.Fτd = [np.asarray(f, dtype=np.float64).reshape(1) for f in Fτd]
+        self.zd = _pack_setpoint(nb, xd, vd, qd, ωd)[None]
+        self.Fd = np.array([f[0] for f in self.Fτd]).reshape(1, -1)
+        dev = _device_mech(mechanism)
+        # linearize (lqr.jl:63)
+        A, Bu, Bl, G = _capi.linearize(dev, self.zd, self.ctrl_joints, self.Fd)
+        self.A, self.Bu, self.Bλ, self.G = A[0], Bu[0], Bl[0], G[0]
+        self._finish(self.A, self.Bu, self.Bλ, self.G, Q, [np.asarray(r, dtype=np.float64) for r in R], horizon, mechanism.Δt)
+
+    def _finish(self, A, Bu, Bl, G, Q, R, horizon, Δt):
+        """LQR(A, Bu, Bλ, G, Q, R, horizon, eqcids, xd, ..., Δt)   lqr.jl:17-47"""
+        self.Q = _blockdiag(Q) * Δt                         # lqr.jl:18
+        self.R = _blockdiag(R) * Δt                         # lqr.jl:19
+        N = horizon / Δt                                    # lqr.jl:21
+        if N < math.inf:
+            N = int(math.ceil(horizon / Δt))                # lqr.jl:23
+            Ntemp = N
+        else:
+            Ntemp = int(math.ceil(10 / Δt))                 # lqr.jl:26: 10 s as maximal horizon for Inf
+        if G.shape[0] == 0 and N == math.inf:
+            # lqr.jl:33 calls dlqr(A,Bu,Q,R,N) which binds N=Inf to the Δt method of util.jl:50 — a defect, not reproduced
+            raise ValueError("unconstrained infinite-horizon LQR is not reachable in the reference (lqr.jl:33)")
+        K, kbreak = _capi.riccati(A, Bu, Bl, G, self.Q, self.R, Ntemp)   # lqr.jl:36 / :39
+        self.kbreak = kbreak
+        self.converged = True
+        if N == math.inf:
+            self.converged = bool(Ntemp < 3 or np.array_equal(K[0], K[1]))
+            if not self.converged:
+                print("[ Info: Riccati recursion did not converge.")      # lqr.jl:41
+            K = K[:1]                                                     # lqr.jl:42
+        self.K = K
+        self.N = 0 if N == math.inf else N                  # device convention: N <= 0 means LQR{T,Inf}
+        self.horizon_steps = N
+        self.NK = K.shape[2]
+
+    @classmethod
+    def from_matrices(cls, A, Bu, Bλ, G, Q, R, horizon, eqcids, xd, vd, qd, ωd, Fτd, Δt, mechanism=None):
+        """the inner constructor lqr.jl:17-47 for callers that bring their own linear model"""
+        self = cls.__new__(cls)
+        nb = len(xd)
+        self.mechanism = mechanism
+        self.eqcids = [int(e) for e in eqcids]
+        self.ctrl_joints = [mechanism.joint_index(e) for e in self.eqcids] if mechanism is not None else list(range(len(eqcids)))
+        self.xd, self.vd, self.qd, self.ωd = xd, vd, qd, ωd
+        self.Fτd = [np.asarray(f, dtype=np.float64).reshape(1) for f in Fτd]
+        self.zd = _pack_setpoint(nb, xd, vd, qd, ωd)[None]
+        self.Fd = np.array([f[0] for f in self.Fτd]).reshape(1, -1)
+        self.A, self.Bu, self.Bλ, self.G = (np.asarray(M, dtype=np.float64) for M in (A, Bu, Bλ, G))
+        self._finish(self.A, self.Bu, self.Bλ, self.G, [np.asarray(q, dtype=np.float64) for q in Q], [np.asarray(r, dtype=np.float64) for r in R],
+                     horizon, Δt)
+        return self
+
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+
+
+class Storage:
+    """Storage{T}(steps, Nb): x[i][k], q[i][k], v[i][k], ω[i][k]  (lqr_tracking.jl:32-35).  Batched: leading instance axis.
+    `z` is the raw [n_inst][steps][nb][13] array; x/q/v/ω index as storage.x[i][k] for instance 0 (or .instance(n))."""
+
+    def __init__(self, steps, nb, n_inst=1, z=None, status=None, zT=None):
+        self.steps, self.nb, self.n_inst = int(steps), int(nb), int(n_inst)
+        self.z = np.zeros((n_inst, steps, nb, 13)) if z is None else z
+        if z is None:
+            self.z[..., 3] = 1.0
+        self.status = status
+        self.zT = zT
+
+    def instance(self, n):
+        return Storage(self.steps, self.nb, 1, self.z[n:n + 1], None if self.status is None else self.status[n:n + 1],
+                       None if self.zT is None else self.zT[n:n + 1])
+
+    def _field(self, lo, hi):
+        return [self.z[0, :, i, lo:hi] for i in range(self.nb)]
+
+    x = property(lambda self: self._field(0, 3))
+    q = property(lambda self: self._field(3, 7))
+    v = property(lambda self: self._field(7, 10))
+    ω = property(lambda self: self._field(10, 13))
+    w = ω
+
+
+class TrackingLQR(Controller):
+    """TrackingLQR{T,N,NK}: per-step setpoints copied out of `storage` and per-step feed-forward Fτ  (lqr_tracking.jl:3-43)"""
+
+    def __init__(self, mechanism, storage, Fτ, eqcids, Q, R, controlfunction=None):
+        if controlfunction is not None:
+            raise NotImplementedError("custom controlfunction (lqr_tracking.jl:19) cannot run on the device; use simulate(..., fric=, noise=)")
+        nb = len(mechanism.bodies)
+        N = storage.steps
+        self.mechanism = mechanism
+        self.eqcids = [int(e) for e in eqcids]
+        self.ctrl_joints = [mechanism.joint_index(e) for e in self.eqcids]
+        self.Q = _blockdiag([np.asarray(q, dtype=np.float64) for q in Q]) * mechanism.Δt     # lqr_tracking.jl:22
+        self.R = _blockdiag([np.asarray(r, dtype=np.float64) for r in R]) * mechanism.Δt     # lqr_tracking.jl:23
+        self.zd = np.ascontiguousarray(storage.z[0])                                          # lqr_tracking.jl:30-37
+        mu = len(self.eqcids)
+        self.Fd = np.array([[np.asarray(Fτ[k][i], dtype=np.float64).reshape(-1)[0] for i in range(mu)] for k in range(N)]).reshape(N, mu)
+        dev = _device_mech(mechanism)
+        self.K, self.kbreak = _capi.riccati_tracking(dev, self.ctrl_joints, self.zd, self.Fd, self.Q, self.R, N)   # lqr_tracking.jl:40
+        self.N = N
+        self.NK = 12 * nb
+
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+
+
+class OpenLoop(Controller):
+    """control!(mechanism, k) = setForce!(mechanism, joint, [U[k]])  — the open-loop closure of
+    examples/trackingLQR_triple_cartpole.jl:46-48 as a table: U[k][i] for controlled joints eqcids."""
+
+    def __init__(self, mechanism, eqcids, U):
+        self.mechanism = mechanism
+        self.eqcids = [int(e) for e in eqcids]
+        self.ctrl_joints = [mechanism.joint_index(e) for e in self.eqcids]
+        U = np.asarray(U, dtype=np.float64)
+        self.Fd = U.reshape(U.shape[0], len(self.eqcids))
+        self.N = self.Fd.shape[0] + 1          # every recorded step applies its force
+        nb = len(mechanism.bodies)
+        zd = np.zeros((self.Fd.shape[0], nb, 13))
+        zd[..., 3] = 1.0
+        self.zd = zd
+
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=None, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+
+
+def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None):
+    """simulate!(mechanism, tend::Real | storage::Storage, controller; record)  -> Storage
+
+    z0 [n_inst][nb][13]: batch of initial states (default: the mechanism's current body states, one instance).
+    fric [ne], noise [n_inst][steps], noise_scale: the friction/noise law of examples/trackingLQR_triple_cartpole.jl:93-111.
+    After the call the mechanism's bodies hold instance 0's final state (simulate! mutates the mechanism)."""
+    if isinstance(tend_or_storage, Storage):
+        steps = tend_or_storage.steps
+    else:
+        steps = int(math.ceil(tend_or_storage / mechanism.Δt))     # steps = 1:ceil(tend/Δt)
+    nb = len(mechanism.bodies)
+    z0 = mechanism.state()[None] if z0 is None else np.asarray(z0, dtype=np.float64).reshape(-1, nb, 13)
+    dev = _device_mech(mechanism)
+    if noise is not None and noise_scale is None:
+        noise_scale = 1.0
+    ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale)
+    zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record)
+    ctrl.close()
+    mechanism.set_state(zT[0])
+    if isinstance(tend_or_storage, Storage) and record:
+        tend_or_storage.z = traj
+        tend_or_storage.n_inst = z0.shape[0]
+        tend_or_storage.status, tend_or_storage.zT = status, zT
+        return tend_or_storage
+    return Storage(steps, nb, z0.shape[0], traj if record else np.zeros((z0.shape[0], 0, nb, 13)), status, zT)

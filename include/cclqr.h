@@ -1,0 +1,119 @@
+/*
+ * cclqr.h -- C ABI of libcclqr.so: the MI355X (gfx950) implementation of ConstrainedControl.jl's batched
+ * LQR-rollout hot path.  Plain pointers and sizes only; every entry point returns an int status
+ * (0 = ok, < 0 = error, see CCLQR_E*); no exceptions cross the boundary.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference repo,
+ * janbruedigam/ConstrainedControl.jl v0.3.0).  The reference has no batch API and no FFI of its own:
+ * INTEGRATION.md shows the `ccall` stubs a maintainer adds on the Julia side.
+ *
+ * Layouts (all fp64, all dense arrays row-major unless stated):
+ *   body state   z[13]   = x(3) world, q(4) scalar-first unit quaternion body->world, v(3) world, w(3) body frame
+ *   batch state  z0[n_inst][nb][13]            (an instance = 13*nb contiguous doubles -> coalesced wave loads)
+ *   trajectory   traj[n_inst][steps][nb][13]   = Storage x/q/v/w of every body at every step (lqr_tracking.jl:32-35)
+ *   gains        K[nK][mu][12*nb]              = lqr.K[k][i] rows (lqr.jl:4); error order per body x,v,q~,w (lqr.jl:92-95)
+ *   linear model A[mx][mx], Bu[mx][mu], Bl[mx][ml], G[ml][mx], mx = 12*nb, ml = 5*ne
+ */
+#ifndef CCLQR_H
+#define CCLQR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCLQR_OK 0
+#define CCLQR_EINVAL -1       /* size / topology mismatch  (the reference's @assert, lqr.jl:59-60) */
+#define CCLQR_ESINGULAR -2    /* G*Bl or M singular        (LAPACK exception from lqr.jl:151,160) */
+#define CCLQR_ENOCONV -3      /* soft: Newton / Riccati did not converge (lqr.jl:41 `@info`) */
+#define CCLQR_EHIP -4         /* HIP runtime error; cclqr_last_error() has the text */
+#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (closed loops, branching bodies, nb > 32) */
+
+#define CCLQR_REVOLUTE 0      /* EqualityConstraint(Revolute(a, b, axis; p1, p2, qoffset)),  examples/lqr_cartpole.jl:26 */
+#define CCLQR_PRISMATIC 1     /* EqualityConstraint(Prismatic(a, b, axis; p1, p2, qoffset)), examples/lqr_cartpole.jl:25 */
+
+/* Mechanism(origin, bodies, eqconstraints; g, Δt) -- examples/lqr_cartpole.jl:32.
+ * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb). */
+typedef struct {
+    int32_t nb, ne;
+    double dt, g;          /* mechanism.Δt (lqr.jl:65), gravity along z */
+    const double *mass;    /* [nb] */
+    const double *inertia; /* [nb][9] body frame */
+    const int32_t *parent; /* [ne] body index or -1 */
+    const int32_t *child;  /* [ne] body index */
+    const int32_t *type;   /* [ne] CCLQR_REVOLUTE / CCLQR_PRISMATIC */
+    const double *p1;      /* [ne][3] vertex in the parent frame */
+    const double *p2;      /* [ne][3] vertex in the child frame */
+    const double *axis;    /* [ne][3] axis in the parent frame */
+    const double *qoff;    /* [ne][4] orientation offset */
+} cclqr_mech_desc;
+
+/* LQR{T,N,NK} (lqr.jl:3-15) / TrackingLQR{T,N,NK} (lqr_tracking.jl:3-15) as flat tables. */
+typedef struct {
+    int32_t mu;                /* length(eqcids) */
+    const int32_t *ctrl_joint; /* [mu] joint indices (eqcids, 0-based joint index) */
+    int32_t nK;                /* gain matrices: N-1, or 1 for LQR{T,Inf} (lqr.jl:42) */
+    int32_t N;                 /* horizon in steps; feedback is gated by k < N (lqr.jl:106); N <= 0: infinite horizon (lqr.jl:116) */
+    const double *K;           /* [nK][mu][12*nb] or NULL (open loop) */
+    int32_t nsp;               /* 1: xd,vd,qd,ωd of LQR ; N: per-step setpoints of TrackingLQR (lqr_tracking.jl:6-9) */
+    const double *zd;          /* [nsp][nb][13] */
+    const double *Fd;          /* [nsp][mu]  Fτd (lqr.jl:12, lqr_tracking.jl:12) */
+    const double *fric;        /* [ne] viscous joint friction of examples/trackingLQR_triple_cartpole.jl:98-101, or NULL */
+    double noise_scale;        /* cart noise amplitude, same file :98 (`randn()*2`); 0 = none */
+} cclqr_ctrl_desc;
+
+typedef struct cclqr_mech cclqr_mech; /* opaque: device-resident mechanism tables */
+typedef struct cclqr_ctrl cclqr_ctrl; /* opaque: device-resident controller tables */
+
+const char *cclqr_last_error(void);
+int cclqr_version(void);
+int cclqr_device_count(int32_t *n);
+int cclqr_set_device(int32_t dev);
+
+/* Mechanism(...) constructor: validates the topology, orders links breadth-first, uploads the tables. */
+int cclqr_mech_create(const cclqr_mech_desc *desc, cclqr_mech **out);
+int cclqr_mech_destroy(cclqr_mech *m);
+
+/* LQR(...) / TrackingLQR(...) result as a device object consumed by cclqr_rollout*. */
+int cclqr_ctrl_create(const cclqr_mech *m, const cclqr_ctrl_desc *desc, cclqr_ctrl **out);
+int cclqr_ctrl_destroy(cclqr_ctrl *c);
+
+/* linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) -- call sites lqr.jl:63, lqr_tracking.jl:88.
+ * Batched over nk knots (nk = 1 for LQR, N-1 for TrackingLQR).  Host pointers.
+ * zd [nk][nb][13], Fd [nk][mu]; outputs A [nk][mx][mx], Bu [nk][mx][mu], Bl [nk][mx][ml], G [nk][ml][mx]. */
+int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
+                    double *A, double *Bu, double *Bl, double *G);
+
+/* dlqr(A, Bu, Bλ, G, Q, R, N) -- lqr.jl:141-184, batched over nprob independent problems (nprob = 1 in the reference).
+ * Q [mx][mx] and R [mu][mu] are the already Δt-scaled block-diagonal weights (lqr.jl:18-19).
+ * K [nprob][N-1][mu][mx]; kbreak [nprob] = value of the loop index k after the loop (lqr.jl:172-181). Host pointers. */
+int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
+                  const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
+
+/* dlqr(mechanism, xd, vd, qd, ωd, Fτd, eqcids, Q, R, N) -- lqr_tracking.jl:73-122: re-linearises at every knot (:88).
+ * zd [N][nb][13], Fd [N][mu], K [N-1][mu][mx]. Host pointers. */
+int cclqr_riccati_tracking(const cclqr_mech *m, int32_t mu, const int32_t *ctrl_joint, const double *zd, const double *Fd, const double *Q,
+                           const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
+
+/* simulate!(mechanism, steps, controller; record) for n_inst independent instances -- the rollout loop of every
+ * example's last line (e.g. examples/lqr_cartpole.jl:44) with control_lqr! (lqr.jl:89-139) / control_trackinglqr!
+ * (lqr_tracking.jl:46-71) fused in.  Step indices run k0 .. k0+steps-1 (1-based like the reference).
+ * HOST pointers; traj may be NULL (record=false); noise [n_inst][steps] standard-normal samples or NULL;
+ * status[n_inst] = max Newton iterations used, negative if a step hit the 100-iteration cap. */
+int cclqr_rollout(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0,
+                  const double *noise, double *traj, double *zT, int32_t *status);
+
+/* Same with DEVICE pointers and an explicit hipStream_t (passed as void*): nothing is copied, the launch is
+ * asynchronous.  lam [n_inst][5*ne] carries the multipliers (Newton warm start) between calls; it is read when
+ * k0 > 1 and always written; pass NULL to start from zero and discard. */
+int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0_dev,
+                      double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
+                      int32_t *status_dev, void *stream);
+
+/* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py) */
+int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

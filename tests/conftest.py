@@ -1,0 +1,54 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cclqr():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """CPU emulation of the rollout kernel's phase functions (tests/emu, test infrastructure only)"""
+    import ctypes as C
+    d = os.path.join(ROOT, "tests", "emu")
+    so = os.path.join(d, "libemu.so")
+    src = os.path.join(d, "emu_rollout.cpp")
+    hdr = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc", "cclqr_dev.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared",
+                               "-o", so, src])
+    return C.CDLL(so)
+
+
+def hanging_setpoint(cclqr, n):
+    return cclqr.examples.cartpole_states(n, [0.0], np.array([[np.pi] + [0.0] * (n - 1)]))[0]
+
+
+def upright_setpoint(n):
+    zd = np.zeros((n + 1, 13))
+    zd[:, 3] = 1.0
+    for i in range(1, n + 1):
+        zd[i, 2] = i - 0.5
+    return zd

@@ -1,0 +1,156 @@
+// emu_rollout.cpp -- TEST INFRASTRUCTURE ONLY (never linked into libcclqr.so).
+// Runs the rollout kernel's __host__ __device__ phase functions (csrc/cclqr_dev.h) serially on the CPU with the same
+// phase order as rollout.hip, lane by lane, so that the kernel's arithmetic, LDS layout and indexing can be checked
+// against the oracle without a GPU.  It is not a fallback: nothing in the product can reach it.
+#include "../../constrainedcontrol.jl_amd/csrc/cclqr_tables.h"
+#include <vector>
+#include <string>
+#include <math.h>
+
+using namespace cclqr;
+
+static double eval_point(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, int s_off, int lam_off) {
+    for (int t = 0; t < G; t++) ph_body_eval(t, nb, Y, L, R[t], dt, s_off);
+    for (int t = 0; t < G; t++) ph_joint_eval(t, nb, Y, L, R[t], dt);
+    double acc = 0.0;
+    for (int t = 0; t < G; t++) acc += ph_force_map_norm(t, G, nb, Y, L, M, lam_off);
+    return sqrt(acc);
+}
+
+extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd, int64_t n_inst, int steps, int k0, const double* z0,
+                           const double* noise, double* traj, double* zT, int* status, int G_override) {
+    cclqr_mech m;
+    std::string err;
+    int rc = build_mech_tables(md, &m, err);
+    if (rc) return rc;
+    CtrlHostTables T;
+    rc = build_ctrl_tables(&m, cd, T, err);
+    if (rc) return rc;
+    T.H.K = T.K.empty() ? nullptr : T.K.data();
+    T.H.zd = T.zd.data();
+    T.H.Fd = T.Fd.empty() ? nullptr : T.Fd.data();
+    const MechDev* M = &m.host;
+    const CtrlDev* C = &T.H;
+    const int nb = M->nb, nz = 13 * nb;
+    const double dt = M->dt;
+    const int G = G_override > 0 ? G_override : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64));
+    const Lay Y = make_layout(nb);
+    std::vector<double> lds(Y.total);
+    std::vector<LaneRegs> R(G);
+    for (int64_t inst = 0; inst < n_inst; inst++) {
+        double* L = lds.data();
+        for (int e = 0; e < Y.total; e++) L[e] = 0.0;
+        for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t < nb ? t : 0);
+        for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = z0[inst * nz + M->perm[l] * 13 + c]; }
+        int worst = 0; bool bad = false;
+        for (int kk = 0; kk < steps; kk++) {
+            const int k = k0 + kk;
+            if (traj) for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; traj[((size_t)inst * steps + kk) * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
+            const bool gate = (C->N <= 0) || (k < C->N);
+            const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
+            const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
+            for (int t = 0; t < G; t++) {
+                if (gate) ph_control_error(t, nb, Y, L, R[t], C, C->zd + (size_t)ksp * nz);
+                else if (t < nb) L[Y.UJ + t] = 0.0;
+            }
+            if (gate)
+                for (int i = 0; i < C->mu; i++) {
+                    double s = 0.0;
+                    if (C->K) for (int t = 0; t < G; t++) s += ph_gain_partial(t, G, nb, Y, L, C->K + ((size_t)kidx * C->mu + i) * 12 * nb);
+                    double u = (C->Fd ? C->Fd[(size_t)ksp * C->mu + i] : 0.0) - s;
+                    if (noise && C->noise_scale != 0.0) u += C->noise_scale * noise[(size_t)inst * steps + (k - k0)];
+                    L[Y.UJ + C->cj[i]] += u;
+                }
+            for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+            double normf0 = eval_point(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+            bool done = false; int its = 0;
+            for (int iter = 1; iter <= 100 && !done; iter++) {
+                for (int t = 0; t < G; t++) ph_schur_w(t, G, nb, Y, L, M);
+                for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M);
+                for (int l = nb - 1; l >= 0; l--) {
+                    double lu[64][5];
+                    for (int t = 0; t < G; t++) ph_tri_fwd(t, l, Y, L, M, lu[t]);
+                    for (int t = 0; t < G; t++) ph_tri_store(t, l, Y, L, lu[t]);
+                }
+                for (int l = 0; l < nb; l++) for (int t = 0; t < G; t++) ph_tri_bwd(t, l, Y, L, M);
+                for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M);
+                double alpha = 1.0, normf1 = 0.0, nd = 0.0;
+                for (int ls = 0; ls <= 10; ls++) {
+                    double pd = 0.0;
+                    for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
+                    if (ls == 0) nd = sqrt(pd);
+                    normf1 = eval_point(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
+                    if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
+                }
+                for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
+                its = iter;
+                if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
+                normf0 = normf1;
+            }
+            if (!done) bad = true;
+            if (its > worst) worst = its;
+            for (int t = 0; t < G; t++) ph_update(t, nb, Y, L);
+        }
+        for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; zT[inst * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
+        if (status) status[inst] = bad ? -worst : worst;
+    }
+    return 0;
+}
+
+#include "../../constrainedcontrol.jl_amd/csrc/cclqr_lin_dev.h"
+// serial twin of linearize.hip's kernel body for one knot
+extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu, const int* ctrl_joint, const double* Fd, double* A, double* Bu,
+                             double* Bl, double* Gm) {
+    cclqr_mech m;
+    std::string err;
+    int rc = build_mech_tables(md, &m, err);
+    if (rc) return rc;
+    const MechDev* M = &m.host;
+    const int nb = M->nb, nz = 13 * nb, mx = 12 * nb, ml = 5 * nb, G = 64;
+    const double dt = M->dt;
+    const Lay Y = make_layout(nb);
+    const int JB = Y.total;
+    std::vector<double> lds(Y.total + LJB * nb, 0.0);
+    double* L = lds.data();
+    std::vector<LaneRegs> R(G);
+    int cj[CCLQR_MAXL];
+    for (int i = 0; i < mu; i++) cj[i] = m.link_of_joint[ctrl_joint[i]];
+    LinOut O;
+    O.A = A; O.Bu = Bu; O.Bl = Bl; O.G = Gm; O.mx = mx; O.mu = mu; O.ml = ml;
+    for (int e = 0; e < mx * mx; e++) A[e] = 0;
+    for (int e = 0; e < mx * mu; e++) Bu[e] = 0;
+    for (int e = 0; e < mx * ml; e++) Bl[e] = 0;
+    for (int e = 0; e < ml * mx; e++) Gm[e] = 0;
+    for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t < nb ? t : 0);
+    for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = zd[M->perm[l] * 13 + c]; }
+    for (int i = 0; i < mu; i++) L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0;
+    for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+    double normf0 = eval_point(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+    bool done = false;
+    for (int iter = 1; iter <= 100 && !done; iter++) {
+        for (int t = 0; t < G; t++) ph_schur_w(t, G, nb, Y, L, M);
+        for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M);
+        for (int l = nb - 1; l >= 0; l--) {
+            double lu[64][5];
+            for (int t = 0; t < G; t++) ph_tri_fwd(t, l, Y, L, M, lu[t]);
+            for (int t = 0; t < G; t++) ph_tri_store(t, l, Y, L, lu[t]);
+        }
+        for (int l = 0; l < nb; l++) for (int t = 0; t < G; t++) ph_tri_bwd(t, l, Y, L, M);
+        for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M);
+        double alpha = 1.0, normf1 = 0.0, nd = 0.0;
+        for (int ls = 0; ls <= 10; ls++) {
+            double pd = 0.0;
+            for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
+            if (ls == 0) nd = sqrt(pd);
+            normf1 = eval_point(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
+            if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
+        }
+        for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
+        if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
+        normf0 = normf1;
+    }
+    if (!done) return -3;
+    for (int t = 0; t < G; t++) ph_lin_joint(t, nb, Y, JB, L, R[t]);
+    for (int t = 0; t < G; t++) { ph_lin_rows_A(t, nb, Y, JB, L, R[t], M, O); ph_lin_rows_B(t, nb, Y, L, R[t], M, cj, O); }
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""GPU parity: HIP rollout kernel (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+Tolerance: fp64, max |state difference| over the whole trajectory < 1e-9 (north star asks < 1e-8)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from conftest import hanging_setpoint, upright_setpoint
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _gains(orc, ex, t, zd, N=1000):
+    A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
+    Q = sl.block_diag(*ex["Q"]) * t.dt
+    R = sl.block_diag(*ex["R"]) * t.dt
+    K, _ = orc.riccati(A, Bu, Bl, G, Q, R, N)
+    return K
+
+
+@pytest.mark.parametrize("n_links,ninst,steps,hanging", [(1, 37, 300, False), (3, 9, 200, False), (7, 5, 150, True), (16, 3, 120, True)])
+def test_rollout_matches_oracle(cclqr, orc, n_links, ninst, steps, hanging):
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links) if hanging else upright_setpoint(n_links)
+    K = _gains(orc, ex, t, zd, N=steps + 50)
+    rng = np.random.default_rng(7)
+    phi = rng.uniform(-1, 1, (ninst, n_links)) * (0.3 if hanging else 0.3 / 3 ** n_links)
+    if hanging:
+        phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, ninst), phi)
+    octrl = orc.ctrl_desc(t.nb, [0], K=K, N=steps + 50, zd=zd)
+    zT_o, traj_o, st_o = orc.rollout(t, octrl, z0, steps, record=True)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=steps + 50, zd=zd)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, steps, record=True)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < TOL
+    assert np.abs(zT - zT_o).max() < TOL
+    # record=False gives the same final state; two launches continue exactly where one left off
+    zT2, _, _ = capi.rollout(mech, ctrl, z0, steps, record=False)
+    assert np.array_equal(zT2, zT)
+
+
+def test_tracking_friction_noise(cclqr, orc):
+    """TrackingLQR-style controller tables (per-step setpoints/feed-forward), friction and injected noise"""
+    capi = cclqr._capi
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N, ninst = 80, 6
+    rng = np.random.default_rng(11)
+    U = 5.0 * np.sin(np.arange(N) * 0.1)
+    z00 = ex["mech"].state()
+    ol = orc.ctrl_desc(t.nb, [0], K=None, N=N + 1, zd=np.tile(z00, (N, 1, 1)), Fd=U.reshape(N, 1))
+    _, ref, _ = orc.rollout(t, ol, z00[None], N, record=True)
+    K = rng.normal(size=(N - 1, 1, 12 * t.nb)) * 0.5
+    noise = rng.normal(size=(ninst, N))
+    kw = dict(K=K, N=N, zd=ref[0], Fd=U.reshape(N, 1), fric=ex["fric"], noise_scale=2.0)
+    z0 = np.tile(z00, (ninst, 1, 1))
+    zT_o, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, [0], noise=noise, **kw), z0, N, record=True)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], **kw)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, N, noise=noise, record=True)
+    assert (st > 0).all()
+    assert np.abs(traj - traj_o).max() < TOL
