@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- LQR-controlled simulation steps/s on the N-link cartpole batch (BASELINE.json metric).
+
+A bench "step" = ONE rollout of the whole per-GPU batch over the full horizon through the HIP hot path
+(control_lqr! + variational-integrator Newton solve fused, one persistent kernel launch), record=true like the
+reference's simulate!(mech, 10, lqr, record = true).  Inputs (initial states, gains, setpoints) are resident in HBM
+before the timed region; outputs stay in HBM.  The LQR itself (linearsystem + 999-step Riccati, both HIP) is setup and is
+timed separately (reported under "setup").
+
+Workload (config.workload): the mechanism of examples/lqr_cartpole_n_pendulum.jl with N = 16 links (17 bodies,
+187 Newton unknowns), 8192 instances per GPU (configs[2]: 65536 over 8 GPUs), 1000 steps, Q = I, R = 1, horizon 10 s,
+regulated about its HANGING equilibrium: about the upright one the reference's own recursion yields |K| ~ 1e11 and every
+fp64 rollout diverges (DESIGN.md "Workloads"), so upright chains are parity-tested up to N = 8 only.
+
+Multi-GPU: one process per GPU (torchrun), instances sharded with no data-path collective, final states gathered to
+rank 0 over RCCL inside the timed region ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # vector fp64 = matrix fp64 on MI355X (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+
+
+def b_step(nb, ml, mu, record):
+    """algorithmic bytes per instance-step, step-per-launch form"""
+    return 2 * (104 * nb + 8 * ml) + (104 * nb if record else 0) + 8 * mu
+
+
+def build_workload(pkg, n_links, n_inst, seed, rank):
+    ex = pkg.examples.cartpole_n(n_links)
+    mech = ex["mech"]
+    zd = pkg.examples.cartpole_states(n_links, [0.0], np.array([[np.pi] + [0.0] * (n_links - 1)]))[0]
+    rng = np.random.default_rng(seed + 1000 * rank)
+    phi = rng.uniform(-0.2, 0.2, (n_inst, n_links))
+    phi[:, 0] += np.pi
+    z0 = pkg.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n_inst), phi)
+    return ex, mech, zd, z0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--links", type=int, default=16)
+    ap.add_argument("--instances", type=int, default=8192, help="instances PER GPU")
+    ap.add_argument("--sim-steps", type=int, default=1000)
+    ap.add_argument("--no-record", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    pkg = graft.load_package()
+    capi = pkg._capi
+    rank, world, local = pkg.dist.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
+    torch.cuda.set_device(local)
+    capi.set_device(local)
+    dev = torch.device("cuda", local)
+    record = not args.no_record
+    n_links, n_inst, T = args.links, args.instances, args.sim_steps
+
+    ex, mech, zd, z0 = build_workload(pkg, n_links, n_inst, 0, rank)
+    t = mech.tables()
+    nb, mx, ml, mu = t.nb, 12 * t.nb, 5 * t.ne, 1
+
+    # ---- setup (untimed for the metric): LQR(mech, bodyids, eqcids, Q, R, 10.; xd, qd) on the device
+    t0 = time.time()
+    lqr = pkg.LQR(mech, [pkg.getid(b) for b in ex["bodies"]], [pkg.getid(ex["ctrl"][0])], ex["Q"], ex["R"], T * t.dt,
+                  xd=[zd[i, 0:3] for i in range(nb)], qd=[zd[i, 3:7] for i in range(nb)])
+    setup_s = time.time() - t0
+    mh = mech._cclqr_handle
+    ctrl = lqr._ctrl_handle(mh)
+    lanes, lds_bytes = mh.geometry()
+
+    z0_d = torch.from_numpy(z0).to(dev)
+    zT_d = torch.empty_like(z0_d)
+    st_d = torch.zeros(n_inst, dtype=torch.int32, device=dev)
+    traj_d = torch.empty((n_inst, T, nb, 13), dtype=torch.float64, device=dev) if record else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_step():
+        capi.rollout_dev(mh, ctrl, n_inst, T, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(),
+                         st_d.data_ptr(), stream)
+        if world > 1:
+            return pkg.dist.gather_to_root(zT_d, n_inst * world, rank, world)   # RCCL fan-in of the final states
+        return zT_d
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        capi.rollout_dev(mh, ctrl, n_inst, T, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(),
+                         st_d.data_ptr(), stream)
+        ev[i][1].record()
+        if world > 1:
+            pkg.dist.gather_to_root(zT_d, n_inst * world, rank, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = pkg.dist.max_over_ranks(elapsed, dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    status = st_d.cpu().numpy()
+    n_bad = int((status <= 0).sum())
+
+    if rank != 0:
+        return
+    total_units = float(n_inst) * world * T * args.steps
+    value = total_units / elapsed
+    bs = b_step(nb, ml, mu, record)
+    alg_bytes_per_launch = bs * float(n_inst) * T
+    achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "LQR sim steps/sec (whole node) on N-link cartpole batch", "value": value, "unit": "instance-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, "
+                               "y0~U(-0.5,0.5) phi_i~U(-0.2,0.2)" % (n_links, nb, T * t.dt),
+                   "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,
+                   "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": "rollout_kernel<%d>" % lanes, "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_instance_step": bs},
+        "newton": {"max_iters_mean": float(status.mean()), "max_iters_max": int(status.max()), "failed_instances": n_bad},
+        "setup": {"lqr_construct_s": setup_s, "riccati_kbreak": int(lqr.kbreak)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_and_flops(pkg, t, lqr, z0, T, value, kern_ms, n_inst))
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_and_flops(pkg, t, lqr, z0, T, gpu_value, kern_ms, n_inst):
+    """oracle (CPU restatement, NOT ConstrainedControl.jl itself) on a bounded sample of the same workload, all host cores"""
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    octrl = orc.ctrl_desc(t.nb, lqr.ctrl_joints, K=lqr.K, N=lqr.N, zd=lqr.zd)
+    # calibrate: one instance, 50 steps
+    t0 = time.time()
+    orc.rollout(t, octrl, z0[:1], 50, nthreads=1)
+    per = (time.time() - t0) / 50.0
+    sample_steps = min(T, 200)
+    n_s = max(cores, min(len(z0), int(15.0 * cores / max(per * sample_steps, 1e-9))))
+    n_s = (n_s // cores) * cores
+    t0 = time.time()
+    orc.rollout(t, octrl, z0[:n_s], sample_steps, nthreads=cores)
+    dt_all = time.time() - t0
+    v_all = n_s * sample_steps / dt_all
+    # counted flops per instance-step (instrumented build), same inputs
+    orc.flops_reset()
+    orc.rollout(t, octrl, z0[:4], sample_steps, nthreads=1, flops=True)
+    f_step = orc.flops_get() / (4.0 * sample_steps)
+    tf = f_step * gpu_value / 1e12
+    return {
+        "cpu_baseline": {"value": v_all, "unit": "instance-steps/s", "cores": cores, "kind": "port",
+                         "sample": "%d instances x %d steps of the same workload, oracle/liborc.so (gcc -O2, OpenMP over instances); "
+                                   "single-thread rate %.0f" % (n_s, sample_steps, 1.0 / per)},
+        "roofline_fp64_valu": {"bound": "fp64 vector ALU (the binding unit; SURVEY 8d)", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "flops_per_instance_step_counted_by_oracle": f_step},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""CPU tests of the HIP kernels' arithmetic: the __host__ __device__ phase functions of csrc/cclqr_dev.h / cclqr_lin_dev.h
+are run serially by tests/emu (same phase order as the kernels) and compared with the oracle.  This checks the LDS
+layout, indexing, the Schur/block-tridiagonal solve and the linearisation without a GPU; the GPU tests then check the
+real kernels through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from conftest import hanging_setpoint, upright_setpoint
+
+dp = C.POINTER(C.c_double)
+
+
+def emu_rollout(emu, orc, t, ctrl, z0, steps, noise=None, G=0):
+    m = orc.mech_desc(t)
+    z0 = np.ascontiguousarray(z0, dtype=np.float64).reshape(-1, t.nb, 13)
+    n = z0.shape[0]
+    traj = np.zeros((n, steps, t.nb, 13))
+    zT = np.zeros_like(z0)
+    st = np.zeros(n, dtype=np.int32)
+    rc = emu.emu_rollout(C.byref(m.desc), C.byref(ctrl.desc), C.c_int64(n), C.c_int(steps), C.c_int(1), z0.ctypes.data_as(dp),
+                         None if noise is None else noise.ctypes.data_as(dp), traj.ctypes.data_as(dp), zT.ctypes.data_as(dp),
+                         st.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(G))
+    assert rc == 0
+    return zT, traj, st
+
+
+@pytest.mark.parametrize("n_links,steps,hanging,G", [(1, 150, False, 0), (1, 60, False, 64), (3, 100, False, 0), (7, 60, True, 0), (16, 25, True, 0)])
+def test_emulated_rollout_matches_oracle(cclqr, orc, emu, n_links, steps, hanging, G):
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links) if hanging else upright_setpoint(n_links)
+    rng = np.random.default_rng(4)
+    if n_links <= 3:
+        A, Bu, Bl, G_ = orc.linearize(t, zd, [0], np.zeros(1))
+        K, _ = orc.riccati(A, Bu, Bl, G_, sl.block_diag(*ex["Q"]) * t.dt, sl.block_diag(*ex["R"]) * t.dt, steps + 20)
+    else:
+        K = rng.normal(size=(steps + 19, 1, 12 * t.nb)) * 0.05
+    phi = rng.uniform(-1, 1, (2, n_links)) * (0.3 if hanging else 0.3 / 3 ** n_links)
+    if hanging:
+        phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, 2), phi)
+    octrl = orc.ctrl_desc(t.nb, [0], K=K, N=steps + 20, zd=zd)
+    zT_o, traj_o, st_o = orc.rollout(t, octrl, z0, steps, record=True)
+    zT, traj, st = emu_rollout(emu, orc, t, octrl, z0, steps, G=G)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10
+    assert np.abs(zT - zT_o).max() < 1e-10
+
+
+def test_emulated_tracking_friction_noise(cclqr, orc, emu):
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N, ninst = 40, 3
+    rng = np.random.default_rng(11)
+    z00 = ex["mech"].state()
+    zd = np.tile(z00, (N, 1, 1))
+    zd[:, 0, 1] = 0.01 * np.arange(N)
+    K = rng.normal(size=(N - 1, 1, 48)) * 0.5
+    noise = rng.normal(size=(ninst, N))
+    c = orc.ctrl_desc(4, [0], K=K, N=N, zd=zd, Fd=rng.normal(size=(N, 1)), fric=ex["fric"], noise_scale=2.0, noise=noise)
+    z0 = np.tile(z00, (ninst, 1, 1))
+    _, traj_o, _ = orc.rollout(t, c, z0, N, record=True)
+    _, traj, _ = emu_rollout(emu, orc, t, c, z0, N, noise=noise)
+    assert np.abs(traj - traj_o).max() < 1e-10
+
+
+def test_body_order_permutation(cclqr, orc, emu):
+    """bodies listed leaf-first: the kernels' breadth-first link order differs from the caller's body/joint numbering"""
+    ex = cclqr.examples.cartpole_n(2)
+    t = ex["mech"].tables()
+    perm = [2, 0, 1]          # new body i = old body perm[i]
+    inv = np.argsort(perm)
+    jperm = [1, 2, 0]         # new joint j = old joint jperm[j]
+    t2 = cclqr.MechTables(3, 3, t.dt, t.g, t.mass[perm], t.inertia[perm], [(-1 if t.parent[j] < 0 else inv[t.parent[j]]) for j in jperm],
+                          [inv[t.child[j]] for j in jperm], t.type[jperm], t.p1[jperm], t.p2[jperm], t.axis[jperm], t.qoff[jperm])
+    rng = np.random.default_rng(0)
+    K = rng.normal(size=(30, 1, 36)) * 0.3
+    zd = upright_setpoint(2)
+    z0 = cclqr.examples.cartpole_states(2, [0.2], [[0.05, -0.03]])
+    K2 = K.reshape(30, 1, 3, 12)[:, :, perm].reshape(30, 1, 36)
+    c1 = orc.ctrl_desc(3, [0], K=K, N=31, zd=zd)
+    c2 = orc.ctrl_desc(3, [jperm.index(0)], K=K2, N=31, zd=zd[perm])
+    _, tr1, _ = orc.rollout(t, c1, z0, 30, record=True)
+    _, tr2o, _ = orc.rollout(t2, c2, z0[:, perm], 30, record=True)
+    assert np.abs(tr2o[:, :, inv] - tr1).max() < 1e-11
+    _, tr2, _ = emu_rollout(emu, orc, t2, c2, z0[:, perm], 30)
+    assert np.abs(tr2 - tr2o).max() < 1e-10
+
+
+def test_emulated_linearize_matches_oracle(cclqr, orc, emu):
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    z = ex["mech"].state()
+    lam = np.zeros(20)
+    for _ in range(20):
+        z, lam, it = orc.step(t, z, lam, np.array([5.0, 0.2, -0.1, 0.05]))
+    cj = np.array([0, 2], dtype=np.int32)
+    Fd = np.array([1.7, -0.4])
+    m = orc.mech_desc(t)
+    mx, ml = 48, 20
+    A, Bu, Bl, G = np.zeros((mx, mx)), np.zeros((mx, 2)), np.zeros((mx, ml)), np.zeros((ml, mx))
+    rc = emu.emu_linearize(C.byref(m.desc), np.ascontiguousarray(z).ctypes.data_as(dp), C.c_int(2), cj.ctypes.data_as(C.POINTER(C.c_int32)),
+                           Fd.ctypes.data_as(dp), A.ctypes.data_as(dp), Bu.ctypes.data_as(dp), Bl.ctypes.data_as(dp), G.ctypes.data_as(dp))
+    assert rc == 0
+    for got, want in zip((A, Bu, Bl, G), orc.linearize(t, z, cj, Fd)):
+        assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max())

@@ -1,0 +1,226 @@
+"""CPU tests pinning the ORACLE (oracle/): known answers, invariants and the reference's own constants.
+The reference holds no numeric fixture (every test is `@test true`), so these are what stands in for golden vectors:
+ - dlqr restatements (C and numpy, both following src/control/lqr.jl:141-184) agree with each other and with SciPy's DARE
+   (the algorithm of src/util/util.jl:1-19);
+ - algebraic invariances of the constrained recursion;
+ - the linearisation equals finite differences of the oracle's own step map;
+ - pendulum minimal-coordinate equivalence, integrator invariants."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from conftest import upright_setpoint
+
+
+def test_dlqr_c_vs_numpy_vs_scipy_dare(orc):
+    rng = np.random.default_rng(1)
+    n, m = 6, 2
+    A = rng.normal(size=(n, n)) * 0.5
+    B = rng.normal(size=(n, m))
+    Q, R = np.eye(n), np.eye(m)
+    E0, G0 = np.zeros((n, 0)), np.zeros((0, n))
+    K, kb = orc.riccati(A, B, E0, G0, Q, R, 2000, tol=1e-13)
+    Kn, kbn = orc.dlqr_np(A, B, E0, G0, Q, R, 2000, tol=1e-13)
+    P = sl.solve_discrete_are(A, B, Q, R)
+    Kd = np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
+    assert kb == kbn and 1 < kb < 1999
+    assert np.abs(K - Kn).max() < 1e-12
+    assert np.abs(K[0] - Kd).max() < 1e-10
+    # back-fill: every step before the break index carries the converged gain (lqr.jl:179-181)
+    assert all(np.array_equal(K[i], K[kb - 1]) for i in range(kb - 1))
+
+
+@pytest.mark.parametrize("n_links", [1, 2])
+def test_constrained_dlqr_c_vs_numpy_and_invariances(cclqr, orc, n_links):
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    A, Bu, Bl, G = orc.linearize(t, upright_setpoint(n_links), [0], np.zeros(1))
+    Q = sl.block_diag(*ex["Q"]) * t.dt
+    R = sl.block_diag(*ex["R"]) * t.dt
+    K, kb = orc.riccati(A, Bu, Bl, G, Q, R, 400)
+    Kn, kbn = orc.dlqr_np(A, Bu, Bl, G, Q, R, 400)
+    assert kb == kbn
+    assert np.abs(K - Kn).max() / np.abs(K).max() < 1e-10
+    # Ku is invariant to the basis of the constraint rows and of the multipliers: G -> T G, Bl -> Bl S
+    rng = np.random.default_rng(0)
+    ml = G.shape[0]
+    T = rng.normal(size=(ml, ml)) + 3 * np.eye(ml)
+    S = rng.normal(size=(ml, ml)) + 3 * np.eye(ml)
+    K2, _ = orc.riccati(A, Bu, Bl @ S, T @ G, Q, R, 400)
+    assert np.abs(K - K2).max() / np.abs(K).max() < 1e-7
+    # the closed loop keeps the constraint: G (A - Bu Ku - Bl Kl) = 0 with [Ku; Kl] = M \ b
+    D = Bu - Bl @ np.linalg.solve(G @ Bl, G @ Bu)
+    P = Q
+    M = np.block([[R + D.T @ P @ Bu, D.T @ P @ Bl], [G @ Bu, G @ Bl]])
+    Kk = np.linalg.solve(M, np.vstack([D.T @ P, G]) @ A)
+    Abar = A - Bu @ Kk[:1] - Bl @ Kk[1:]
+    assert np.abs(G @ Abar).max() < 1e-9
+    assert np.abs(K[-1] - Kk[:1]).max() < 1e-9 * max(1.0, np.abs(Kk).max())
+
+
+def _err_state(cclqr, t, z, zd):
+    out = np.zeros((t.nb, 12))
+    for b in range(t.nb):
+        out[b, 0:3] = z[b, 0:3] - zd[b, 0:3]
+        out[b, 3:6] = z[b, 7:10] - zd[b, 7:10]
+        out[b, 6:9] = cclqr.qmul(cclqr.qconj(zd[b, 3:7]), z[b, 3:7])[1:]
+        out[b, 9:12] = z[b, 10:13] - zd[b, 10:13]
+    return out.reshape(-1)
+
+
+def _perturb(cclqr, t, zd, dz):
+    dz = dz.reshape(t.nb, 12)
+    z = zd.copy()
+    for b in range(t.nb):
+        z[b, 0:3] += dz[b, 0:3]
+        z[b, 7:10] += dz[b, 3:6]
+        z[b, 10:13] += dz[b, 9:12]
+        qt = dz[b, 6:9]
+        z[b, 3:7] = cclqr.qmul(zd[b, 3:7], np.concatenate([[np.sqrt(1 - qt @ qt)], qt]))
+    return z
+
+
+@pytest.mark.parametrize("which", ["cartpole", "triple"])
+def test_linearisation_is_the_jacobian_of_the_step_map(cclqr, orc, which):
+    """A, Bu, Bl = d z+ / d (z, u, lambda) with lambda exogenous (incl. the geometric stiffness d(G'lambda)/dz), G = dg/dz+"""
+    if which == "cartpole":
+        ex = cclqr.examples.cartpole_n(1)
+        cj, Fd, uj0 = [0, 1], np.array([0.7, -0.4]), np.array([0.3, 0.0])
+    else:
+        ex = cclqr.examples.triple_cartpole()
+        cj, Fd, uj0 = [0, 2], np.array([1.7, -0.4]), np.array([5.0, 0.2, -0.1, 0.05])
+    t = ex["mech"].tables()
+    z = ex["mech"].state()
+    lam = np.zeros(5 * t.ne)
+    for _ in range(12):
+        z, lam, it = orc.step(t, z, lam, uj0)
+        assert it > 0
+    A, Bu, Bl, G = orc.linearize(t, z, cj, Fd)
+    uj = np.zeros(t.ne)
+    for i, j in enumerate(cj):
+        uj[j] += Fd[i]
+    zn, lam, it = orc.step(t, z, np.zeros(5 * t.ne), uj)
+    assert np.abs(orc.step_fixed_lambda(t, z, lam, uj) - zn).max() < 1e-12
+    mx, h = 12 * t.nb, 1e-6
+    Afd = np.zeros((mx, mx))
+    Gfd = np.zeros((5 * t.ne, mx))
+    for c in range(mx):
+        e = np.zeros(mx)
+        e[c] = h
+        zp = orc.step_fixed_lambda(t, _perturb(cclqr, t, z, e), lam, uj)
+        zm = orc.step_fixed_lambda(t, _perturb(cclqr, t, z, -e), lam, uj)
+        Afd[:, c] = (_err_state(cclqr, t, zp, zn) - _err_state(cclqr, t, zm, zn)) / (2 * h)
+        Gfd[:, c] = (orc.constraints(t, _perturb(cclqr, t, zn, e)) - orc.constraints(t, _perturb(cclqr, t, zn, -e))) / (2 * h)
+    assert np.abs(A - Afd).max() < 2e-8 * max(1.0, np.abs(A).max())
+    assert np.abs(G - Gfd).max() < 1e-8
+    for i, j in enumerate(cj):
+        up, um = uj.copy(), uj.copy()
+        up[j] += h
+        um[j] -= h
+        col = (_err_state(cclqr, t, orc.step_fixed_lambda(t, z, lam, up), zn) - _err_state(cclqr, t, orc.step_fixed_lambda(t, z, lam, um), zn)) / (2 * h)
+        assert np.abs(Bu[:, i] - col).max() < 1e-8
+    for c in range(5 * t.ne):
+        lp, lm = lam.copy(), lam.copy()
+        lp[c] += h
+        lm[c] -= h
+        col = (_err_state(cclqr, t, orc.step_fixed_lambda(t, z, lp, uj), zn) - _err_state(cclqr, t, orc.step_fixed_lambda(t, z, lm, uj), zn)) / (2 * h)
+        assert np.abs(Bl[:, c] - col).max() < 1e-8
+
+
+def test_pendulum_gain_equals_minimal_coordinate_lqr(cclqr, orc):
+    """project the maximal-coordinate gain of examples/lqr_pendulum.jl onto (theta, thetadot) and compare with
+    the 2-state discrete LQR of the same semi-implicit map.  I_pivot = J_xx + m l^2, Q_min = diag(1000/4, 100) dt, R = dt."""
+    ex = cclqr.examples.pendulum()
+    mech = ex["mech"]
+    t = mech.tables()
+    zd = np.zeros((1, 13))
+    zd[0, 0:3] = ex["xd"][0]
+    zd[0, 3:7] = ex["qd"][0]
+    A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
+    Q = ex["Q"][0] * t.dt
+    R = ex["R"][0] * t.dt
+    K, kb = orc.riccati(A, Bu, Bl, G, Q, R, 1000)
+    assert kb > 1, "infinite-horizon recursion converges within the 10 s cap (lqr.jl:26)"
+    dt, m, l, g = t.dt, 1.0, 0.5, 9.81
+    I = (0.1 ** 2 + 1.0 ** 2) / 12.0 + m * l * l
+    Am = np.array([[1 + dt * dt * m * g * l / I, dt], [dt * m * g * l / I, 1.0]])
+    Bm = np.array([[dt * dt / I], [dt / I]])
+    Qm = np.diag([1000.0 / 4, 100.0]) * dt
+    P = sl.solve_discrete_are(Am, Bm, Qm, np.array([[dt]]))
+    Km = np.linalg.solve(np.array([[dt]]) + Bm.T @ P @ Bm, Bm.T @ P @ Am)[0]
+    # tangent of the constraint manifold at the setpoint (body frame = world rotated by pi about x):
+    # d theta about the joint axis: qtilde_x = dtheta/2, omega_x = thetadot, COM moves along -y*... obtained numerically
+    def state(theta, thetad):
+        q = cclqr.qmul(ex["qd"][0], cclqr.RotX(theta))
+        x = -cclqr.vrotate(np.array([0, 0, 0.5]), q)
+        v = np.cross(cclqr.vrotate(np.array([thetad, 0, 0]), q), x)
+        z = np.zeros((1, 13))
+        z[0, 0:3], z[0, 3:7], z[0, 7:10], z[0, 10:13] = x, q, v, [thetad, 0, 0]
+        return z
+    h = 1e-6
+    e_th = (_err_state(cclqr, t, state(h, 0), zd) - _err_state(cclqr, t, state(-h, 0), zd)) / (2 * h)
+    e_td = (_err_state(cclqr, t, state(0, h), zd) - _err_state(cclqr, t, state(0, -h), zd)) / (2 * h)
+    k_th, k_td = K[0, 0] @ e_th, K[0, 0] @ e_td
+    assert abs(k_th - Km[0]) / abs(Km[0]) < 2e-2
+    assert abs(k_td - Km[1]) / abs(Km[1]) < 2e-2
+
+
+def test_integrator_invariants(cclqr, orc):
+    # chain at rest under gravity stays at rest and the multipliers carry the weight of the links below
+    n = 4
+    ex = cclqr.examples.cartpole_n(n)
+    t = ex["mech"].tables()
+    z = cclqr.examples.cartpole_states(n, [0.0], np.array([[np.pi] + [0.0] * (n - 1)]))[0]
+    lam = np.zeros(5 * t.ne)
+    for _ in range(5):
+        z2, lam, it = orc.step(t, z, lam, np.zeros(t.ne))
+        assert it > 0 and np.abs(z2 - z).max() < 1e-11
+        z = z2
+    weights = [9.81 * (n - i) for i in range(n)]    # revolute i carries links i..n-1 (mass 1 each)
+    for i in range(n):
+        fz = lam[5 * (i + 1) + 2]
+        assert abs(abs(fz) - weights[i]) < 1e-8
+    # frictionless pendulum: constraints hold to round-off, quaternion stays unit, energy oscillates without drift
+    exp = cclqr.examples.pendulum(θ0=np.pi - 1.0)
+    tp = exp["mech"].tables()
+    octrl = orc.ctrl_desc(1, [0], K=None, N=0)
+    zT, traj, st = orc.rollout(tp, octrl, exp["mech"].state()[None], 20000, record=True)
+    assert (st > 0).all()
+    q = traj[0, :, 0, 3:7]
+    assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-11
+    x, v, w = traj[0, :, 0, 0:3], traj[0, :, 0, 7:10], traj[0, :, 0, 10:13]
+    J = tp.inertia.reshape(3, 3)
+    E = 0.5 * np.sum(v * v, axis=1) + 0.5 * np.einsum("ki,ij,kj->k", w, J, w) + 9.81 * x[:, 2]
+    assert np.abs(np.linalg.norm(x, axis=1) - 0.5).max() < 1e-10        # COM stays on the sphere of the joint
+    e0 = E[100:5000]
+    e1 = E[-5000:]
+    assert abs(e1.mean() - e0.mean()) < 2e-3 * (E.max() - E.min() + 1.0)  # no secular drift (symplectic)
+
+
+def test_reference_constants_and_quirks(cclqr, orc):
+    """behaviours read from the reference: k<N gate (lqr.jl:106), raw vector part without sign fix (lqr.jl:101-102),
+    Δz order x,v,q~,ω (lqr.jl:92-95), friction+noise law inside the gate (trackingLQR_triple_cartpole.jl:98-111)"""
+    ex = cclqr.examples.cartpole_n(1)
+    t = ex["mech"].tables()
+    zd = upright_setpoint(1)
+    K = np.arange(24, dtype=float).reshape(1, 1, 24) + 1
+    z = ex["mech"].state()
+    z[0, 7:10] = [0.1, 0.2, 0.3]
+    z[1, 10:13] = [0.4, 0.5, 0.6]
+    c = orc.ctrl_desc(2, [0], K=np.repeat(K, 4, axis=0), N=5, zd=zd)
+    dz = _err_state(cclqr, t, z, zd)
+    assert abs(orc.control(t, c, z, 3)[0] + K[0, 0] @ dz) < 1e-12
+    assert orc.control(t, c, z, 5)[0] == 0.0 and orc.control(t, c, z, 9)[0] == 0.0     # k >= N: no force written
+    cinf = orc.ctrl_desc(2, [0], K=K, N=0, zd=zd)
+    assert abs(orc.control(t, cinf, z, 999)[0] + K[0, 0] @ dz) < 1e-12                 # LQR{T,Inf}: K[1] always
+    # double cover: q and -q give opposite q~ (sign fix commented out in the reference)
+    z2 = z.copy()
+    z2[1, 3:7] *= -1
+    dz2 = _err_state(cclqr, t, z2, zd)
+    assert np.allclose(dz2[18:21], -dz[18:21])
+    # friction + noise
+    cf = orc.ctrl_desc(2, [0], K=None, N=5, zd=zd, fric=np.array([0.1, 0.1]), noise_scale=2.0)
+    u = orc.control(t, cf, z, 1, noise_sample=0.25)
+    assert abs(u[0] - (-0.1 * 0.2 + 2.0 * 0.25)) < 1e-12       # cart: -0.1 v_y + 2 randn
+    assert abs(u[1] - (-0.1 * 0.4)) < 1e-12                    # pole: -0.1 (omega_x - 0)
+    assert np.all(orc.control(t, cf, z, 5, noise_sample=0.25) == 0.0)
