@@ -22,7 +22,7 @@
 
 namespace cclqr {
 
-// ---- mechanism tables in device memory (internal link order = breadth-first from the origin) ----
+// ---- mechanism tables in device memory (internal link order = chain by chain, root to leaf) ----
 struct MechDev {
     int nb;
     double dt, g;
@@ -32,6 +32,10 @@ struct MechDev {
     int type[CCLQR_MAXL];     // 0 revolute, 1 prismatic
     int perm[CCLQR_MAXL];     // user body index of link l
     int jperm[CCLQR_MAXL];    // user joint index of link l's joint
+    // links are numbered chain by chain (parent[l] == l-1 inside a chain): bit l of start_mask / end_mask marks the
+    // link attached to the origin / the leaf of its chain, so the hot phases need no table lookups
+    unsigned start_mask, end_mask;
+    int nchains, chain_start[CCLQR_MAXL], chain_len[CCLQR_MAXL];
     double m[CCLQR_MAXL], J[CCLQR_MAXL][9];
     double p1[CCLQR_MAXL][3], p2[CCLQR_MAXL][3], axis[CCLQR_MAXL][3], qoc[CCLQR_MAXL][4]; // qoc = conj(qoffset)
     double sel[CCLQR_MAXL][5][3]; // row r of the joint = sel[r] . (translational | rotational 3-vector)
@@ -50,6 +54,7 @@ struct CtrlDev {
 };
 
 // ---- LDS layout of one instance (offsets in doubles) ----
+// NB holds N(w+) D_R^-1 (so that the joint evaluation emits W = G_v D^-1 directly)
 struct Lay {
     int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, DZ, total;
 };
@@ -113,6 +118,18 @@ HD void mtm3(const double* A, const double* B, double* C) {  // C = A' B
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
 }
+// reciprocal for pivots: v_rcp_f64 seed + two Newton steps (~1 ulp) instead of the ~12-instruction IEEE division sequence
+HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
 HD void inv3(const double* A, double* Ai) {
     double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
     double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
@@ -135,9 +152,22 @@ HD void lane_load_consts(LaneRegs& r, const MechDev* M, int l) {
 
 // ------------------------------------------------------------------ joint: g and d g/d(x, phi) for both bodies
 // translational  R(qa)'(xb + R(qb) p2 - xa) - p1 ; rotational vec(qa^-1 qb qoff^-1); rows picked by sel/rotmask.
-// Ba/Bb (5x6 row major, row stride 6): [dg/dx * sx , (dg/dphi) * Nside]  where N = 3x3 (nullptr = identity)
+// Ba/Bb (5x6 row major, row stride 6): [dg/dx * sx_side , (dg/dphi) * Nside]  where N = 3x3 (nullptr = identity).
+// JAC = false evaluates g only (rejected line-search trials need no Jacobian).
+template <bool JAC>
 HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const double* xb, const double* qb, bool has_a,
-                   double sx, const double* Na, const double* Nb, double* g, double* Ba, double* Bb) {
+                   double sxa, double sxb, const double* Na_, const double* Nb_, double* g, double* Ba, double* Bb) {
+    // copy every input into registers first: the outputs go to LDS too, and a store that may alias would otherwise
+    // serialise the remaining input loads (one LDS round trip each)
+    const double xa_[3] = {xa[0], xa[1], xa[2]}, qa_[4] = {qa[0], qa[1], qa[2], qa[3]};
+    const double xb_[3] = {xb[0], xb[1], xb[2]}, qb_[4] = {qb[0], qb[1], qb[2], qb[3]};
+    double Na[9], Nb[9];
+    const bool hasNa = JAC && Na_ != nullptr, hasNb = JAC && Nb_ != nullptr;
+    if (JAC) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Na[i] = hasNa ? Na_[i] : 0.0; Nb[i] = hasNb ? Nb_[i] : 0.0; }
+    }
+    xa = xa_; qa = qa_; xb = xb_; qb = qb_;
     double Ra[9], Rb[9], rp[3], w[3], RaTw[3], gT[3];
     rotmat(qa, Ra); rotmat(qb, Rb);
     mv3(Rb, r.p2, rp);
@@ -147,10 +177,19 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
     double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
     qmul(qac, qb, rel);
     qmul(rel, r.qoc, e);
+    if (!JAC) {
+#pragma unroll
+        for (int row = 0; row < 5; row++) {
+            bool rot = (r.rotmask >> row) & 1;
+            double s0 = r.sel[row][0], s1 = r.sel[row][1], s2 = r.sel[row][2];
+            g[row] = rot ? (s0 * e[1] + s1 * e[2] + s2 * e[3]) : (s0 * gT[0] + s1 * gT[1] + s2 * gT[2]);
+        }
+        return;
+    }
     // child side 3x3s:  XT_b = Ra' ; PT_b = -2 Ra' Rb [p2]x ; PR_b = V L(rel) R(qoc) V'
     double RaTRb[9], PTb[9], PRb[9];
     mtm3(Ra, Rb, RaTRb);
-    {   // M [p]x : column c of M[p]x = M (e_c-th column of [p]x);  [p]x = [0 -pz py; pz 0 -px; -py px 0]
+    {   // M [p]x ;  [p]x = [0 -pz py; pz 0 -px; -py px 0]
         const double* p = r.p2;
         for (int i = 0; i < 3; i++) {
             double a = RaTRb[i * 3], b = RaTRb[i * 3 + 1], c = RaTRb[i * 3 + 2];
@@ -162,7 +201,6 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
     {   // rows 1..3, cols 1..3 of L(rel) R(qoc)
         double s = rel[0], x = rel[1], y = rel[2], z = rel[3];
         double os = r.qoc[0], ox = r.qoc[1], oy = r.qoc[2], oz = r.qoc[3];
-        // L(rel) rows 1..3: [x s -z y; y z s -x; z -y x s] ; R(qoc) cols 1..3: [-ox -oy -oz; os oz -oy; -oz os ox; oy -ox os]
         double Lr[3][4] = {{x, s, -z, y}, {y, z, s, -x}, {z, -y, x, s}};
         double Rc[4][3] = {{-ox, -oy, -oz}, {os, oz, -oy}, {-oz, os, ox}, {oy, -ox, os}};
         for (int i = 0; i < 3; i++)
@@ -171,6 +209,7 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
     // parent side 3x3s: XT_a = -Ra' ; PT_a = 2 [Ra'w]x ; PR_a = -(e_s I - [e_v]x)
     double PTa[9] = {0, -2 * RaTw[2], 2 * RaTw[1], 2 * RaTw[2], 0, -2 * RaTw[0], -2 * RaTw[1], 2 * RaTw[0], 0};
     double PRa[9] = {-e[0], -e[3], e[2], e[3], -e[0], -e[1], -e[2], e[1], -e[0]};
+#pragma unroll
     for (int row = 0; row < 5; row++) {
         bool rot = (r.rotmask >> row) & 1;
         double s0 = r.sel[row][0], s1 = r.sel[row][1], s2 = r.sel[row][2];
@@ -190,10 +229,10 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
             pa3[c] = rot ? pra : pta;
         }
         for (int c = 0; c < 3; c++) {
-            Bb[row * 6 + c] = xb3[c] * sx;
-            Ba[row * 6 + c] = has_a ? -xb3[c] * sx : 0.0;
-            double nb_ = Nb ? (pb3[0] * Nb[c] + pb3[1] * Nb[3 + c] + pb3[2] * Nb[6 + c]) : pb3[c];
-            double na_ = Na ? (pa3[0] * Na[c] + pa3[1] * Na[3 + c] + pa3[2] * Na[6 + c]) : pa3[c];
+            Bb[row * 6 + c] = xb3[c] * sxb;
+            Ba[row * 6 + c] = has_a ? -xb3[c] * sxa : 0.0;
+            double nb_ = hasNb ? (pb3[0] * Nb[c] + pb3[1] * Nb[3 + c] + pb3[2] * Nb[6 + c]) : pb3[c];
+            double na_ = hasNa ? (pa3[0] * Na[c] + pa3[1] * Na[3 + c] + pa3[2] * Na[6 + c]) : pa3[c];
             Bb[row * 6 + 3 + c] = nb_;
             Ba[row * 6 + 3 + c] = has_a ? na_ : 0.0;
         }
@@ -289,14 +328,26 @@ HD void ph_knot_jac(int t, int nb, const Lay& Y, double* L, const LaneRegs& r) {
     const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
     const double* zb = L + Y.Z + 13 * t;
     double g[5];
-    joint_eval(r, za ? za : X0, za ? za + 3 : QID_, zb, zb + 3, a >= 0, 1.0, nullptr, nullptr, g, L + Y.GKA + BLK * t, L + Y.GKB + BLK * t);
+    joint_eval<true>(r, za ? za : X0, za ? za + 3 : QID_, zb, zb + 3, a >= 0, 1.0, 1.0, nullptr, nullptr, g, L + Y.GKA + BLK * t, L + Y.GKB + BLK * t);
 }
 
-// E1: body t at the trial solution s: next pose, N, dynamics residual (without G'lambda), D_R^-1
+// N(w) = (dt^2/4)(sq I - [w]x + w w'/sq):  d phi+ = N d w+
+HD void make_N(const double* w2, double sq2, double dt, double* N) {
+    double k = 0.25 * dt * dt, isq = 1.0 / sq2;
+    N[0] = k * (sq2 + w2[0] * w2[0] * isq); N[1] = k * (w2[2] + w2[0] * w2[1] * isq);  N[2] = k * (-w2[1] + w2[0] * w2[2] * isq);
+    N[3] = k * (-w2[2] + w2[1] * w2[0] * isq); N[4] = k * (sq2 + w2[1] * w2[1] * isq); N[5] = k * (w2[0] + w2[1] * w2[2] * isq);
+    N[6] = k * (w2[1] + w2[2] * w2[0] * isq);  N[7] = k * (-w2[0] + w2[2] * w2[1] * isq); N[8] = k * (sq2 + w2[2] * w2[2] * isq);
+}
+
+// E1: body t at the trial solution s: next pose, dynamics residual (without G'lambda); with JAC also D_R^-1 and N D_R^-1
+template <bool JAC>
 HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt, int s_off) {
     if (t >= nb) return;
-    const double* z = L + Y.Z + 13 * t;
-    const double* s = L + s_off + 6 * t;
+    double z[7], s[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) z[i] = L[Y.Z + 13 * t + i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[i] = L[s_off + 6 * t + i];
     const double* w2 = s + 3;
     double* xq = L + Y.XQ + 7 * t;
     for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
@@ -307,45 +358,46 @@ HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, 
     mv3(r.J, w2, Jw2); cross3(w2, Jw2, c2);
     double* d = L + Y.D + 6 * t;
     for (int i = 0; i < 3; i++) { d[i] = r.m * s[i] / dt + r.cT[i]; d[3 + i] = sq2 * Jw2[i] + c2[i] + r.cR[i]; }
+    if (!JAC) return;
     // D_R = (sq2 I + [w2]x) J - [J w2]x - (J w2) w2'/sq2
-    double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2}, SJ[9], Dr[9];
+    double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2}, SJ[9], Dr[9], Di[9], N[9];
     mm3(S, r.J, SJ);
     double isq = 1.0 / sq2;
     double Sj[9] = {0, -Jw2[2], Jw2[1], Jw2[2], 0, -Jw2[0], -Jw2[1], Jw2[0], 0};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Dr[i * 3 + j] = SJ[i * 3 + j] - Sj[i * 3 + j] - Jw2[i] * w2[j] * isq;
-    inv3(Dr, L + Y.DINV + 9 * t);
-    // N = (dt^2/4)(sq2 I - [w2]x + w2 w2'/sq2):  d phi+ = N d w+
-    double* N = L + Y.NB + 9 * t;
-    double k = 0.25 * dt * dt;
-    N[0] = k * (sq2 + w2[0] * w2[0] * isq); N[1] = k * (w2[2] + w2[0] * w2[1] * isq);  N[2] = k * (-w2[1] + w2[0] * w2[2] * isq);
-    N[3] = k * (-w2[2] + w2[1] * w2[0] * isq); N[4] = k * (sq2 + w2[1] * w2[1] * isq); N[5] = k * (w2[0] + w2[1] * w2[2] * isq);
-    N[6] = k * (w2[1] + w2[2] * w2[0] * isq);  N[7] = k * (-w2[0] + w2[2] * w2[1] * isq); N[8] = k * (sq2 + w2[2] * w2[2] * isq);
+    inv3(Dr, Di);
+    for (int i = 0; i < 9; i++) L[Y.DINV + 9 * t + i] = Di[i];
+    make_N(w2, sq2, dt, N);
+    mm3(N, Di, L + Y.NB + 9 * t);
 }
 
-// E2: joint t at the next knot: g and G_v = [X dt, Phi N]
+// E2: joint t at the next knot: g and W = G_v D^-1 = [X dt (dt/m), Phi N D_R^-1]  (JAC) or g only
+template <bool JAC>
 HD void ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt) {
     if (t >= nb) return;
     int a = r.parent;
     const double X0[3] = {0, 0, 0};
     const double* pa = (a >= 0) ? L + Y.XQ + 7 * a : nullptr;
     const double* pb = L + Y.XQ + 7 * t;
-    joint_eval(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, dt, (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * t,
-               L + Y.G + 5 * t, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
+    joint_eval<JAC>(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, (a >= 0) ? dt * L[Y.DTM + a] : 0.0, dt * L[Y.DTM + t],
+                    (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * t, L + Y.G + 5 * t, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
 }
 
+HD int link_parent(const MechDev* M, int l) { return ((M->start_mask >> l) & 1u) ? -1 : l - 1; }
+HD int link_child(const MechDev* M, int l) { return ((M->end_mask >> l) & 1u) ? -1 : l + 1; }
+
 // E3: d -= G_k' lambda (lambda at lam_off) and partial sum of squares of the residual entries this lane touches
-HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M, int lam_off) {
+HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask, int lam_off) {
     double acc = 0.0;
     for (int e = t; e < 6 * nb; e += G) {
         int b = e / 6, c = e - 6 * b;
         const double* Gb = L + Y.GKB + BLK * b;
         const double* lb = L + lam_off + 5 * b;
         double s = Gb[c] * lb[0] + Gb[6 + c] * lb[1] + Gb[12 + c] * lb[2] + Gb[18 + c] * lb[3] + Gb[24 + c] * lb[4];
-        int ch = M->childl[b];
-        if (ch >= 0) {
-            const double* Ga = L + Y.GKA + BLK * ch;
-            const double* lc = L + lam_off + 5 * ch;
+        if (!((end_mask >> b) & 1u)) {
+            const double* Ga = L + Y.GKA + BLK * (b + 1);
+            const double* lc = L + lam_off + 5 * (b + 1);
             s += Ga[c] * lc[0] + Ga[6 + c] * lc[1] + Ga[12 + c] * lc[2] + Ga[18 + c] * lc[3] + Ga[24 + c] * lc[4];
         }
         double d = L[Y.D + e] - s;
@@ -356,120 +408,190 @@ HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, const
     return acc;
 }
 
-// S1: W = G_v D^-1 in place (rows of both sides): [Gv_x * dt/m , Gv_phi * D_R^-1]
-HD void ph_schur_w(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
-    for (int e = t; e < 10 * nb; e += G) {
-        int j = e / 10, rr = e - 10 * j, side = rr / 5, row = rr - 5 * side;
-        int body = side ? j : M->parent[j];
-        if (body < 0) continue;
-        double* w = L + (side ? Y.GVB : Y.GVA) + BLK * j + 6 * row;
-        double dtm = L[Y.DTM + body];
-        const double* Di = L + Y.DINV + 9 * body;
-        double a = w[3], b = w[4], c = w[5];
-        w[0] *= dtm; w[1] *= dtm; w[2] *= dtm;
-        w[3] = a * Di[0] + b * Di[3] + c * Di[6];
-        w[4] = a * Di[1] + b * Di[4] + c * Di[7];
-        w[5] = a * Di[2] + b * Di[5] + c * Di[8];
-    }
-}
-
 HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 
-// S2: Schur complement blocks and right-hand side
-//   S_jj = W_b Gk_b' + W_a Gk_a' ; S_jp = W_a(j) Gk_b(p)' ; S_pj = W_b(p) Gk_a(j)' ; r_j = g_j - W_b d_b - W_a d_a
-HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
-    for (int e = t; e < 25 * nb; e += G) {
-        int j = e / 25, rc = e - 25 * j, row = rc / 5, col = rc - 5 * row;
-        int p = M->parent[j];
-        const double* Wb = L + Y.GVB + BLK * j + 6 * row;
-        double s = dot6(Wb, L + Y.GKB + BLK * j + 6 * col);
-        if (p >= 0) {
-            const double* Wa = L + Y.GVA + BLK * j + 6 * row;
-            s += dot6(Wa, L + Y.GKA + BLK * j + 6 * col);
-            L[Y.SJP + e] = dot6(Wa, L + Y.GKB + BLK * p + 6 * col);
-            L[Y.SPJ + e] = dot6(L + Y.GVB + BLK * p + 6 * row, L + Y.GKA + BLK * j + 6 * col);
+// S2: Schur complement blocks and right-hand side, one task per (joint, row); two branch-uniform passes:
+//   pass 0: row of S_jj = W_b Gk_b' + W_a Gk_a'  and  r_j = g_j - W_b d_b - W_a d_a
+//   pass 1: rows of S_jp = W_a(j) Gk_b(p)'  and  S_pj = W_b(p) Gk_a(j)'     (p = j-1, the parent link)
+// Each task loads all its operands into registers, computes, then stores (no store between loads).
+HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, unsigned start_mask) {
+    for (int e = t; e < 5 * nb; e += G) {
+        int j = e / 5, row = e - 5 * j;
+        bool has_p = !((start_mask >> j) & 1u);
+        double wb[6], wa[6], gb[30], ga[30], db[6], da[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { wb[i] = L[Y.GVB + BLK * j + 6 * row + i]; db[i] = L[Y.D + 6 * j + i]; }
+#pragma unroll
+        for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * j + i];
+        double g0 = L[Y.G + 5 * j + row];
+        if (has_p) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { wa[i] = L[Y.GVA + BLK * j + 6 * row + i]; da[i] = L[Y.D + 6 * (j - 1) + i]; }
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * j + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { wa[i] = 0.0; da[i] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = 0.0;
         }
-        L[Y.SJJ + e] = s;
+        double o[5];
+#pragma unroll
+        for (int col = 0; col < 5; col++) o[col] = dot6(wb, gb + 6 * col) + dot6(wa, ga + 6 * col);
+        double rr = g0 - dot6(wb, db) - dot6(wa, da);
+#pragma unroll
+        for (int col = 0; col < 5; col++) L[Y.SJJ + 25 * j + 5 * row + col] = o[col];
+        L[Y.R + 5 * j + row] = rr;
     }
     for (int e = t; e < 5 * nb; e += G) {
         int j = e / 5, row = e - 5 * j;
-        int p = M->parent[j];
-        double s = L[Y.G + e] - dot6(L + Y.GVB + BLK * j + 6 * row, L + Y.D + 6 * j);
-        if (p >= 0) s -= dot6(L + Y.GVA + BLK * j + 6 * row, L + Y.D + 6 * p);
-        L[Y.R + e] = s;
+        if ((start_mask >> j) & 1u) continue;
+        int p = j - 1;
+        double wa[6], wp[6], gpb[30], gja[30];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { wa[i] = L[Y.GVA + BLK * j + 6 * row + i]; wp[i] = L[Y.GVB + BLK * p + 6 * row + i]; }
+#pragma unroll
+        for (int i = 0; i < 30; i++) { gpb[i] = L[Y.GKB + BLK * p + i]; gja[i] = L[Y.GKA + BLK * j + i]; }
+        double o1[5], o2[5];
+#pragma unroll
+        for (int col = 0; col < 5; col++) { o1[col] = dot6(wa, gpb + 6 * col); o2[col] = dot6(wp, gja + 6 * col); }
+#pragma unroll
+        for (int col = 0; col < 5; col++) { L[Y.SJP + 25 * j + 5 * row + col] = o1[col]; L[Y.SPJ + 25 * j + 5 * row + col] = o2[col]; }
     }
 }
 
-// S3a: eliminate link l into its parent (lanes t < 5, each owns one row).  LU (no pivoting; S is SPD-like) of S_ll is
-// computed redundantly by the 5 lanes; lane t keeps row t of the packed LU (unit L, reciprocal diagonal) in lu[5].
-HD void ph_tri_fwd(int t, int l, const Lay& Y, double* L, const MechDev* M, double* lu) {
-    if (t >= 5) return;
-    double A[25];
-    for (int i = 0; i < 25; i++) A[i] = L[Y.SJJ + 25 * l + i];
+// ---- S3: block-tridiagonal solve along one chain [cs, cs+cn), swept from BOTH ends at once (twisted factorisation).
+// Two "fronts" run the same instruction stream on different lanes: front 0 = lanes 0..4 eliminates from the leaf towards
+// the middle link, front 1 = lanes 8..12 from the root towards the middle; lane (t & 7) owns one row.  Link numbering
+// inside a chain: parent of l is l-1.  Block names: SJP[l] = S_{l,l-1}, SPJ[l] = S_{l-1,l}.
+struct TriPlan { int cs, cn, nA, nB, mid, steps; };
+HD TriPlan tri_plan(int cs, int cn) {
+    TriPlan P;
+    P.cs = cs; P.cn = cn;
+    int rest = cn - 1;
+    P.nB = (rest + 1) / 2 + ((rest % 2 == 0 && rest > 0) ? 1 : 0);   // top-down count; unequal counts keep the two last updates of the middle apart
+    if (P.nB > rest) P.nB = rest;
+    P.nA = rest - P.nB;                                                // bottom-up count
+    P.mid = cs + P.nB;
+    P.steps = P.nB > P.nA ? P.nB : P.nA;
+    return P;
+}
+// LU (no pivoting; S is SPD-like) of the 5x5 block at L[off], all in registers with static indices
+HD void lu5(const double* L, int off, double* A) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) A[i] = L[off + i];
+#pragma unroll
     for (int k = 0; k < 5; k++) {
-        double inv = 1.0 / A[k * 5 + k];
+        double inv = fast_rcp(A[k * 5 + k]);
         A[k * 5 + k] = inv;
+#pragma unroll
         for (int i = k + 1; i < 5; i++) {
             double f = A[i * 5 + k] * inv;
             A[i * 5 + k] = f;
+#pragma unroll
             for (int j = k + 1; j < 5; j++) A[i * 5 + j] -= f * A[k * 5 + j];
         }
     }
-    for (int j = 0; j < 5; j++) lu[j] = A[t * 5 + j];
-    int p = M->parent[l];
-    if (p < 0) return;
-    // row t of T = S_pl S_ll^-1:  x U = b (columns ascending), then y L = x (columns descending)
+}
+// elimination step i: front 0 folds link l = cs+cn-1-i into q = l-1, front 1 folds l = cs+i into q = l+1.
+// Every lane of a front factorises S_ll redundantly (same latency as one lane) and then owns one row of the update of
+// S_qq and r_q.  lu[25] keeps the packed LU; the front's lane 0 stores it afterwards (ph_tri_store).
+HD bool ph_tri_elim(int t, int i, const TriPlan& P, const Lay& Y, double* L, double* lu, int* l_out) {
+    const int front = t >> 3, row = t & 7;
+    if (t >= 16 || row >= 5) return false;
+    if (i >= (front ? P.nB : P.nA)) return false;
+    const int l = front ? P.cs + i : P.cs + P.cn - 1 - i;
+    const int q = front ? l + 1 : l - 1;
+    const int oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * l;   // S_{q,l}
+    const int oLQ = front ? Y.SPJ + 25 * q : Y.SJP + 25 * l;   // S_{l,q}
+    // ---- loads
+    double bq[5], slq[25], rl[5], sqq[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) { bq[c] = L[oQL + 5 * row + c]; rl[c] = L[Y.R + 5 * l + c]; sqq[c] = L[Y.SJJ + 25 * q + 5 * row + c]; }
+#pragma unroll
+    for (int c = 0; c < 25; c++) slq[c] = L[oLQ + c];
+    double rq = L[Y.R + 5 * q + row];
+    lu5(L, Y.SJJ + 25 * l, lu);
+    // ---- row of T = S_ql S_ll^-1:  x U = b (columns ascending), then y L = x (columns descending)
     double x[5];
+#pragma unroll
     for (int c = 0; c < 5; c++) {
-        double s = L[Y.SPJ + 25 * l + 5 * t + c];
-        for (int k = 0; k < c; k++) s -= x[k] * A[k * 5 + c];
-        x[c] = s * A[c * 5 + c];
+        double s = bq[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) s -= x[k] * lu[k * 5 + c];
+        x[c] = s * lu[c * 5 + c];
     }
+#pragma unroll
     for (int c = 4; c >= 0; c--) {
         double s = x[c];
-        for (int k = c + 1; k < 5; k++) s -= x[k] * A[k * 5 + c];
+#pragma unroll
+        for (int k = c + 1; k < 5; k++) s -= x[k] * lu[k * 5 + c];
         x[c] = s;
     }
-    const double* Slp = L + Y.SJP + 25 * l;
-    for (int c = 0; c < 5; c++)
-        L[Y.SJJ + 25 * p + 5 * t + c] -= x[0] * Slp[c] + x[1] * Slp[5 + c] + x[2] * Slp[10 + c] + x[3] * Slp[15 + c] + x[4] * Slp[20 + c];
-    const double* rl = L + Y.R + 5 * l;
-    L[Y.R + 5 * p + t] -= x[0] * rl[0] + x[1] * rl[1] + x[2] * rl[2] + x[3] * rl[3] + x[4] * rl[4];
+#pragma unroll
+    for (int c = 0; c < 5; c++) sqq[c] -= x[0] * slq[c] + x[1] * slq[5 + c] + x[2] * slq[10 + c] + x[3] * slq[15 + c] + x[4] * slq[20 + c];
+    rq -= x[0] * rl[0] + x[1] * rl[1] + x[2] * rl[2] + x[3] * rl[3] + x[4] * rl[4];
+    // ---- stores
+#pragma unroll
+    for (int c = 0; c < 5; c++) L[Y.SJJ + 25 * q + 5 * row + c] = sqq[c];
+    L[Y.R + 5 * q + row] = rq;
+    *l_out = l;
+    return row == 0;
 }
-// S3b: store the packed LU of link l (lane t writes row t)
 HD void ph_tri_store(int t, int l, const Lay& Y, double* L, const double* lu) {
-    if (t >= 5) return;
-    for (int j = 0; j < 5; j++) L[Y.SJJ + 25 * l + 5 * t + j] = lu[j];
+#pragma unroll
+    for (int j = 0; j < 25; j++) L[Y.SJJ + 25 * l + j] = lu[j];
 }
-// S3c: back substitution for link l (root to leaf): dl_l = S_ll^-1 (r_l - S_lp dl_p); lane t writes component t
-HD void ph_tri_bwd(int t, int l, const Lay& Y, double* L, const MechDev* M) {
-    if (t >= 5) return;
-    double A[25], b[5];
-    for (int i = 0; i < 25; i++) A[i] = L[Y.SJJ + 25 * l + i];
-    int p = M->parent[l];
-    for (int i = 0; i < 5; i++) {
-        double s = L[Y.R + 5 * l + i];
-        if (p >= 0) {
-            const double* Sr = L + Y.SJP + 25 * l + 5 * i;
-            const double* dp = L + Y.DL + 5 * p;
-            s -= Sr[0] * dp[0] + Sr[1] * dp[1] + Sr[2] * dp[2] + Sr[3] * dp[3] + Sr[4] * dp[4];
-        }
-        b[i] = s;
-    }
-    for (int i = 1; i < 5; i++)
+// forward/back substitution with the packed LU in registers
+HD void lu5_solve(const double* A, double* b) {
+#pragma unroll
+    for (int i = 1; i < 5; i++) {
+#pragma unroll
         for (int k = 0; k < i; k++) b[i] -= A[i * 5 + k] * b[k];
+    }
+#pragma unroll
     for (int i = 4; i >= 0; i--) {
+#pragma unroll
         for (int k = i + 1; k < 5; k++) b[i] -= A[i * 5 + k] * b[k];
         b[i] *= A[i * 5 + i];
     }
-    L[Y.DL + 5 * l + t] = b[t];
+}
+// middle link: factorise (both sides have been folded in) and solve; one lane
+HD void ph_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
+    if (t != 0) return;
+    double A[25], b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) b[i] = L[Y.R + 5 * P.mid + i];
+    lu5(L, Y.SJJ + 25 * P.mid, A);
+    lu5_solve(A, b);
+#pragma unroll
+    for (int i = 0; i < 5; i++) L[Y.DL + 5 * P.mid + i] = b[i];
+}
+// back substitution step j: front 0 (lane 0) solves l = mid+1+j from dl_{l-1}, front 1 (lane 8) solves l = mid-1-j from dl_{l+1}
+HD void ph_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
+    const int front = t >> 3;
+    if (t != 0 && t != 8) return;
+    if (j >= (front ? P.nB : P.nA)) return;
+    const int l = front ? P.mid - 1 - j : P.mid + 1 + j;
+    const int nbr = front ? l + 1 : l - 1;
+    const int oLN = front ? Y.SPJ + 25 * nbr : Y.SJP + 25 * l;   // S_{l,nbr}
+    double A[25], S[25], b[5], dn[5];
+#pragma unroll
+    for (int i = 0; i < 25; i++) { A[i] = L[Y.SJJ + 25 * l + i]; S[i] = L[oLN + i]; }   // A = packed LU stored by ph_tri_store
+#pragma unroll
+    for (int i = 0; i < 5; i++) { b[i] = L[Y.R + 5 * l + i]; dn[i] = L[Y.DL + 5 * nbr + i]; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) b[i] -= S[5 * i] * dn[0] + S[5 * i + 1] * dn[1] + S[5 * i + 2] * dn[2] + S[5 * i + 3] * dn[3] + S[5 * i + 4] * dn[4];
+    lu5_solve(A, b);
+#pragma unroll
+    for (int i = 0; i < 5; i++) L[Y.DL + 5 * l + i] = b[i];
 }
 
 // S4: ds_b = D_b^-1 (d_b + sum_j Gk_jb' dl_j)
-HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
     for (int e = t; e < 6 * nb; e += G) {
         int b = e / 6, c = e - 6 * b;
-        int ch = M->childl[b];
+        bool has_c = !((end_mask >> b) & 1u);
         double tv[3];
         int c0 = (c < 3) ? c : 3, n = (c < 3) ? 1 : 3;
         for (int q = 0; q < n; q++) {
@@ -477,9 +599,9 @@ HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, const MechD
             const double* Gb = L + Y.GKB + BLK * b;
             const double* lb = L + Y.DL + 5 * b;
             double s = L[Y.D + 6 * b + cc] + Gb[cc] * lb[0] + Gb[6 + cc] * lb[1] + Gb[12 + cc] * lb[2] + Gb[18 + cc] * lb[3] + Gb[24 + cc] * lb[4];
-            if (ch >= 0) {
-                const double* Ga = L + Y.GKA + BLK * ch;
-                const double* lc = L + Y.DL + 5 * ch;
+            if (has_c) {
+                const double* Ga = L + Y.GKA + BLK * (b + 1);
+                const double* lc = L + Y.DL + 5 * (b + 1);
                 s += Ga[cc] * lc[0] + Ga[6 + cc] * lc[1] + Ga[12 + cc] * lc[2] + Ga[18 + cc] * lc[3] + Ga[24 + cc] * lc[4];
             }
             tv[q] = s;

@@ -6,7 +6,7 @@
 // term d(G(z)' lambda*)/dz and the state dependence of the applied joint input (arXiv:2010.05886).
 //
 // Runs after one converged Newton step on the setpoint held in LDS: S = (v+, w+), LAM = lambda*, XQ = next pose,
-// DINV = D_R(w+)^-1, NB = N(w+), GKA/GKB = G at the current knot, UJ = joint inputs.
+// DINV = D_R(w+)^-1 (N(w+) is recomputed here), GKA/GKB = G at the current knot, UJ = joint inputs.
 #pragma once
 #include "cclqr_dev.h"
 
@@ -164,7 +164,11 @@ HD void ph_lin_rows_A(int t, int nb, const Lay& Y, int JB, const double* L, cons
     if (t >= nb) return;
     const double dt = M->dt, dtm = dt / r.m;
     const double* Dinv = L + Y.DINV + 9 * t;
-    const double* N = L + Y.NB + 9 * t;
+    double N[9];
+    {
+        const double* w2n = L + Y.S + 6 * t + 3;
+        make_N(w2n, sqrt(4.0 / (dt * dt) - (w2n[0] * w2n[0] + w2n[1] * w2n[1] + w2n[2] * w2n[2])), dt, N);
+    }
     const double* own = L + JB + LJB * t;
     const int a = r.parent, c = r.childl;
     const double* ch = (c >= 0) ? L + JB + LJB * c : nullptr;
@@ -238,7 +242,11 @@ HD void ph_lin_rows_B(int t, int nb, const Lay& Y, const double* L, const LaneRe
     if (t >= nb) return;
     const double dt = M->dt, dtm = dt / r.m;
     const double* Dinv = L + Y.DINV + 9 * t;
-    const double* N = L + Y.NB + 9 * t;
+    double N[9];
+    {
+        const double* w2n = L + Y.S + 6 * t + 3;
+        make_N(w2n, sqrt(4.0 / (dt * dt) - (w2n[0] * w2n[0] + w2n[1] * w2n[1] + w2n[2] * w2n[2])), dt, N);
+    }
     const int rb = 12 * M->perm[t];
     const int c = r.childl;
     // the joint of link l is the caller's joint jperm(l): constraint rows keep the caller's joint numbering
@@ -280,7 +288,7 @@ HD void ph_lin_rows_B(int t, int nb, const Lay& Y, const double* L, const LaneRe
         const double* pa = (a >= 0) ? L + Y.XQ + 7 * a : nullptr;
         const double* pb = L + Y.XQ + 7 * t;
         double g[5], Ba[30], Bb[30];
-        joint_eval(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, 1.0, nullptr, nullptr, g, Ba, Bb);
+        joint_eval<true>(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, 1.0, 1.0, nullptr, nullptr, g, Ba, Bb);
         for (int row = 0; row < 5; row++) {
             double* Gr = O.G + (size_t)(5 * M->jperm[t] + row) * O.mx;
             for (int q = 0; q < 3; q++) {

@@ -5,6 +5,29 @@
 
 namespace cclqr {
 
+// ---- optional in-kernel phase stamps (diagnostic build only: -DCCLQR_PROFILE; the shipped library contains none) ----
+#ifdef CCLQR_PROFILE
+enum { PF_CONTROL, PF_FORCES, PF_EVAL_BODY, PF_EVAL_JOINT, PF_EVAL_MAP, PF_SCHUR_W, PF_SCHUR_S, PF_TRI_FWD, PF_TRI_BWD, PF_BODY_SOLVE, PF_TRIAL,
+       PF_ACCEPT, PF_IO, PF_NEWTON_ITERS, PF_EVALS, PF_STEPS, PF_N };
+static __device__ unsigned long long g_prof[PF_N];
+struct Prof {
+    unsigned long long t0, acc[PF_N];
+    __device__ void start() { for (int i = 0; i < PF_N; i++) acc[i] = 0; t0 = __builtin_readcyclecounter(); }
+    __device__ void stamp(int c) { unsigned long long t1 = __builtin_readcyclecounter(); acc[c] += t1 - t0; t0 = t1; }
+    __device__ void count(int c, int n = 1) { acc[c] += n; }
+    __device__ void flush() { if ((threadIdx.x & 63) == 0) for (int i = 0; i < PF_N; i++) atomicAdd(&g_prof[i], acc[i]); }
+};
+#define PROF_ARG , Prof& prof
+#define PROF_PASS , prof
+#define STAMP(c) prof.stamp(c)
+#define PCOUNT(c) prof.count(c)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define STAMP(c)
+#define PCOUNT(c)
+#endif
+
 #define NEWTON_EPS 1e-10
 #define NEWTON_MAXIT 100
 #define LINE_MAXIT 10
@@ -16,70 +39,96 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
-// residual + Jacobians at the point stored at (s_off, lam_off); returns the group's ||f||_2
-template <int G>
+// residual (+ Jacobians when JAC) at the point stored at (s_off, lam_off); returns the group's ||f||_2
+template <int G, bool JAC>
 __device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M, double dt,
-                                             int s_off, int lam_off, bool active) {
-    if (active) ph_body_eval(t, nb, Y, L, r, dt, s_off);
+                                             int s_off, int lam_off, bool active PROF_ARG) {
+    if (active) ph_body_eval<JAC>(t, nb, Y, L, r, dt, s_off);
     __syncthreads();
-    if (active) ph_joint_eval(t, nb, Y, L, r, dt);
+    STAMP(PF_EVAL_BODY);
+    if (active) ph_joint_eval<JAC>(t, nb, Y, L, r, dt);
     __syncthreads();
-    double part = active ? ph_force_map_norm(t, G, nb, Y, L, M, lam_off) : 0.0;
-    return sqrt(group_sum<G>(part));
+    STAMP(PF_EVAL_JOINT);
+    double part = active ? ph_force_map_norm(t, G, nb, Y, L, M->end_mask, lam_off) : 0.0;
+    double nrm = sqrt(group_sum<G>(part));
+    STAMP(PF_EVAL_MAP);
+    PCOUNT(PF_EVALS);
+    return nrm;
 }
 
-
-// newton! on the instance held in LDS (S/LAM = guess in, solution out; XQ/NB/DINV/GV* = values at the solution).
+// newton! on the instance held in LDS (S/LAM = guess in, solution out; XQ = next pose of the solution).
 // valid=false groups only keep the wave's control flow uniform.  Returns iterations used; *converged reports success.
+// After a successful return DINV/NB/GV* hold the values at the solution only if the last accepted trial was a full step
+// (callers that need them -- the linearisation -- re-evaluate).
 template <int G>
 __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt, bool valid,
-                                            bool* converged) {
-    double normf0 = eval_point<G>(t, nb, Y, L, r, M, dt, Y.S, Y.LAM, valid);
+                                            bool* converged PROF_ARG) {
+    double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, Y.LAM, valid PROF_PASS);
     bool done = !valid;
     int its = 0;
+    const unsigned smask = M->start_mask, emask = M->end_mask;
+    const int nchains = M->nchains;
     for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
         if (!__any(!done)) break;
-        // Schur complement on the multipliers, block-tridiagonal solve along each chain, body back-substitution
-        if (!done) ph_schur_w(t, G, nb, Y, L, M);
+        PCOUNT(PF_NEWTON_ITERS);
+        // Schur complement on the multipliers
+        if (!done) ph_schur_s(t, G, nb, Y, L, smask);
         __syncthreads();
-        if (!done) ph_schur_s(t, G, nb, Y, L, M);
-        __syncthreads();
-        for (int l = nb - 1; l >= 0; l--) {
-            double lu[5];
-            if (!done) ph_tri_fwd(t, l, Y, L, M, lu);
+        STAMP(PF_SCHUR_S);
+        // block-tridiagonal solve along each chain, swept from both ends
+        for (int c = 0; c < nchains; c++) {
+            const TriPlan P = tri_plan(M->chain_start[c], M->chain_len[c]);
+            for (int i = 0; i < P.steps; i++) {
+                double lu[25];
+                int l = 0;
+                bool act = !done && ph_tri_elim(t, i, P, Y, L, lu, &l);
+                __syncthreads();
+                if (act) ph_tri_store(t, l, Y, L, lu);
+                __syncthreads();
+            }
+            STAMP(PF_TRI_FWD);
+            if (!done) ph_tri_mid(t, P, Y, L);
             __syncthreads();
-            if (!done) ph_tri_store(t, l, Y, L, lu);
-            __syncthreads();
+            for (int j = 0; j < P.steps; j++) {
+                if (!done) ph_tri_back(t, j, P, Y, L);
+                __syncthreads();
+            }
+            STAMP(PF_TRI_BWD);
         }
-        for (int l = 0; l < nb; l++) {
-            if (!done) ph_tri_bwd(t, l, Y, L, M);
-            __syncthreads();
-        }
-        if (!done) ph_body_solve(t, G, nb, Y, L, M);
+        if (!done) ph_body_solve(t, G, nb, Y, L, emask);
         __syncthreads();
-        // line search: halve while ||f|| grows
+        STAMP(PF_BODY_SOLVE);
+        // line search: halve while ||f|| grows.  The first (full-step) trial also evaluates the Jacobians, speculating that it
+        // is accepted; later trials evaluate the residual only.
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;
-        bool ls_done = done;
+        bool ls_done = done, jac_ok = true;
         for (int ls = 0; ls <= LINE_MAXIT; ls++) {
             if (!__any(!ls_done)) break;
             double pd = ls_done ? 0.0 : ph_trial(t, G, nb, Y, L, alpha);
             double nd2 = group_sum<G>(pd);
             if (ls == 0) nd = sqrt(nd2);
             __syncthreads();
-            double nf = eval_point<G>(t, nb, Y, L, r, M, dt, Y.ST, Y.LT, !ls_done);
+            STAMP(PF_TRIAL);
+            double nf = (ls == 0) ? eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.ST, Y.LT, !ls_done PROF_PASS)
+                                  : eval_point<G, false>(t, nb, Y, L, r, M, dt, Y.ST, Y.LT, !ls_done PROF_PASS);
             if (!ls_done) {
                 normf1 = nf;
+                if (ls > 0) jac_ok = false;
                 if (normf1 > normf0 && ls < LINE_MAXIT) alpha *= 0.5; else ls_done = true;
             }
             __syncthreads();
         }
+        bool need_jac = false;
         if (!done) {
             ph_accept(t, G, nb, Y, L);
             its = iter;
             if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
             normf0 = normf1;
+            need_jac = !done && !jac_ok;
         }
         __syncthreads();
+        STAMP(PF_ACCEPT);
+        if (__any(need_jac)) eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, Y.LAM, need_jac PROF_PASS);
     }
     *converged = done;
     return its;

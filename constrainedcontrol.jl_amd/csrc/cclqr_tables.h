@@ -43,10 +43,21 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
     }
     for (int b = 0; b < nb; b++)
         if (nchild[b] > 1) { err = "a body with more than one child joint (branching tree) is not supported yet"; return CCLQR_EUNSUPPORTED; }
-    std::vector<int> bfs;
-    for (int j = 0; j < nb; j++) if (d->parent[j] == -1) bfs.push_back(d->child[j]);
-    for (size_t h = 0; h < bfs.size(); h++)
-        for (int j = 0; j < nb; j++) if (d->parent[j] == bfs[h]) bfs.push_back(d->child[j]);
+    // link order: chain by chain (every body has at most one child joint, so the mechanism is a forest of chains), root to leaf
+    std::vector<int> bfs, cstart, clen;
+    for (int j = 0; j < nb; j++)
+        if (d->parent[j] == -1) {
+            cstart.push_back((int)bfs.size());
+            int b = d->child[j];
+            while (b >= 0) {
+                bfs.push_back(b);
+                int nxt = -1;
+                for (int k = 0; k < nb; k++) if (d->parent[k] == b) nxt = d->child[k];
+                b = nxt;
+                if ((int)bfs.size() > nb) break;
+            }
+            clen.push_back((int)bfs.size() - cstart.back());
+        }
     if ((int)bfs.size() != nb) { err = "mechanism is not a tree rooted at the origin"; return CCLQR_EINVAL; }
 
     memset(&m->host, 0, sizeof(MechDev));
@@ -82,6 +93,15 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
         }
     }
     for (int l = 0; l < nb; l++) if (H.parent[l] >= 0) H.childl[H.parent[l]] = l;
+    H.nchains = (int)cstart.size();
+    H.start_mask = 0; H.end_mask = 0;
+    for (int c = 0; c < H.nchains; c++) {
+        H.chain_start[c] = cstart[c]; H.chain_len[c] = clen[c];
+        H.start_mask |= 1u << cstart[c];
+        H.end_mask |= 1u << (cstart[c] + clen[c] - 1);
+    }
+    for (int l = 0; l < nb; l++)
+        if (H.parent[l] != (((H.start_mask >> l) & 1u) ? -1 : l - 1)) { err = "internal: link order is not chain-contiguous"; return CCLQR_EINVAL; }
     return CCLQR_OK;
 }
 

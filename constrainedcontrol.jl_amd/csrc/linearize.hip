@@ -41,7 +41,14 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     ph_knot_jac(t, nb, Y, L, r);
     __syncthreads();
     bool done = false;
-    int its = newton_solve<G>(t, nb, Y, L, r, M, dt, true, &done);
+#ifdef CCLQR_PROFILE
+    Prof prof;
+    prof.start();
+#endif
+    int its = newton_solve<G>(t, nb, Y, L, r, M, dt, true, &done PROF_PASS);
+    __syncthreads();
+    // D_R^-1 and the next pose at the converged solution (the last line-search trial may have been residual-only)
+    ph_body_eval<true>(t, nb, Y, L, r, dt, Y.S);
     __syncthreads();
     ph_lin_joint(t, nb, Y, JB, L, r);
     __syncthreads();

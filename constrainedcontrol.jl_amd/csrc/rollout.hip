@@ -26,6 +26,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 
     LaneRegs r;
     lane_load_consts(r, M, t < nb ? t : 0);
+#ifdef CCLQR_PROFILE
+    Prof prof;
+    prof.start();
+#endif
 
     if (valid) {
         for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = a.z0[inst * nz + M->perm[l] * 13 + c]; }
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (a.traj && valid)
             for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.traj[((size_t)inst * a.steps + kk) * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
 
+        STAMP(PF_IO);
         // ---------------- feedback law (lqr.jl:89-139 / lqr_tracking.jl:46-71)
         const bool gate = (C->N <= 0) || (k < C->N);
         const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
@@ -63,14 +68,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 __syncthreads();
             }
         }
+        STAMP(PF_CONTROL);
         // ---------------- per-step invariants
         ph_forces(t, nb, Y, L, r, M);
         ph_knot_jac(t, nb, Y, L, r);
         __syncthreads();
+        STAMP(PF_FORCES);
+        PCOUNT(PF_STEPS);
 
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool done = false;
-        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid, &done);
+        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid, &done PROF_PASS);
         if (valid) { if (!done) bad = true; if (its > worst) worst = its; }
         if (valid) ph_update(t, nb, Y, L);
         __syncthreads();
@@ -80,7 +88,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (a.lam) for (int e = t; e < 5 * nb; e += G) a.lam[inst * 5 * nb + e] = L[Y.LAM + e];
         if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
     }
+#ifdef CCLQR_PROFILE
+    prof.stamp(PF_IO);
+    prof.flush();
+#endif
 }
+
+#ifdef CCLQR_PROFILE
+extern "C" int cclqr_prof_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PF_N);
+    if (e == hipSuccess && reset) { unsigned long long z[PF_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return e == hipSuccess ? PF_N : -1;
+}
+#endif
 
 int rollout_lanes_per_instance(int nb) { return nb <= 4 ? 16 : (nb <= 8 ? 32 : 64); }
 

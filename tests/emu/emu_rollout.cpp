@@ -9,12 +9,53 @@
 
 using namespace cclqr;
 
+template <bool JAC>
 static double eval_point(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, int s_off, int lam_off) {
-    for (int t = 0; t < G; t++) ph_body_eval(t, nb, Y, L, R[t], dt, s_off);
-    for (int t = 0; t < G; t++) ph_joint_eval(t, nb, Y, L, R[t], dt);
+    for (int t = 0; t < G; t++) ph_body_eval<JAC>(t, nb, Y, L, R[t], dt, s_off);
+    for (int t = 0; t < G; t++) ph_joint_eval<JAC>(t, nb, Y, L, R[t], dt);
     double acc = 0.0;
-    for (int t = 0; t < G; t++) acc += ph_force_map_norm(t, G, nb, Y, L, M, lam_off);
+    for (int t = 0; t < G; t++) acc += ph_force_map_norm(t, G, nb, Y, L, M->end_mask, lam_off);
     return sqrt(acc);
+}
+
+// serial twin of cclqr_newton.h newton_solve<G> (one group)
+static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, bool* converged) {
+    double normf0 = eval_point<true>(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+    bool done = false;
+    int its = 0;
+    for (int iter = 1; iter <= 100 && !done; iter++) {
+        for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M->start_mask);
+        for (int c = 0; c < M->nchains; c++) {
+            const TriPlan P = tri_plan(M->chain_start[c], M->chain_len[c]);
+            for (int i = 0; i < P.steps; i++) {
+                double lu[64][25];
+                int l[64];
+                bool act[64];
+                for (int t = 0; t < G; t++) act[t] = ph_tri_elim(t, i, P, Y, L, lu[t], &l[t]);
+                for (int t = 0; t < G; t++) if (act[t]) ph_tri_store(t, l[t], Y, L, lu[t]);
+            }
+            for (int t = 0; t < G; t++) ph_tri_mid(t, P, Y, L);
+            for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ph_tri_back(t, j, P, Y, L);
+        }
+        for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M->end_mask);
+        double alpha = 1.0, normf1 = 0.0, nd = 0.0;
+        bool jac_ok = true;
+        for (int ls = 0; ls <= 10; ls++) {
+            double pd = 0.0;
+            for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
+            if (ls == 0) nd = sqrt(pd);
+            normf1 = (ls == 0) ? eval_point<true>(G, nb, Y, L, R, M, dt, Y.ST, Y.LT) : eval_point<false>(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
+            if (ls > 0) jac_ok = false;
+            if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
+        }
+        for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
+        its = iter;
+        if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
+        normf0 = normf1;
+        if (!done && !jac_ok) eval_point<true>(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+    }
+    *converged = done;
+    return its;
 }
 
 extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd, int64_t n_inst, int steps, int k0, const double* z0,
@@ -62,31 +103,8 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     L[Y.UJ + C->cj[i]] += u;
                 }
             for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
-            double normf0 = eval_point(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
-            bool done = false; int its = 0;
-            for (int iter = 1; iter <= 100 && !done; iter++) {
-                for (int t = 0; t < G; t++) ph_schur_w(t, G, nb, Y, L, M);
-                for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M);
-                for (int l = nb - 1; l >= 0; l--) {
-                    double lu[64][5];
-                    for (int t = 0; t < G; t++) ph_tri_fwd(t, l, Y, L, M, lu[t]);
-                    for (int t = 0; t < G; t++) ph_tri_store(t, l, Y, L, lu[t]);
-                }
-                for (int l = 0; l < nb; l++) for (int t = 0; t < G; t++) ph_tri_bwd(t, l, Y, L, M);
-                for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M);
-                double alpha = 1.0, normf1 = 0.0, nd = 0.0;
-                for (int ls = 0; ls <= 10; ls++) {
-                    double pd = 0.0;
-                    for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
-                    if (ls == 0) nd = sqrt(pd);
-                    normf1 = eval_point(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
-                    if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
-                }
-                for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
-                its = iter;
-                if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
-                normf0 = normf1;
-            }
+            bool done = false;
+            int its = emu_newton(G, nb, Y, L, R, M, dt, &done);
             if (!done) bad = true;
             if (its > worst) worst = its;
             for (int t = 0; t < G; t++) ph_update(t, nb, Y, L);
@@ -125,31 +143,10 @@ extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu
     for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = zd[M->perm[l] * 13 + c]; }
     for (int i = 0; i < mu; i++) L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0;
     for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
-    double normf0 = eval_point(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
     bool done = false;
-    for (int iter = 1; iter <= 100 && !done; iter++) {
-        for (int t = 0; t < G; t++) ph_schur_w(t, G, nb, Y, L, M);
-        for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M);
-        for (int l = nb - 1; l >= 0; l--) {
-            double lu[64][5];
-            for (int t = 0; t < G; t++) ph_tri_fwd(t, l, Y, L, M, lu[t]);
-            for (int t = 0; t < G; t++) ph_tri_store(t, l, Y, L, lu[t]);
-        }
-        for (int l = 0; l < nb; l++) for (int t = 0; t < G; t++) ph_tri_bwd(t, l, Y, L, M);
-        for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M);
-        double alpha = 1.0, normf1 = 0.0, nd = 0.0;
-        for (int ls = 0; ls <= 10; ls++) {
-            double pd = 0.0;
-            for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
-            if (ls == 0) nd = sqrt(pd);
-            normf1 = eval_point(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
-            if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
-        }
-        for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
-        if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
-        normf0 = normf1;
-    }
+    emu_newton(G, nb, Y, L, R, M, dt, &done);
     if (!done) return -3;
+    for (int t = 0; t < G; t++) ph_body_eval<true>(t, nb, Y, L, R[t], dt, Y.S);
     for (int t = 0; t < G; t++) ph_lin_joint(t, nb, Y, JB, L, R[t]);
     for (int t = 0; t < G; t++) { ph_lin_rows_A(t, nb, Y, JB, L, R[t], M, O); ph_lin_rows_B(t, nb, Y, L, R[t], M, cj, O); }
     return 0;
