@@ -387,76 +387,83 @@ HD void ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r,
 HD int link_parent(const MechDev* M, int l) { return ((M->start_mask >> l) & 1u) ? -1 : l - 1; }
 HD int link_child(const MechDev* M, int l) { return ((M->end_mask >> l) & 1u) ? -1 : l + 1; }
 
-// E3: d -= G_k' lambda (lambda at lam_off) and partial sum of squares of the residual entries this lane touches
+// E3: d_b -= Gk_b(own joint)' lambda_b + Gk_a(child joint)' lambda_child, one task per body; returns the partial sum of squares
+// of the residual entries (d_b and g_b) this lane owns
 HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask, int lam_off) {
     double acc = 0.0;
-    for (int e = t; e < 6 * nb; e += G) {
-        int b = e / 6, c = e - 6 * b;
-        const double* Gb = L + Y.GKB + BLK * b;
-        const double* lb = L + lam_off + 5 * b;
-        double s = Gb[c] * lb[0] + Gb[6 + c] * lb[1] + Gb[12 + c] * lb[2] + Gb[18 + c] * lb[3] + Gb[24 + c] * lb[4];
-        if (!((end_mask >> b) & 1u)) {
-            const double* Ga = L + Y.GKA + BLK * (b + 1);
-            const double* lc = L + lam_off + 5 * (b + 1);
-            s += Ga[c] * lc[0] + Ga[6 + c] * lc[1] + Ga[12 + c] * lc[2] + Ga[18 + c] * lc[3] + Ga[24 + c] * lc[4];
+    for (int b = t; b < nb; b += G) {
+        const bool has_c = !((end_mask >> b) & 1u);
+        double d[6], gb[30], lb[5], ga[30], lc[5], g[5];
+#pragma unroll
+        for (int i = 0; i < 6; i++) d[i] = L[Y.D + 6 * b + i];
+#pragma unroll
+        for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { lb[i] = L[lam_off + 5 * b + i]; g[i] = L[Y.G + 5 * b + i]; }
+        if (has_c) {
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * (b + 1) + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = L[lam_off + 5 * (b + 1) + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = 0.0;
         }
-        double d = L[Y.D + e] - s;
-        L[Y.D + e] = d;
-        acc += d * d;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            d[c] -= gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
+                  + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+            acc += d[c] * d[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) acc += g[c] * g[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) L[Y.D + 6 * b + c] = d[c];
     }
-    for (int e = t; e < 5 * nb; e += G) { double g = L[Y.G + e]; acc += g * g; }
     return acc;
 }
 
 HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 
-// S2: Schur complement blocks and right-hand side, one task per (joint, row); two branch-uniform passes:
-//   pass 0: row of S_jj = W_b Gk_b' + W_a Gk_a'  and  r_j = g_j - W_b d_b - W_a d_a
-//   pass 1: rows of S_jp = W_a(j) Gk_b(p)'  and  S_pj = W_b(p) Gk_a(j)'     (p = j-1, the parent link)
+// S2: Schur complement blocks and right-hand side.  Tasks (part, joint j, row) of ONE shape -- two 6-vectors against two
+// 5x6 blocks -- so that every pass is branch-uniform:
+//   part 0: (W_b[j], Gk_b[j]) + (W_a[j], Gk_a[j]) -> row of S_jj ;  r_j = g_j - W_b d_b - W_a d_a
+//   part 1: (W_a[j], Gk_b[p]) -> row of S_jp ,  (W_b[p], Gk_a[j]) -> row of S_pj        (p = j-1, the parent link)
 // Each task loads all its operands into registers, computes, then stores (no store between loads).
 HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, unsigned start_mask) {
-    for (int e = t; e < 5 * nb; e += G) {
-        int j = e / 5, row = e - 5 * j;
-        bool has_p = !((start_mask >> j) & 1u);
-        double wb[6], wa[6], gb[30], ga[30], db[6], da[6];
+    for (int e = t; e < 10 * nb; e += G) {
+        const int part = (e >= 5 * nb) ? 1 : 0;
+        const int e5 = e - part * 5 * nb;
+        const int j = e5 / 5, row = e5 - 5 * j;
+        const bool has_p = !((start_mask >> j) & 1u);
+        if (part && !has_p) continue;
+        const int p = has_p ? j - 1 : j;
+        const int ov1 = (part ? Y.GVA + BLK * j : Y.GVB + BLK * j) + 6 * row;
+        const int ov2 = (part ? Y.GVB + BLK * p : Y.GVA + BLK * j) + 6 * row;
+        const int om1 = part ? Y.GKB + BLK * p : Y.GKB + BLK * j;
+        const int om2 = Y.GKA + BLK * j;
+        const int od1 = Y.D + 6 * j, od2 = Y.D + 6 * p;
+        double v1[6], v2[6], m1[30], m2[30], d1[6], d2[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { wb[i] = L[Y.GVB + BLK * j + 6 * row + i]; db[i] = L[Y.D + 6 * j + i]; }
+        for (int i = 0; i < 6; i++) { v1[i] = L[ov1 + i]; v2[i] = L[ov2 + i]; d1[i] = L[od1 + i]; d2[i] = L[od2 + i]; }
 #pragma unroll
-        for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * j + i];
-        double g0 = L[Y.G + 5 * j + row];
-        if (has_p) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) { wa[i] = L[Y.GVA + BLK * j + 6 * row + i]; da[i] = L[Y.D + 6 * (j - 1) + i]; }
-#pragma unroll
-            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * j + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; i++) { wa[i] = 0.0; da[i] = 0.0; }
-#pragma unroll
-            for (int i = 0; i < 30; i++) ga[i] = 0.0;
-        }
-        double o[5];
-#pragma unroll
-        for (int col = 0; col < 5; col++) o[col] = dot6(wb, gb + 6 * col) + dot6(wa, ga + 6 * col);
-        double rr = g0 - dot6(wb, db) - dot6(wa, da);
-#pragma unroll
-        for (int col = 0; col < 5; col++) L[Y.SJJ + 25 * j + 5 * row + col] = o[col];
-        L[Y.R + 5 * j + row] = rr;
-    }
-    for (int e = t; e < 5 * nb; e += G) {
-        int j = e / 5, row = e - 5 * j;
-        if ((start_mask >> j) & 1u) continue;
-        int p = j - 1;
-        double wa[6], wp[6], gpb[30], gja[30];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { wa[i] = L[Y.GVA + BLK * j + 6 * row + i]; wp[i] = L[Y.GVB + BLK * p + 6 * row + i]; }
-#pragma unroll
-        for (int i = 0; i < 30; i++) { gpb[i] = L[Y.GKB + BLK * p + i]; gja[i] = L[Y.GKA + BLK * j + i]; }
+        for (int i = 0; i < 30; i++) { m1[i] = L[om1 + i]; m2[i] = L[om2 + i]; }
+        const double g0 = L[Y.G + 5 * j + row];
+        const double use2 = (part || has_p) ? 1.0 : 0.0;     // part 0 on a chain root: no parent-side block
         double o1[5], o2[5];
 #pragma unroll
-        for (int col = 0; col < 5; col++) { o1[col] = dot6(wa, gpb + 6 * col); o2[col] = dot6(wp, gja + 6 * col); }
+        for (int col = 0; col < 5; col++) { o1[col] = dot6(v1, m1 + 6 * col); o2[col] = use2 * dot6(v2, m2 + 6 * col); }
+        const double rr = g0 - dot6(v1, d1) - use2 * dot6(v2, d2);
+        if (part == 0) {
 #pragma unroll
-        for (int col = 0; col < 5; col++) { L[Y.SJP + 25 * j + 5 * row + col] = o1[col]; L[Y.SPJ + 25 * j + 5 * row + col] = o2[col]; }
+            for (int col = 0; col < 5; col++) L[Y.SJJ + 25 * j + 5 * row + col] = o1[col] + o2[col];
+            L[Y.R + 5 * j + row] = rr;
+        } else {
+#pragma unroll
+            for (int col = 0; col < 5; col++) { L[Y.SJP + 25 * j + 5 * row + col] = o1[col]; L[Y.SPJ + 25 * j + 5 * row + col] = o2[col]; }
+        }
     }
 }
 
@@ -493,56 +500,7 @@ HD void lu5(const double* L, int off, double* A) {
         }
     }
 }
-// elimination step i: front 0 folds link l = cs+cn-1-i into q = l-1, front 1 folds l = cs+i into q = l+1.
-// Every lane of a front factorises S_ll redundantly (same latency as one lane) and then owns one row of the update of
-// S_qq and r_q.  lu[25] keeps the packed LU; the front's lane 0 stores it afterwards (ph_tri_store).
-HD bool ph_tri_elim(int t, int i, const TriPlan& P, const Lay& Y, double* L, double* lu, int* l_out) {
-    const int front = t >> 3, row = t & 7;
-    if (t >= 16 || row >= 5) return false;
-    if (i >= (front ? P.nB : P.nA)) return false;
-    const int l = front ? P.cs + i : P.cs + P.cn - 1 - i;
-    const int q = front ? l + 1 : l - 1;
-    const int oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * l;   // S_{q,l}
-    const int oLQ = front ? Y.SPJ + 25 * q : Y.SJP + 25 * l;   // S_{l,q}
-    // ---- loads
-    double bq[5], slq[25], rl[5], sqq[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) { bq[c] = L[oQL + 5 * row + c]; rl[c] = L[Y.R + 5 * l + c]; sqq[c] = L[Y.SJJ + 25 * q + 5 * row + c]; }
-#pragma unroll
-    for (int c = 0; c < 25; c++) slq[c] = L[oLQ + c];
-    double rq = L[Y.R + 5 * q + row];
-    lu5(L, Y.SJJ + 25 * l, lu);
-    // ---- row of T = S_ql S_ll^-1:  x U = b (columns ascending), then y L = x (columns descending)
-    double x[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        double s = bq[c];
-#pragma unroll
-        for (int k = 0; k < c; k++) s -= x[k] * lu[k * 5 + c];
-        x[c] = s * lu[c * 5 + c];
-    }
-#pragma unroll
-    for (int c = 4; c >= 0; c--) {
-        double s = x[c];
-#pragma unroll
-        for (int k = c + 1; k < 5; k++) s -= x[k] * lu[k * 5 + c];
-        x[c] = s;
-    }
-#pragma unroll
-    for (int c = 0; c < 5; c++) sqq[c] -= x[0] * slq[c] + x[1] * slq[5 + c] + x[2] * slq[10 + c] + x[3] * slq[15 + c] + x[4] * slq[20 + c];
-    rq -= x[0] * rl[0] + x[1] * rl[1] + x[2] * rl[2] + x[3] * rl[3] + x[4] * rl[4];
-    // ---- stores
-#pragma unroll
-    for (int c = 0; c < 5; c++) L[Y.SJJ + 25 * q + 5 * row + c] = sqq[c];
-    L[Y.R + 5 * q + row] = rq;
-    *l_out = l;
-    return row == 0;
-}
-HD void ph_tri_store(int t, int l, const Lay& Y, double* L, const double* lu) {
-#pragma unroll
-    for (int j = 0; j < 25; j++) L[Y.SJJ + 25 * l + j] = lu[j];
-}
-// forward/back substitution with the packed LU in registers
+// solve (packed LU in A) for one right-hand side, in place
 HD void lu5_solve(const double* A, double* b) {
 #pragma unroll
     for (int i = 1; i < 5; i++) {
@@ -556,6 +514,45 @@ HD void lu5_solve(const double* A, double* b) {
         b[i] *= A[i * 5 + i];
     }
 }
+// elimination step i: front 0 folds link l = cs+cn-1-i into q = l-1, front 1 folds l = cs+i into q = l+1.
+// A front is 6 lanes (t & 7 = 0..5): every lane factorises S_ll redundantly (same latency as one lane) and then solves ONE
+// right-hand side: lanes 0..4 column c of Z = S_ll^-1 S_lq, lane 5 y = S_ll^-1 r_l.  The same lane applies S_ql to its
+// solution and updates column c of S_qq (lanes 0..4) or r_q (lane 5):  S_qq -= S_ql Z,  r_q -= S_ql y.
+// Z and y are kept (zy[5]) and stored afterwards over S_ll / r_l: the back substitution is then dl_l = y - Z dl_q.
+HD bool ph_tri_elim(int t, int i, const TriPlan& P, const Lay& Y, double* L, double* zy, int* l_out) {
+    const int front = t >> 3, col = t & 7;
+    if (t >= 16 || col >= 6) return false;
+    if (i >= (front ? P.nB : P.nA)) return false;
+    const int l = front ? P.cs + i : P.cs + P.cn - 1 - i;
+    const int q = front ? l + 1 : l - 1;
+    const int oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * l;   // S_{q,l}
+    const int oLQ = front ? Y.SPJ + 25 * q : Y.SJP + 25 * l;   // S_{l,q}
+    const bool isy = col == 5;
+    // ---- loads: own right-hand side (a column of S_lq, or r_l), own target (a column of S_qq, or r_q), S_ql, S_ll
+    const int orhs = isy ? Y.R + 5 * l : oLQ + col, srhs = isy ? 1 : 5;
+    const int otgt = isy ? Y.R + 5 * q : Y.SJJ + 25 * q + col, stgt = isy ? 1 : 5;
+    double sql[25], tg[5], lu[25];
+#pragma unroll
+    for (int r = 0; r < 5; r++) { zy[r] = L[orhs + srhs * r]; tg[r] = L[otgt + stgt * r]; }
+#pragma unroll
+    for (int c = 0; c < 25; c++) sql[c] = L[oQL + c];
+    lu5(L, Y.SJJ + 25 * l, lu);
+    lu5_solve(lu, zy);
+#pragma unroll
+    for (int r = 0; r < 5; r++) tg[r] -= sql[5 * r] * zy[0] + sql[5 * r + 1] * zy[1] + sql[5 * r + 2] * zy[2] + sql[5 * r + 3] * zy[3] + sql[5 * r + 4] * zy[4];
+    // ---- stores
+#pragma unroll
+    for (int r = 0; r < 5; r++) L[otgt + stgt * r] = tg[r];
+    *l_out = l;
+    return true;
+}
+// Z (one column per lane) overwrites S_ll, y overwrites r_l
+HD void ph_tri_store(int t, int l, const Lay& Y, double* L, const double* zy) {
+    const int col = t & 7;
+    const int o = (col == 5) ? Y.R + 5 * l : Y.SJJ + 25 * l + col, st = (col == 5) ? 1 : 5;
+#pragma unroll
+    for (int r = 0; r < 5; r++) L[o + st * r] = zy[r];
+}
 // middle link: factorise (both sides have been folded in) and solve; one lane
 HD void ph_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
     if (t != 0) return;
@@ -567,50 +564,55 @@ HD void ph_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
 #pragma unroll
     for (int i = 0; i < 5; i++) L[Y.DL + 5 * P.mid + i] = b[i];
 }
-// back substitution step j: front 0 (lane 0) solves l = mid+1+j from dl_{l-1}, front 1 (lane 8) solves l = mid-1-j from dl_{l+1}
+// back substitution step j: dl_l = y_l - Z_l dl_nbr; front 0 (lanes 0..4) l = mid+1+j, nbr = l-1; front 1 (lanes 8..12) l = mid-1-j, nbr = l+1
 HD void ph_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
-    const int front = t >> 3;
-    if (t != 0 && t != 8) return;
+    const int front = t >> 3, row = t & 7;
+    if (t >= 16 || row >= 5) return;
     if (j >= (front ? P.nB : P.nA)) return;
     const int l = front ? P.mid - 1 - j : P.mid + 1 + j;
     const int nbr = front ? l + 1 : l - 1;
-    const int oLN = front ? Y.SPJ + 25 * nbr : Y.SJP + 25 * l;   // S_{l,nbr}
-    double A[25], S[25], b[5], dn[5];
+    double z[5], dn[5];
 #pragma unroll
-    for (int i = 0; i < 25; i++) { A[i] = L[Y.SJJ + 25 * l + i]; S[i] = L[oLN + i]; }   // A = packed LU stored by ph_tri_store
-#pragma unroll
-    for (int i = 0; i < 5; i++) { b[i] = L[Y.R + 5 * l + i]; dn[i] = L[Y.DL + 5 * nbr + i]; }
-#pragma unroll
-    for (int i = 0; i < 5; i++) b[i] -= S[5 * i] * dn[0] + S[5 * i + 1] * dn[1] + S[5 * i + 2] * dn[2] + S[5 * i + 3] * dn[3] + S[5 * i + 4] * dn[4];
-    lu5_solve(A, b);
-#pragma unroll
-    for (int i = 0; i < 5; i++) L[Y.DL + 5 * l + i] = b[i];
+    for (int c = 0; c < 5; c++) { z[c] = L[Y.SJJ + 25 * l + 5 * row + c]; dn[c] = L[Y.DL + 5 * nbr + c]; }
+    double y = L[Y.R + 5 * l + row];
+    L[Y.DL + 5 * l + row] = y - (z[0] * dn[0] + z[1] * dn[1] + z[2] * dn[2] + z[3] * dn[3] + z[4] * dn[4]);
 }
 
-// S4: ds_b = D_b^-1 (d_b + sum_j Gk_jb' dl_j)
+// S4: ds_b = D_b^-1 (d_b + Gk_b(own joint)' dl_b + Gk_a(child joint)' dl_child), one task per body
 HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
-    for (int e = t; e < 6 * nb; e += G) {
-        int b = e / 6, c = e - 6 * b;
-        bool has_c = !((end_mask >> b) & 1u);
-        double tv[3];
-        int c0 = (c < 3) ? c : 3, n = (c < 3) ? 1 : 3;
-        for (int q = 0; q < n; q++) {
-            int cc = c0 + q;
-            const double* Gb = L + Y.GKB + BLK * b;
-            const double* lb = L + Y.DL + 5 * b;
-            double s = L[Y.D + 6 * b + cc] + Gb[cc] * lb[0] + Gb[6 + cc] * lb[1] + Gb[12 + cc] * lb[2] + Gb[18 + cc] * lb[3] + Gb[24 + cc] * lb[4];
-            if (has_c) {
-                const double* Ga = L + Y.GKA + BLK * (b + 1);
-                const double* lc = L + Y.DL + 5 * (b + 1);
-                s += Ga[cc] * lc[0] + Ga[6 + cc] * lc[1] + Ga[12 + cc] * lc[2] + Ga[18 + cc] * lc[3] + Ga[24 + cc] * lc[4];
-            }
-            tv[q] = s;
+    for (int b = t; b < nb; b += G) {
+        const bool has_c = !((end_mask >> b) & 1u);
+        double d[6], gb[30], lb[5], ga[30], lc[5], Di[9];
+#pragma unroll
+        for (int i = 0; i < 6; i++) d[i] = L[Y.D + 6 * b + i];
+#pragma unroll
+        for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) lb[i] = L[Y.DL + 5 * b + i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Di[i] = L[Y.DINV + 9 * b + i];
+        const double dtm = L[Y.DTM + b];
+        if (has_c) {
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * (b + 1) + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = L[Y.DL + 5 * (b + 1) + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = 0.0;
         }
-        if (c < 3) L[Y.DS + e] = tv[0] * L[Y.DTM + b];
-        else {
-            const double* Di = L + Y.DINV + 9 * b + 3 * (c - 3);
-            L[Y.DS + e] = Di[0] * tv[0] + Di[1] * tv[1] + Di[2] * tv[2];
-        }
+        double tv[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            tv[c] = d[c] + gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
+                         + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+        double o[6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { o[c] = tv[c] * dtm; o[3 + c] = Di[3 * c] * tv[3] + Di[3 * c + 1] * tv[4] + Di[3 * c + 2] * tv[5]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) L[Y.DS + 6 * b + c] = o[c];
     }
 }
 

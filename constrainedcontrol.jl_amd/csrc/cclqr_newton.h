@@ -32,10 +32,31 @@ struct Prof {
 #define NEWTON_MAXIT 100
 #define LINE_MAXIT 10
 
+// 16-lane row rotation through the DPP crossbar (no LDS round trip)
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the G lanes of a group, result in every lane of the group: rotate-and-add inside each 16-lane row (DPP), then
+// combine rows (G = 32: one cross-row permute; G = 64: four scalar lane reads)
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    if (G == 32) v += __shfl_xor(v, 16, 64);
+    if (G == 64) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        v = (r0 + r1) + (r2 + r3);
+    }
     return v;
 }
 
@@ -79,7 +100,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         for (int c = 0; c < nchains; c++) {
             const TriPlan P = tri_plan(M->chain_start[c], M->chain_len[c]);
             for (int i = 0; i < P.steps; i++) {
-                double lu[25];
+                double lu[5];
                 int l = 0;
                 bool act = !done && ph_tri_elim(t, i, P, Y, L, lu, &l);
                 __syncthreads();

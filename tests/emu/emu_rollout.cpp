@@ -28,7 +28,7 @@ static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRe
         for (int c = 0; c < M->nchains; c++) {
             const TriPlan P = tri_plan(M->chain_start[c], M->chain_len[c]);
             for (int i = 0; i < P.steps; i++) {
-                double lu[64][25];
+                double lu[64][5];
                 int l[64];
                 bool act[64];
                 for (int t = 0; t < G; t++) act[t] = ph_tri_elim(t, i, P, Y, L, lu[t], &l[t]);
