@@ -106,3 +106,16 @@ def triple_cartpole():
         Q[i][9, 9] = 1.0
     R = [np.ones((1, 1)) * 0.1]
     return dict(mech=mech, bodies=bodies, joints=joints, Q=Q, R=R, ctrl=[joints[0]], fric=np.array([0.1, 0.1, 0.1, 0.1]), noise_scale=2.0)
+
+
+def sawyer(tables, g=0.0):
+    """examples/lqr_sawyer.jl:8-33 from the numeric content of examples_files/sawyer_arm.urdf (tests/golden/sawyer_arm_tables.json):
+    7 bodies / 7 revolute joints (base link welded to the origin), g = 0, zero pose as setpoint, Q = 1000 I12 per body,
+    R = 1 per joint, all joints controlled, horizon 20 s."""
+    from .mechanism import mechanism_from_urdf_tables
+    mech = mechanism_from_urdf_tables(tables, floating=False, g=g)
+    nb = len(mech.bodies)
+    z = mech.state()
+    return dict(mech=mech, bodies=mech.bodies, joints=mech.eqconstraints, Q=[np.eye(12) * 1000.0 for _ in range(nb)],
+                R=[np.ones((1, 1)) for _ in range(nb)], xd=[z[i, 0:3] for i in range(nb)], qd=[z[i, 3:7] for i in range(nb)],
+                ctrl=list(mech.eqconstraints), horizon=20.0, tend=20.0)

@@ -162,9 +162,13 @@ class MechTables:
 class Mechanism:
     """Mechanism(origin, bodies, eqconstraints; g=-9.81, Δt=0.01)"""
 
-    def __init__(self, origin, bodies, eqconstraints, g=-9.81, dt=None, **kw):
+    def __init__(self, origin, bodies=None, eqconstraints=None, g=-9.81, dt=None, floating=False, **kw):
         if "Δt" in kw:
             dt = kw.pop("Δt")
+        if isinstance(origin, str):      # Mechanism(path, floating=false, g=0.0)   examples/lqr_sawyer.jl:9
+            m = mechanism_from_urdf_tables(parse_urdf(origin), floating=floating, g=g, dt=0.01 if dt is None else dt)
+            self.__dict__.update(m.__dict__)
+            return
         if kw:
             raise TypeError("unexpected keyword(s): %s" % list(kw))
         self.origin = origin
@@ -266,3 +270,85 @@ def setJointPosition(mech, eqc, θ):
         setPosition(j.body1, j.body2, p1=j.p1, p2=j.p2, Δq=dq)
     else:
         setPosition(j.body1, j.body2, p1=j.p1, p2=j.p2, Δx=θ * a, Δq=j.qoffset)
+
+
+# ------------------------------------------------------------------ URDF subset: Mechanism(path, floating=false, g=0.0)
+def parse_urdf(path):
+    """links (mass, COM offset, inertia about the COM in the link frame) and revolute/prismatic joints of a URDF file.
+    Returns a plain dict of numbers (also the format of tests/golden/sawyer_arm_tables.json)."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(path).getroot()
+
+    def vec(s, n=3):
+        v = [float(x) for x in s.split()] if s else [0.0] * n
+        assert len(v) == n
+        return v
+
+    links, joints = {}, []
+    for ln in root.findall("link"):
+        ine = ln.find("inertial")
+        if ine is None:
+            links[ln.get("name")] = dict(mass=0.0, com=[0.0, 0.0, 0.0], rpy=[0.0, 0.0, 0.0], inertia=[0.0] * 6)
+            continue
+        org = ine.find("origin")
+        I = ine.find("inertia")
+        links[ln.get("name")] = dict(mass=float(ine.find("mass").get("value")), com=vec(org.get("xyz") if org is not None else None),
+                                     rpy=vec(org.get("rpy") if org is not None else None),
+                                     inertia=[float(I.get(k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")])
+    for jn in root.findall("joint"):
+        typ = jn.get("type")
+        if typ not in ("revolute", "continuous", "prismatic"):
+            raise ValueError("URDF joint type %r is outside the supported subset (1-DoF joints)" % typ)
+        org = jn.find("origin")
+        ax = jn.find("axis")
+        joints.append(dict(name=jn.get("name"), type="prismatic" if typ == "prismatic" else "revolute", parent=jn.find("parent").get("link"),
+                           child=jn.find("child").get("link"), xyz=vec(org.get("xyz") if org is not None else None),
+                           rpy=vec(org.get("rpy") if org is not None else None), axis=vec(ax.get("xyz")) if ax is not None else [1.0, 0.0, 0.0]))
+    return dict(links=links, joints=joints)
+
+
+def mechanism_from_urdf_tables(tab, floating=False, g=-9.81, dt=0.01):
+    """Build the Mechanism from parse_urdf() output.  floating=false welds the root link to the origin (SURVEY 8a-bis 'URDF').
+    Body frame = link frame orientation with its origin at the COM; joint vertices are shifted to COM frames; inertia tensors
+    are full 3x3.  The bodies are placed at the zero pose."""
+    if floating:
+        raise NotImplementedError("floating base needs a 6-DoF root joint, outside the 1-DoF scope (lqr.jl:1-2)")
+    links, joints = tab["links"], tab["joints"]
+    children = {j["child"] for j in joints}
+    roots = [n for n in links if n not in children]
+    if len(roots) != 1:
+        raise ValueError("URDF must have exactly one root link")
+    origin = Origin(roots[0])
+    bodies, eqcs, body_of = [], [], {roots[0]: origin}
+    com = {roots[0]: np.zeros(3)}    # root link frame = world frame; its inertia is irrelevant when welded
+    pending = list(joints)
+    while pending:
+        progressed = False
+        for j in list(pending):
+            if j["parent"] not in body_of:
+                continue
+            L = links[j["child"]]
+            Ic = np.array([[L["inertia"][0], L["inertia"][1], L["inertia"][2]], [L["inertia"][1], L["inertia"][3], L["inertia"][4]],
+                           [L["inertia"][2], L["inertia"][4], L["inertia"][5]]])
+            if any(abs(a) > 0 for a in L["rpy"]):
+                from_rpy = rpy_quaternion(*L["rpy"])
+                Rm = np.array([vrotate(e, from_rpy) for e in np.eye(3)]).T
+                Ic = Rm @ Ic @ Rm.T
+            b = Body(L["mass"], Ic, name=j["child"])
+            com[j["child"]] = np.asarray(L["com"], dtype=np.float64)
+            qj = rpy_quaternion(*j["rpy"])
+            axis_parent = vrotate(np.asarray(j["axis"], dtype=np.float64), qj)
+            p1 = np.asarray(j["xyz"], dtype=np.float64) - com[j["parent"]]
+            p2 = -com[j["child"]]
+            ctor = Prismatic if j["type"] == "prismatic" else Revolute
+            eqcs.append(EqualityConstraint(ctor(body_of[j["parent"]], b, axis_parent, p1=p1, p2=p2, qoffset=qj), name=j["name"]))
+            bodies.append(b)
+            body_of[j["child"]] = b
+            pending.remove(j)
+            progressed = True
+        if not progressed:
+            raise ValueError("URDF joints do not form a tree")
+    mech = Mechanism(origin, bodies, eqcs, g=g, dt=dt)
+    for e in mech.eqconstraints:      # zero pose, root to leaf
+        setJointPosition(mech, e, 0.0)
+    return mech

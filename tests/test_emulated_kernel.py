@@ -107,3 +107,68 @@ def test_emulated_linearize_matches_oracle(cclqr, orc, emu):
     assert rc == 0
     for got, want in zip((A, Bu, Bl, G), orc.linearize(t, z, cj, Fd)):
         assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max())
+
+
+def test_emulated_sawyer_rollout_and_linearize(cclqr, orc, emu):
+    """config 4 mechanism: 7 revolute joints with rpy offsets, full inertia tensors, 7 controlled joints (mu = 7)"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab, g=-9.81)
+    mech = ex["mech"]
+    t = mech.tables()
+    rng = np.random.default_rng(3)
+    zd = mech.state()
+    K = rng.normal(size=(49, 7, 84)) * 0.004
+    z0 = []
+    for n in range(2):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.3, 0.3))
+        z0.append(mech.state())
+    z0 = np.stack(z0)
+    c = orc.ctrl_desc(7, list(range(7)), K=K, N=50, zd=zd, Fd=0.02 * rng.normal(size=(1, 7)))
+    zT_o, traj_o, st_o = orc.rollout(t, c, z0, 40, record=True)
+    zT, traj, st = emu_rollout(emu, orc, t, c, z0, 40)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10
+    cj = np.arange(7, dtype=np.int32)
+    Fd = rng.normal(size=7)
+    m = orc.mech_desc(t)
+    A, Bu, Bl, G = np.zeros((84, 84)), np.zeros((84, 7)), np.zeros((84, 35)), np.zeros((35, 84))
+    rc = emu.emu_linearize(C.byref(m.desc), np.ascontiguousarray(z0[1]).ctypes.data_as(dp), C.c_int(7), cj.ctypes.data_as(C.POINTER(C.c_int32)),
+                           Fd.ctypes.data_as(dp), A.ctypes.data_as(dp), Bu.ctypes.data_as(dp), Bl.ctypes.data_as(dp), G.ctypes.data_as(dp))
+    assert rc == 0
+    for got, want in zip((A, Bu, Bl, G), orc.linearize(t, z0[1], cj, Fd)):
+        assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max())
+
+
+def test_emulated_two_chains(cclqr, orc, emu):
+    """forest of chains: two independent cartpoles hanging off the same origin, bodies interleaved in the caller's numbering"""
+    e1 = cclqr.examples.cartpole_n(2)
+    t1 = e1["mech"].tables()
+    nb = 6
+    # caller's numbering: bodies 0,2,4 = chain A (cart, pole, pole), 1,3,5 = chain B
+    ia, ib = [0, 2, 4], [1, 3, 5]
+    mass, inertia = np.zeros(nb), np.zeros((nb, 9))
+    parent, child, typ = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+    p1, p2, axis, qoff = np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 4))
+    for ids in (ia, ib):
+        for k in range(3):
+            mass[ids[k]], inertia[ids[k]] = t1.mass[k], t1.inertia[k]
+            j = ids[k]                      # joint j hangs body ids[k]
+            parent[j] = -1 if t1.parent[k] < 0 else ids[t1.parent[k]]
+            child[j], typ[j], p1[j], p2[j], axis[j], qoff[j] = ids[k], t1.type[k], t1.p1[k], t1.p2[k], t1.axis[k], t1.qoff[k]
+    t2 = cclqr.MechTables(nb, nb, t1.dt, t1.g, mass, inertia, parent, child, typ, p1, p2, axis, qoff)
+    rng = np.random.default_rng(9)
+    za = cclqr.examples.cartpole_states(2, [0.2], [[0.1, -0.2]])[0]
+    zb = cclqr.examples.cartpole_states(2, [-0.3], [[-0.15, 0.05]])[0]
+    z0 = np.zeros((1, nb, 13))
+    z0[0, ia], z0[0, ib] = za, zb
+    zd = np.zeros((nb, 13))
+    zd[:, 3] = 1
+    K = rng.normal(size=(30, 2, 12 * nb)) * 0.2
+    c = orc.ctrl_desc(nb, [0, 1], K=K, N=31, zd=zd)
+    _, traj_o, st_o = orc.rollout(t2, c, z0, 30, record=True)
+    _, traj, st = emu_rollout(emu, orc, t2, c, z0, 30)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10

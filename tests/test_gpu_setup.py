@@ -163,3 +163,34 @@ def test_error_codes(cclqr):
     with pytest.raises(capi.CclqrError) as e:
         capi.CtrlHandle(mech, [7])
     assert e.value.code == capi.EINVAL
+
+
+def test_sawyer_config4_pipeline(cclqr, orc):
+    """examples/lqr_sawyer.jl through the mirror: URDF numbers -> Mechanism -> LQR (mx = 84, mu = 7, ml = 35) -> batched simulate!"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    ids = [cclqr.getid(b) for b in mech.bodies]
+    eids = [cclqr.getid(e) for e in mech.eqconstraints]
+    lqr = cclqr.LQR(mech, ids, eids, ex["Q"], ex["R"], 2.0, xd=ex["xd"], qd=ex["qd"])       # 200-step horizon keeps the oracle fast
+    assert lqr.K.shape == (199, 7, 84)
+    Ao, Buo, Blo, Go = orc.linearize(t, lqr.zd[0], list(range(7)), np.zeros(7))
+    for a, b in zip((lqr.A, lqr.Bu, lqr.Bλ, lqr.G), (Ao, Buo, Blo, Go)):
+        assert _rel(a, b) < 1e-10
+    Ko, kbo = orc.riccati(Ao, Buo, Blo, Go, lqr.Q, lqr.R, 200)
+    assert lqr.kbreak == kbo and _rel(lqr.K, Ko) < 1e-7
+    rng = np.random.default_rng(1)
+    z0 = []
+    for n in range(9):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.05, 0.05))      # SURVEY 8d: q_j ~ U(-0.05, 0.05) about the zero pose
+        z0.append(mech.state())
+    z0 = np.stack(z0)
+    st = cclqr.simulate(mech, 1.5, lqr, z0=z0)
+    oc = orc.ctrl_desc(7, list(range(7)), K=lqr.K, N=lqr.N, zd=lqr.zd)
+    _, traj, sto = orc.rollout(t, oc, z0, 150, record=True)
+    assert (st.status > 0).all() and (sto > 0).all()
+    assert np.abs(st.z - traj).max() < 1e-9

@@ -116,3 +116,46 @@ def test_gloo_world2_shard_and_gather(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GLOO_OK" in r.stdout
+
+
+_URDF = """<?xml version="1.0"?>
+<robot name="two_link">
+  <link name="base"><inertial><origin xyz="0 0 0.1" rpy="0 0 0"/><mass value="3"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial></link>
+  <link name="l0"><inertial><origin xyz="0.1 0.02 0.3" rpy="0 0 0"/><mass value="2.5"/><inertia ixx="0.05" ixy="0.001" ixz="-0.002" iyy="0.06" iyz="0.003" izz="0.02"/></inertial></link>
+  <link name="l1"><inertial><origin xyz="0 -0.05 0.2" rpy="0 0 0"/><mass value="1.5"/><inertia ixx="0.03" ixy="0" ixz="0.001" iyy="0.03" iyz="0" izz="0.01"/></inertial></link>
+  <joint name="j0" type="revolute"><origin xyz="0 0 0.08" rpy="0 0 0"/><parent link="base"/><child link="l0"/><axis xyz="0 0 1"/></joint>
+  <joint name="j1" type="revolute"><origin xyz="0.081 0.05 0.237" rpy="-1.5707963 1.5707963 0"/><parent link="l0"/><child link="l1"/><axis xyz="0 0 1"/></joint>
+</robot>
+"""
+
+
+def test_urdf_subset_reader(cclqr, orc, tmp_path):
+    """Mechanism(path, floating=false, g=0.0) (examples/lqr_sawyer.jl:9): COM-frame bodies, full inertia, rpy joint frames"""
+    f = tmp_path / "two_link.urdf"
+    f.write_text(_URDF)
+    mech = cclqr.Mechanism(str(f), floating=False, g=0.0)
+    assert len(mech.bodies) == 2 and [e.name for e in mech.eqconstraints] == ["j0", "j1"]
+    t = mech.tables()
+    assert list(t.parent) == [-1, 0] and np.allclose(t.mass, [2.5, 1.5])
+    assert np.allclose(t.inertia[0].reshape(3, 3), [[0.05, 0.001, -0.002], [0.001, 0.06, 0.003], [-0.002, 0.003, 0.02]])
+    assert np.allclose(t.p1[0], [0, 0, 0.08]) and np.allclose(t.p2[0], [-0.1, -0.02, -0.3])
+    assert np.allclose(t.p1[1], np.array([0.081, 0.05, 0.237]) - [0.1, 0.02, 0.3])
+    z = mech.state()
+    assert np.abs(orc.constraints(t, z)).max() < 1e-14          # zero pose satisfies every joint
+    assert np.allclose(z[0, 0:3], [0.1, 0.02, 0.38])
+    # the joint axis really is the free direction: rotate joint 1 and the constraints still hold
+    cclqr.setJointPosition(mech, mech.geteqconstraint("j1"), 0.7)
+    assert np.abs(orc.constraints(t, mech.state())).max() < 1e-14
+    with pytest.raises(NotImplementedError):
+        cclqr.Mechanism(str(f), floating=True)
+
+
+def test_sawyer_fixture_matches_reference_urdf_when_present(cclqr):
+    import json
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "sawyer_arm_tables.json")))
+    assert len(tab["joints"]) == 7 and len(tab["links"]) == 8
+    ref = "/root/reference/examples/examples_files/sawyer_arm.urdf"
+    if os.path.exists(ref):
+        assert cclqr.parse_urdf(ref) == tab
+    ex = cclqr.examples.sawyer(tab)
+    assert len(ex["mech"].bodies) == 7 and ex["mech"].tables().ml == 35      # SURVEY 2.1: Nb = 7, mλ = 35
