@@ -100,6 +100,7 @@ extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32
 extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
                                  double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
                                  void* stream) {
+    if (m && c && n_inst == 0) return CCLQR_OK;   // empty batch
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
@@ -113,6 +114,7 @@ extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64
 
 extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
                              const double* noise, double* traj, double* zT, int32_t* status) {
+    if (m && c && n_inst == 0) return CCLQR_OK;   // empty batch
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     const size_t nz = (size_t)13 * m->nb;
     double *dz0 = nullptr, *dzT = nullptr, *dtraj = nullptr, *dnoise = nullptr;

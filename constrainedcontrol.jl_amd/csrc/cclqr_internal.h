@@ -48,6 +48,7 @@ struct RicArgs {
     int* kbreak;             // [nprob]
     int* status;             // [nprob]
     double* work;            // [nprob][ric_work_doubles]
+    int lds_cols;            // right-hand-side columns staged in LDS per batch (set by launch_riccati)
 };
 size_t ric_work_doubles(int mx, int mu, int ml);
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream);

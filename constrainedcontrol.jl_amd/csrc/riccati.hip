@@ -8,51 +8,71 @@
 // Statement-by-statement correspondence with lqr.jl is marked with the line numbers.
 #include "cclqr_internal.h"
 #include <math.h>
+#include <type_traits>
 
 namespace cclqr {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) double lds_double;   // explicit LDS address space: ds_read/ds_write instead of flat_*
 #define RIC_THREADS 512
 #define RIC_WAVES (RIC_THREADS / 64)
 
 // C (M x N, ldc) = beta * C + alpha * op(A) (M x K) * B (K x N);  op(A) = A' when TA (A stored K x M).  Whole workgroup.
-// fragment maps of v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
-// C/D: col = lane&15, row = (lane>>4) + 4*reg  (cdna_hip_programming.md §3).
+// Each wavefront owns a 32x32 block of C = 2x2 tiles of v_mfma_f64_16x16x4_f64, so every operand fragment feeds two MFMAs,
+// and k is unrolled by two so that eight loads are in flight before the first MFMA of an iteration.
+// fragment maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], C/D: col = lane&15, row = (lane>>4) + 4*reg
+// (cdna_hip_programming.md §3).
 template <bool TA>
 __device__ void wg_gemm(int M, int N, int K, double alpha, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                         double beta, double* __restrict__ C, int ldc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
-    for (int tile = wave; tile < tm * tn; tile += RIC_WAVES) {
-        const int i0 = (tile / tn) << 4, j0 = (tile % tn) << 4;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        const bool iok = (i0 + li) < M, jok = (j0 + li) < N;
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + lk;
-            double a = 0.0, b = 0.0;
-            if (k < K) {
-                if (iok) a = TA ? A[(size_t)k * lda + i0 + li] : A[(size_t)(i0 + li) * lda + k];
-                if (jok) b = B[(size_t)k * ldb + j0 + li];
-            }
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-        if (jok) {
+    const int bm = (M + 31) >> 5, bn = (N + 31) >> 5;
+    for (int blk = wave; blk < bm * bn; blk += RIC_WAVES) {
+        const int i0 = (blk / bn) << 5, j0 = (blk % bn) << 5;
+        v4d acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+        const bool iok[2] = {(i0 + li) < M, (i0 + 16 + li) < M}, jok[2] = {(j0 + li) < N, (j0 + 16 + li) < N};
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            double a[2][2], b[2][2];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = i0 + lk + 4 * r;
-                if (row < M) {
-                    double* c = C + (size_t)row * ldc + j0 + li;
-                    *c = (beta == 0.0 ? 0.0 : beta * *c) + alpha * acc[r];
+            for (int u = 0; u < 2; u++) {
+                const int k = k0 + 4 * u + lk;
+                const bool kok = k < K;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = i0 + 16 * h + li, j = j0 + 16 * h + li;
+                    a[u][h] = (kok && iok[h]) ? (TA ? A[(size_t)k * lda + i] : A[(size_t)i * lda + k]) : 0.0;
+                    b[u][h] = (kok && jok[h]) ? B[(size_t)k * ldb + j] : 0.0;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+                    for (int hj = 0; hj < 2; hj++) acc[hi][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][hi], b[u][hj], acc[hi][hj], 0, 0, 0);
         }
+#pragma unroll
+        for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+            for (int hj = 0; hj < 2; hj++) {
+                if (!jok[hj]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = i0 + 16 * hi + lk + 4 * r;
+                    if (row < M) {
+                        double* c = C + (size_t)row * ldc + j0 + 16 * hj + li;
+                        *c = (beta == 0.0 ? 0.0 : beta * *c) + alpha * acc[hi][hj][r];
+                    }
+                }
+            }
     }
     __syncthreads();
 }
 
 // in-place LU with partial pivoting of the n x n matrix A (row major, lda); piv[c] = pivot row of column c.  *sing set if a pivot is 0.
-__device__ void wg_lu(int n, double* A, int lda, int* piv, int* sing, double* red_v, int* red_i) {
+template <typename MP>
+__device__ void wg_lu(int n, MP A, int lda, int* piv, int* sing, double* red_v, int* red_i) {
     const int tid = threadIdx.x;
     for (int c = 0; c < n; c++) {
         // pivot search by the first wavefront
@@ -73,17 +93,68 @@ __device__ void wg_lu(int n, double* A, int lda, int* piv, int* sing, double* re
         const double inv = 1.0 / A[(size_t)c * lda + c];
         for (int r = c + 1 + tid; r < n; r += RIC_THREADS) A[(size_t)r * lda + c] *= inv;
         __syncthreads();
-        const int w = n - c - 1;
-        for (int e = tid; e < w * w; e += RIC_THREADS) {
-            int r = c + 1 + e / w, j = c + 1 + e % w;
-            A[(size_t)r * lda + j] -= A[(size_t)r * lda + c] * A[(size_t)c * lda + j];
+        // rank-1 update of the trailing block on a 16 x 32 thread grid (no per-element index division)
+        {
+            const int tr = tid >> 5, tc = tid & 31;
+            for (int r = c + 1 + tr; r < n; r += RIC_THREADS / 32) {
+                const double l = A[(size_t)r * lda + c];
+                MP Ar = A + (size_t)r * lda;
+                MP Ac = A + (size_t)c * lda;
+                for (int j = c + 1 + tc; j < n; j += 32) Ar[j] -= l * Ac[j];
+            }
         }
         __syncthreads();
     }
     (void)red_i;
 }
-// solve (LU) X = B for nrhs columns, B (n x nrhs, ldb) in place; one column per thread
-__device__ void wg_lu_solve(int n, const double* LU, int lda, const int* piv, double* B, int ldb, int nrhs) {
+// solve (LU) X = B for nrhs columns, B (n x nrhs, ldb) in place; one column per thread.
+// With Xs != nullptr the columns are processed in batches of CB staged in LDS (Xs[i*CB + thread]: conflict-free), so the
+// n^2 multiply-adds per column read LDS instead of re-reading B from global memory.
+template <typename MP>
+__device__ void wg_lu_solve(int n, MP LU, int lda, const int* piv, double* B, int ldb, int nrhs, MP Xs, int CB) {
+    if (CB > 0) {
+        const int tid = threadIdx.x;
+        for (int c0 = 0; c0 < nrhs; c0 += CB) {
+            const int j = c0 + tid;
+            if (tid < CB && j < nrhs) {
+                MP x = Xs + tid;
+                for (int i = 0; i < n; i++) x[(size_t)i * CB] = B[(size_t)i * ldb + j];
+                for (int c = 0; c < n; c++) { int p = piv[c]; if (p != c) { double t = x[(size_t)c * CB]; x[(size_t)c * CB] = x[(size_t)p * CB]; x[(size_t)p * CB] = t; } }
+                // dot products unrolled by 8 with 4 accumulators: 16 LDS loads are in flight before the first multiply-add
+                for (int i = 1; i < n; i++) {
+                    MP Li = LU + (size_t)i * lda;
+                    double s[4] = {x[i * CB], 0.0, 0.0, 0.0};
+                    int r = 0;
+                    for (; r + 8 <= i; r += 8) {
+                        double lv[8], xv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { lv[u] = Li[r + u]; xv[u] = x[(r + u) * CB]; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) s[u & 3] -= lv[u] * xv[u];
+                    }
+                    for (; r < i; r++) s[0] -= Li[r] * x[r * CB];
+                    x[i * CB] = (s[0] + s[1]) + (s[2] + s[3]);
+                }
+                for (int i = n - 1; i >= 0; i--) {
+                    MP Li = LU + (size_t)i * lda;
+                    double s[4] = {x[i * CB], 0.0, 0.0, 0.0};
+                    int r = i + 1;
+                    for (; r + 8 <= n; r += 8) {
+                        double lv[8], xv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { lv[u] = Li[r + u]; xv[u] = x[(r + u) * CB]; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) s[u & 3] -= lv[u] * xv[u];
+                    }
+                    for (; r < n; r++) s[0] -= Li[r] * x[r * CB];
+                    x[i * CB] = ((s[0] + s[1]) + (s[2] + s[3])) / Li[i];
+                }
+                for (int i = 0; i < n; i++) B[(size_t)i * ldb + j] = x[(size_t)i * CB];
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < nrhs; j += RIC_THREADS) {
         for (int c = 0; c < n; c++) { int p = piv[c]; if (p != c) { double t = B[(size_t)c * ldb + j]; B[(size_t)c * ldb + j] = B[(size_t)p * ldb + j]; B[(size_t)p * ldb + j] = t; } }
         for (int i = 1; i < n; i++) { double s = B[(size_t)i * ldb + j]; for (int r = 0; r < i; r++) s -= LU[(size_t)i * lda + r] * B[(size_t)r * ldb + j]; B[(size_t)i * ldb + j] = s; }
@@ -107,14 +178,30 @@ __host__ __device__ inline size_t ric_carve(int mx, int mu, int ml, double* base
     double *GBl = take((size_t)ml * ml), *GBlT = take((size_t)ml * ml), *GBu = take((size_t)ml * mu), *Yt = take((size_t)ml * mx),
            *BlT = take((size_t)ml * mx), *BuT = take((size_t)mu * mx), *D = take((size_t)mx * mu), *GA = take((size_t)ml * mx),
            *DtP = take((size_t)mu * mx), *Mm = take(m * m), *bb = take(m * mx), *Abar = take((size_t)mx * mx), *T = take((size_t)mx * mx),
-           *P = take((size_t)mx * mx), *Pn = take((size_t)mx * mx), *KRK = take((size_t)mu * mx), *piv = take(m + ml + 2);
+           *P = take((size_t)mx * mx), *Pn = take((size_t)mx * mx), *KRK = take((size_t)mu * mx), *piv = take(2 * (m + ml) + 2 * m + 16);
     if (w) { w->GBl = GBl; w->GBlT = GBlT; w->GBu = GBu; w->Yt = Yt; w->BlT = BlT; w->BuT = BuT; w->D = D; w->GA = GA; w->DtP = DtP; w->Mm = Mm;
              w->bb = bb; w->Abar = Abar; w->T = T; w->P = P; w->Pn = Pn; w->KRK = KRK; w->piv = (int*)piv; }
     return o;
 }
 size_t ric_work_doubles(int mx, int mu, int ml) { return ric_carve(mx, mu, ml, nullptr, nullptr); }
 
+#ifdef CCLQR_PROFILE
+enum { RP_PRE, RP_DTP, RP_MB, RP_LU, RP_SOLVE, RP_ABAR, RP_PP, RP_NORM, RP_STEPS, RP_N };
+static __device__ unsigned long long g_rprof[RP_N];
+#define RSTAMP(c) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t1_ = __builtin_readcyclecounter(); g_rprof[c] += t1_ - rt0; rt0 = t1_; } } while (0)
+#else
+#define RSTAMP(c)
+#endif
+
+#define RIC_LDS_M 96   // M (m x m) is kept in LDS for the pivoted LU when m <= 96 (72 KB)
+
+template <bool LDSM>
 __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
+    extern __shared__ double lds_M[];
+    typedef typename std::conditional<LDSM, lds_double*, double*>::type MP;
+#ifdef CCLQR_PROFILE
+    unsigned long long rt0 = __builtin_readcyclecounter();
+#endif
     __shared__ double red_v[RIC_WAVES];
     __shared__ int red_i[4];
     __shared__ int sing;
@@ -122,6 +209,10 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
     const int mx = a.mx, mu = a.mu, ml = a.ml, m = mu + ml, N = a.N;
     RicWork w;
     ric_carve(mx, mu, ml, a.work + (size_t)prob * ric_carve(mx, mu, ml, nullptr, nullptr), &w);
+    MP Mm = LDSM ? (MP)lds_M : (MP)w.Mm;
+    MP Xs = LDSM ? (MP)lds_M + (size_t)m * m : (MP) nullptr;
+    const int CB = LDSM ? a.lds_cols : 0;
+    double* Msmall = w.Mm;   // global scratch for the mu x m upper block written by the MFMA products (then copied into M)
     const size_t nlin = a.time_varying ? (size_t)(N - 1) : 1;
     const double* Ab = a.A + (size_t)prob * nlin * mx * mx;
     const double* Bub = a.Bu + (size_t)prob * nlin * mx * mu;
@@ -150,43 +241,54 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
                 for (int e = tid; e < ml * ml; e += RIC_THREADS) { int r = e / ml, c = e % ml; w.GBlT[e] = w.GBl[(size_t)c * ml + r]; }
                 for (int e = tid; e < ml * mx; e += RIC_THREADS) w.Yt[e] = w.BlT[e];
                 __syncthreads();
-                wg_lu(ml, w.GBlT, ml, w.piv + m + 1, &sing, red_v, red_i);          // (G Bλ)' Y' = Bλ'
-                wg_lu_solve(ml, w.GBlT, ml, w.piv + m + 1, w.Yt, mx, mx);
+                wg_lu<double*>(ml, w.GBlT, ml, w.piv + m + 1, &sing, red_v, red_i);          // (G Bλ)' Y' = Bλ'
+                wg_lu_solve<double*>(ml, w.GBlT, ml, w.piv + m + 1, w.Yt, mx, mx, nullptr, 0);
                 wg_gemm<true>(mx, mu, ml, -1.0, w.Yt, mx, w.GBu, mu, 1.0, w.D, mu);
             }
         }
         if (sing) { status = CCLQR_ESINGULAR_; break; }
+        RSTAMP(RP_PRE);
         // M = [R + D'PBu  D'PBλ; G*Bu  G*Bλ] ; b = [D'*Pk; G]*A                                                    lqr.jl:152-158
         wg_gemm<true>(mu, mx, mx, 1.0, w.D, mu, P, mx, 0.0, w.DtP, mx);
-        for (int e = tid; e < mu * mu; e += RIC_THREADS) w.Mm[(size_t)(e / mu) * m + e % mu] = a.R[e];
-        for (int e = tid; e < ml * mu; e += RIC_THREADS) w.Mm[(size_t)(mu + e / mu) * m + e % mu] = w.GBu[e];
-        for (int e = tid; e < ml * ml; e += RIC_THREADS) w.Mm[(size_t)(mu + e / ml) * m + mu + e % ml] = w.GBl[e];
+        RSTAMP(RP_DTP);
+        // upper block [R + D'P Bu, D'P Bλ] through the MFMA products into global scratch, then M is assembled where the LU runs
+        for (int e = tid; e < mu * mu; e += RIC_THREADS) Msmall[(size_t)(e / mu) * m + e % mu] = a.R[e];
         for (int e = tid; e < ml * mx; e += RIC_THREADS) w.bb[(size_t)mu * mx + e] = w.GA[e];
         __syncthreads();
-        wg_gemm<false>(mu, mu, mx, 1.0, w.DtP, mx, Bu, mu, 1.0, w.Mm, m);
-        if (ml > 0) wg_gemm<false>(mu, ml, mx, 1.0, w.DtP, mx, Bl, ml, 0.0, w.Mm + mu, m);
+        wg_gemm<false>(mu, mu, mx, 1.0, w.DtP, mx, Bu, mu, 1.0, Msmall, m);
+        if (ml > 0) wg_gemm<false>(mu, ml, mx, 1.0, w.DtP, mx, Bl, ml, 0.0, Msmall + mu, m);
         wg_gemm<false>(mu, mx, mx, 1.0, w.DtP, mx, A, mx, 0.0, w.bb, mx);
+        if (LDSM) for (int e = tid; e < mu * m; e += RIC_THREADS) Mm[e] = Msmall[e];
+        for (int e = tid; e < ml * mu; e += RIC_THREADS) Mm[(size_t)(mu + e / mu) * m + e % mu] = w.GBu[e];
+        for (int e = tid; e < ml * ml; e += RIC_THREADS) Mm[(size_t)(mu + e / ml) * m + mu + e % ml] = w.GBl[e];
+        __syncthreads();
+        RSTAMP(RP_MB);
         // Kk = M\b                                                                                                  lqr.jl:160
-        wg_lu(m, w.Mm, m, w.piv, &sing, red_v, red_i);
+        wg_lu<MP>(m, Mm, m, w.piv, &sing, red_v, red_i);
         if (sing) { status = CCLQR_ESINGULAR_; break; }
-        wg_lu_solve(m, w.Mm, m, w.piv, w.bb, mx, mx);
-        for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k - 1) * mu * mx + e] = w.bb[e];   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
+        RSTAMP(RP_LU);
+        wg_lu_solve<MP>(m, Mm, m, w.piv, w.bb, mx, mx, Xs, CB);
+        double* Kk = w.bb;
+        RSTAMP(RP_SOLVE);
+        for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k - 1) * mu * mx + e] = Kk[e];   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
         // Abar = A-Bu*Kuk-Bλ*Kλk                                                                                    lqr.jl:169
         for (int e = tid; e < mx * mx; e += RIC_THREADS) w.Abar[e] = A[e];
         // KRK = R Kuk (mu x mx), tiny
         for (int e = tid; e < mu * mx; e += RIC_THREADS) {
             int i = e / mx, c = e % mx; double s = 0.0;
-            for (int q = 0; q < mu; q++) s += a.R[i * mu + q] * w.bb[(size_t)q * mx + c];
+            for (int q = 0; q < mu; q++) s += a.R[i * mu + q] * Kk[(size_t)q * mx + c];
             w.KRK[e] = s;
         }
         for (int e = tid; e < mx * mx; e += RIC_THREADS) Pn[e] = a.Q[e];
         __syncthreads();
-        wg_gemm<true>(mx, mx, mu, -1.0, w.BuT, mx, w.bb, mx, 1.0, w.Abar, mx);
-        if (ml > 0) wg_gemm<true>(mx, mx, ml, -1.0, w.BlT, mx, w.bb + (size_t)mu * mx, mx, 1.0, w.Abar, mx);
+        wg_gemm<true>(mx, mx, mu, -1.0, w.BuT, mx, Kk, mx, 1.0, w.Abar, mx);
+        if (ml > 0) wg_gemm<true>(mx, mx, ml, -1.0, w.BlT, mx, Kk + (size_t)mu * mx, mx, 1.0, w.Abar, mx);
+        RSTAMP(RP_ABAR);
         // Pkp1 = Q + Kuk'*R*Kuk + Abar'*Pk*Abar                                                                     lqr.jl:170
-        wg_gemm<true>(mx, mx, mu, 1.0, w.bb, mx, w.KRK, mx, 1.0, Pn, mx);
+        wg_gemm<true>(mx, mx, mu, 1.0, Kk, mx, w.KRK, mx, 1.0, Pn, mx);
         wg_gemm<true>(mx, mx, mx, 1.0, P, mx, w.Abar, mx, 0.0, w.T, mx);    // Pk Abar (Pk symmetric)
         wg_gemm<true>(mx, mx, mx, 1.0, w.Abar, mx, w.T, mx, 1.0, Pn, mx);
+        RSTAMP(RP_PP);
         // if norm(Pk-Pkp1) < 1e-5  break                                                                            lqr.jl:172-174
         double acc = 0.0;
         for (int e = tid; e < mx * mx; e += RIC_THREADS) { double d = P[e] - Pn[e]; acc += d * d; }
@@ -196,6 +298,10 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
         double tot = 0.0;
         for (int q = 0; q < RIC_WAVES; q++) tot += red_v[q];
         __syncthreads();
+        RSTAMP(RP_NORM);
+#ifdef CCLQR_PROFILE
+        if (tid == 0 && blockIdx.x == 0) g_rprof[RP_STEPS] += 1;
+#endif
         if (sqrt(tot) < a.tol) break;
         double* tmp = P; P = Pn; Pn = tmp;                                                               // Pk = Pkp1  lqr.jl:176
     }
@@ -213,8 +319,34 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
 
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
-    hipLaunchKernelGGL(riccati_kernel, dim3(a.nprob), dim3(RIC_THREADS), 0, stream, a);
+    const int m = a.mu + a.ml;
+    RicArgs a2 = a;
+    size_t lds = 0;
+    a2.lds_cols = 0;
+    if (m <= RIC_LDS_M && m > 0) {
+        const size_t budget = 150 * 1024;                 // of the 160 KB per CU; the rest is static LDS
+        size_t cols = (budget - (size_t)m * m * sizeof(double)) / ((size_t)m * sizeof(double));
+        if (cols > RIC_THREADS) cols = RIC_THREADS;
+        if (cols > (size_t)a.mx) cols = a.mx;
+        a2.lds_cols = (int)cols;
+        lds = ((size_t)m * m + (size_t)m * cols) * sizeof(double);   // M for the pivoted LU + one batch of right-hand-side columns
+    }
+    if (lds > 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)riccati_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(riccati_kernel<true>, dim3(a.nprob), dim3(RIC_THREADS), lds, stream, a2);
+    } else {
+        hipLaunchKernelGGL(riccati_kernel<false>, dim3(a.nprob), dim3(RIC_THREADS), 0, stream, a2);
+    }
     return hipGetLastError();
 }
+
+#ifdef CCLQR_PROFILE
+extern "C" int cclqr_ric_prof_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rprof), sizeof(unsigned long long) * RP_N);
+    if (e == hipSuccess && reset) { unsigned long long z[RP_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_rprof), z, sizeof(z)); }
+    return e == hipSuccess ? RP_N : -1;
+}
+#endif
 
 }  // namespace cclqr

@@ -1,0 +1,27 @@
+"""diagnostic (not a test): section shares of the Riccati kernel from the -DCCLQR_PROFILE build"""
+import sys, os, time, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.load_package(); capi = pkg._capi
+capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libcclqr_prof.so")
+name = sys.argv[1] if len(sys.argv) > 1 else "chain16_hanging_cfg3"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+nprob = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+gd = np.load(os.path.join(g.ROOT, "tests", "golden", name + ".npz"))
+A, Bu, Bl, G = gd["A"], gd["Bu"], gd["Bl"], gd["G"]
+mx, mu, ml = A.shape[0], Bu.shape[1], Bl.shape[1]
+Q = np.eye(mx) * 0.01; R = np.eye(mu) * 0.01
+rep = lambda M: np.tile(M[None], (nprob, 1, 1))
+buf = (C.c_ulonglong * 16)()
+capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, 3)   # warm
+capi.lib().cclqr_ric_prof_read(buf, 1)
+t0 = time.time(); K, kb = capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, N); dt = time.time() - t0
+capi.lib().cclqr_ric_prof_read(buf, 1)
+v = np.array(list(buf), dtype=np.float64); steps = max(v[8], 1); tot = v[:8].sum()
+m = mu + ml
+F = 4 * mx**3 + 4 * mx**2 * m + 2 * mx * (ml**2 + m**2) + 2 / 3 * m**3 + 2 / 3 * ml**3
+kbs = np.atleast_1d(kb); done = (N - np.maximum(kbs, 1) + 1).sum()
+print("%s mx=%d mu=%d ml=%d nprob=%d N=%d: %.3fs total, %.3f ms/backward-step/problem-wave, kbreak %s, %.1f GFLOP/s (F_ric=%.3g)" % (name, mx, mu, ml, nprob, N, dt, 1e3 * dt / max(1, N - kbs.min()), kbs[:3], F * done / dt / 1e9, F))
+for i, n in enumerate(["precompute", "D'P", "M,b assembly", "LU(M)", "solve M\\b", "Abar", "P Abar, Abar'(P Abar)", "norm"]):
+    print("  %-24s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / steps))

@@ -1,0 +1,93 @@
+"""GPU tests at BASELINE.json's full batch sizes through size-independent properties (the oracle would need minutes-hours
+there): run-to-run determinism, batch-order invariance, shard-by-shard == whole batch, constraint satisfaction to round-off,
+unit quaternions, and the controller doing its job on every instance.  Plus ragged / empty batches."""
+import numpy as np
+import pytest
+
+from conftest import hanging_setpoint
+
+pytestmark = pytest.mark.gpu
+
+
+def _constraint_violation(cclqr, orc, t, z, sample):
+    return max(float(np.abs(orc.constraints(t, z[i])).max()) for i in sample)
+
+
+def test_cfg2_cartpole_4096_full_horizon(cclqr, orc):
+    """configs[1]: lqr_cartpole.jl, 4096 random-init instances, 1000 steps"""
+    ex = cclqr.examples.cartpole_n(1)
+    mech = ex["mech"]
+    lqr = cclqr.LQR(mech, [1, 2], [3], ex["Q"], ex["R"], 10.0, xd=ex["xd"])
+    rng = np.random.default_rng(0xC0FFEE)
+    n = 4096
+    z0 = cclqr.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, n), rng.uniform(0, 1 / 3, (n, 1)))
+    z0[0] = cclqr.examples.cartpole_n(1)["mech"].state()          # instance 0 = the script's nominal point
+    st = cclqr.simulate(mech, 10, lqr, record=False, z0=z0)
+    assert (st.status > 0).all() and (st.status <= 6).all()
+    zT = st.zT
+    # every instance regulated: cart at the origin, pole upright, at rest
+    assert np.abs(zT[:, 0, 1]).max() < 2e-2 and np.abs(zT[:, 1, 4]).max() < 1e-3 and np.abs(zT[:, :, 7:]).max() < 5e-2
+    assert np.abs(np.linalg.norm(zT[:, :, 3:7], axis=2) - 1).max() < 1e-12
+    t = mech.tables()
+    assert _constraint_violation(cclqr, orc, t, zT, range(0, n, 97)) < 1e-12
+    # determinism and batch-order invariance (bitwise)
+    st2 = cclqr.simulate(mech, 10, lqr, record=False, z0=z0)
+    assert np.array_equal(st2.zT, zT)
+    perm = rng.permutation(n)
+    st3 = cclqr.simulate(mech, 10, lqr, record=False, z0=z0[perm])
+    assert np.array_equal(st3.zT, zT[perm])
+    # spot-check against the oracle
+    octrl = orc.ctrl_desc(2, [0], K=lqr.K, N=lqr.N, zd=lqr.zd)
+    idx = [0, 1, 1234, 4095]
+    zo, _, _ = orc.rollout(t, octrl, z0[idx], 1000)
+    assert np.abs(zo - zT[idx]).max() < 1e-9
+
+
+def test_cfg3_chain16_8192_shard_equivalence(cclqr, orc):
+    """configs[2] per-GPU shard: 8192 instances of the 17-body chain; 8 shards of 1024 == one batch of 8192 (what the
+    multi-GPU path relies on), launches chain exactly (k0 continuation with the multipliers carried over)"""
+    import ctypes as C
+    capi = cclqr._capi
+    n_links, n, steps = 16, 8192, 40
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "chain16_hanging_cfg3.npz"))
+    K = np.tile(g["K_first"][None], (999, 1, 1))
+    rng = np.random.default_rng(7)
+    phi = rng.uniform(-0.2, 0.2, (n, n_links))
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n), phi)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=1000, zd=zd)
+    zT, _, st = capi.rollout(mech, ctrl, z0, steps)
+    assert (st > 0).all()
+    for s in range(0, 8, 3):
+        lo, hi = cclqr.dist.shard_bounds(n, s, 8)
+        zs, _, _ = capi.rollout(mech, ctrl, z0[lo:hi], steps)
+        assert np.array_equal(zs, zT[lo:hi])
+    assert np.abs(np.linalg.norm(zT[:, :, 3:7], axis=2) - 1).max() < 1e-12
+    assert _constraint_violation(cclqr, orc, t, zT, range(0, n, 511)) < 1e-11
+    octrl = orc.ctrl_desc(t.nb, [0], K=K, N=1000, zd=zd)
+    zo, _, _ = orc.rollout(t, octrl, z0[[0, 8191]], steps)
+    assert np.abs(zo - zT[[0, 8191]]).max() < 1e-9
+
+
+def test_ragged_and_empty_batches(cclqr):
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(1)
+    t = ex["mech"].tables()
+    mech = capi.MechHandle(t)
+    zd = np.zeros((2, 13))
+    zd[:, 3] = 1
+    zd[1, 2] = 0.5
+    ctrl = capi.CtrlHandle(mech, [0], K=np.zeros((9, 1, 24)), N=10, zd=zd)
+    z0 = cclqr.examples.cartpole_states(1, np.linspace(-0.4, 0.4, 7), np.full((7, 1), 0.1))
+    full, _, _ = capi.rollout(mech, ctrl, z0, 20)
+    for n in (1, 3, 4, 5, 7):                    # 4 instances share a wavefront (G = 16): partial groups, partial waves
+        part, _, st = capi.rollout(mech, ctrl, z0[:n], 20)
+        assert np.array_equal(part, full[:n]) and (st > 0).all()
+    empty, _, st = capi.rollout(mech, ctrl, z0[:0], 20)
+    assert empty.shape == (0, 2, 13)
+    same, _, _ = capi.rollout(mech, ctrl, z0, 0)  # zero steps: state passes through
+    assert np.array_equal(same, z0)
