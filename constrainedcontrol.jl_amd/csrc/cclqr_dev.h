@@ -56,7 +56,7 @@ struct CtrlDev {
 // ---- LDS layout of one instance (offsets in doubles) ----
 // NB holds N(w+) D_R^-1 (so that the joint evaluation emits W = G_v D^-1 directly)
 struct Lay {
-    int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, DZ, total;
+    int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, C, CD, DZ, total;
 };
 #define BLK 31   // stride of a 5x6 block (30 used; odd stride keeps ds_read_b64 conflict-free across lanes)
 HD Lay make_layout(int nb) {
@@ -68,6 +68,8 @@ HD Lay make_layout(int nb) {
     L.GKA = o; o += BLK * nb; L.GKB = o; o += BLK * nb; L.GVA = o; o += BLK * nb; L.GVB = o; o += BLK * nb;
     L.SJJ = o; o += 25 * nb; L.SJP = o; o += 25 * nb; L.SPJ = o; o += 25 * nb;
     L.UJ = o; o += nb;
+    L.C = o; o += 6 * nb;    // G_k' lambda at the accepted point
+    L.CD = o; o += 6 * nb;   // G_k' dlambda of the current Newton step
     L.DZ = L.GVA;            // control error aliases the (dead at control time) Gv storage: 12 nb <= 31 nb
     L.total = o | 1;         // odd instance stride
     return L;
@@ -339,15 +341,17 @@ HD void make_N(const double* w2, double sq2, double dt, double* N) {
     N[6] = k * (w2[1] + w2[2] * w2[0] * isq);  N[7] = k * (-w2[0] + w2[2] * w2[1] * isq); N[8] = k * (sq2 + w2[2] * w2[2] * isq);
 }
 
-// E1: body t at the trial solution s: next pose, dynamics residual (without G'lambda); with JAC also D_R^-1 and N D_R^-1
+// E1: body t at the trial solution s: next pose, residual d = dyn(s) - (C - alpha CD) where C = G_k' lambda, CD = G_k' dlambda
+// (the constraint-force map is linear in lambda, so a trial point lambda - alpha dlambda needs no new G_k' product);
+// with JAC also D_R^-1 and N D_R^-1.  Returns this lane's partial sum of squares of d.
 template <bool JAC>
-HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt, int s_off) {
-    if (t >= nb) return;
-    double z[7], s[6];
+HD double ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt, int s_off, double alpha) {
+    if (t >= nb) return 0.0;
+    double z[7], s[6], cf[6];
 #pragma unroll
     for (int i = 0; i < 7; i++) z[i] = L[Y.Z + 13 * t + i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) s[i] = L[s_off + 6 * t + i];
+    for (int i = 0; i < 6; i++) { s[i] = L[s_off + 6 * t + i]; cf[i] = L[Y.C + 6 * t + i] - alpha * L[Y.CD + 6 * t + i]; }
     const double* w2 = s + 3;
     double* xq = L + Y.XQ + 7 * t;
     for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
@@ -357,8 +361,13 @@ HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, 
     double Jw2[3], c2[3];
     mv3(r.J, w2, Jw2); cross3(w2, Jw2, c2);
     double* d = L + Y.D + 6 * t;
-    for (int i = 0; i < 3; i++) { d[i] = r.m * s[i] / dt + r.cT[i]; d[3 + i] = sq2 * Jw2[i] + c2[i] + r.cR[i]; }
-    if (!JAC) return;
+    double acc = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double dT = r.m * s[i] / dt + r.cT[i] - cf[i], dR = sq2 * Jw2[i] + c2[i] + r.cR[i] - cf[3 + i];
+        d[i] = dT; d[3 + i] = dR;
+        acc += dT * dT + dR * dR;
+    }
+    if (!JAC) return acc;
     // D_R = (sq2 I + [w2]x) J - [J w2]x - (J w2) w2'/sq2
     double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2}, SJ[9], Dr[9], Di[9], N[9];
     mm3(S, r.J, SJ);
@@ -370,41 +379,43 @@ HD void ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, 
     for (int i = 0; i < 9; i++) L[Y.DINV + 9 * t + i] = Di[i];
     make_N(w2, sq2, dt, N);
     mm3(N, Di, L + Y.NB + 9 * t);
+    return acc;
 }
 
-// E2: joint t at the next knot: g and W = G_v D^-1 = [X dt (dt/m), Phi N D_R^-1]  (JAC) or g only
+// E2: joint t at the next knot: g and W = G_v D^-1 = [X dt (dt/m), Phi N D_R^-1]  (JAC) or g only; returns |g_t|^2
 template <bool JAC>
-HD void ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt) {
-    if (t >= nb) return;
+HD double ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, double dt) {
+    if (t >= nb) return 0.0;
     int a = r.parent;
     const double X0[3] = {0, 0, 0};
     const double* pa = (a >= 0) ? L + Y.XQ + 7 * a : nullptr;
     const double* pb = L + Y.XQ + 7 * t;
+    double g[5];
     joint_eval<JAC>(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, (a >= 0) ? dt * L[Y.DTM + a] : 0.0, dt * L[Y.DTM + t],
-                    (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * t, L + Y.G + 5 * t, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
+                    (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * t, g, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { L[Y.G + 5 * t + i] = g[i]; acc += g[i] * g[i]; }
+    return acc;
 }
 
 HD int link_parent(const MechDev* M, int l) { return ((M->start_mask >> l) & 1u) ? -1 : l - 1; }
 HD int link_child(const MechDev* M, int l) { return ((M->end_mask >> l) & 1u) ? -1 : l + 1; }
 
-// E3: d_b -= Gk_b(own joint)' lambda_b + Gk_a(child joint)' lambda_child, one task per body; returns the partial sum of squares
-// of the residual entries (d_b and g_b) this lane owns
-HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask, int lam_off) {
-    double acc = 0.0;
+// F3 (once per step, after the knot Jacobians): C_b = Gk_b(own joint)' lambda_b + Gk_a(child joint)' lambda_child
+HD void ph_force_map(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
     for (int b = t; b < nb; b += G) {
         const bool has_c = !((end_mask >> b) & 1u);
-        double d[6], gb[30], lb[5], ga[30], lc[5], g[5];
-#pragma unroll
-        for (int i = 0; i < 6; i++) d[i] = L[Y.D + 6 * b + i];
+        double gb[30], lb[5], ga[30], lc[5];
 #pragma unroll
         for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
 #pragma unroll
-        for (int i = 0; i < 5; i++) { lb[i] = L[lam_off + 5 * b + i]; g[i] = L[Y.G + 5 * b + i]; }
+        for (int i = 0; i < 5; i++) lb[i] = L[Y.LAM + 5 * b + i];
         if (has_c) {
 #pragma unroll
             for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * (b + 1) + i];
 #pragma unroll
-            for (int i = 0; i < 5; i++) lc[i] = L[lam_off + 5 * (b + 1) + i];
+            for (int i = 0; i < 5; i++) lc[i] = L[Y.LAM + 5 * (b + 1) + i];
         } else {
 #pragma unroll
             for (int i = 0; i < 30; i++) ga[i] = 0.0;
@@ -413,16 +424,11 @@ HD double ph_force_map_norm(int t, int G, int nb, const Lay& Y, double* L, unsig
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-            d[c] -= gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
-                  + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
-            acc += d[c] * d[c];
+            L[Y.C + 6 * b + c] = gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
+                               + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+            L[Y.CD + 6 * b + c] = 0.0;
         }
-#pragma unroll
-        for (int c = 0; c < 5; c++) acc += g[c] * g[c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) L[Y.D + 6 * b + c] = d[c];
     }
-    return acc;
 }
 
 HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
@@ -603,29 +609,49 @@ HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned en
 #pragma unroll
             for (int i = 0; i < 5; i++) lc[i] = 0.0;
         }
-        double tv[6];
+        double tv[6], cd[6];
 #pragma unroll
-        for (int c = 0; c < 6; c++)
-            tv[c] = d[c] + gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
-                         + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+        for (int c = 0; c < 6; c++) {
+            cd[c] = gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4]
+                  + ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+            tv[c] = d[c] + cd[c];
+        }
         double o[6];
 #pragma unroll
         for (int c = 0; c < 3; c++) { o[c] = tv[c] * dtm; o[3 + c] = Di[3 * c] * tv[3] + Di[3 * c + 1] * tv[4] + Di[3 * c + 2] * tv[5]; }
 #pragma unroll
-        for (int c = 0; c < 6; c++) L[Y.DS + 6 * b + c] = o[c];
+        for (int c = 0; c < 6; c++) { L[Y.DS + 6 * b + c] = o[c]; L[Y.CD + 6 * b + c] = cd[c]; }
     }
 }
 
-// T1: trial point  st = s - alpha ds ; lt = lam - alpha dl ; returns partial ||(ds, dl)||^2
-HD double ph_trial(int t, int G, int nb, const Lay& Y, double* L, double alpha) {
+// T1: trial point  st = s - alpha ds ; lt = lam - alpha dl  (one task per link); returns partial ||(ds, dl)||^2
+HD double ph_trial(int t, int G, int nb, const Lay& Y, double* L, double alpha, int s_cur, int s_try, int l_cur, int l_try) {
     double acc = 0.0;
-    for (int e = t; e < 6 * nb; e += G) { double d = L[Y.DS + e]; L[Y.ST + e] = L[Y.S + e] - alpha * d; acc += d * d; }
-    for (int e = t; e < 5 * nb; e += G) { double d = L[Y.DL + e]; L[Y.LT + e] = L[Y.LAM + e] - alpha * d; acc += d * d; }
+    for (int b = t; b < nb; b += G) {
+        double sv[6], dv[6], lv[5], ev[5];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { sv[i] = L[s_cur + 6 * b + i]; dv[i] = L[Y.DS + 6 * b + i]; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) { lv[i] = L[l_cur + 5 * b + i]; ev[i] = L[Y.DL + 5 * b + i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { L[s_try + 6 * b + i] = sv[i] - alpha * dv[i]; acc += dv[i] * dv[i]; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) { L[l_try + 5 * b + i] = lv[i] - alpha * ev[i]; acc += ev[i] * ev[i]; }
+    }
     return acc;
 }
-HD void ph_accept(int t, int G, int nb, const Lay& Y, double* L) {
-    for (int e = t; e < 6 * nb; e += G) L[Y.S + e] = L[Y.ST + e];
-    for (int e = t; e < 5 * nb; e += G) L[Y.LAM + e] = L[Y.LT + e];
+// accept: the trial buffers become the current ones (the caller swaps offsets); C follows lambda:  C -= alpha CD
+HD void ph_accept(int t, int G, int nb, const Lay& Y, double* L, double alpha) {
+    for (int b = t; b < nb; b += G) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { L[Y.C + 6 * b + i] -= alpha * L[Y.CD + 6 * b + i]; L[Y.CD + 6 * b + i] = 0.0; }
+    }
+}
+// copy the solution back into S/LAM when the Newton loop ended on the swapped buffers
+HD void ph_copy_solution(int t, int G, int nb, const Lay& Y, double* L, int s_cur, int l_cur) {
+    if (s_cur == Y.S) return;
+    for (int e = t; e < 6 * nb; e += G) L[Y.S + e] = L[s_cur + e];
+    for (int e = t; e < 5 * nb; e += G) L[Y.LAM + e] = L[l_cur + e];
 }
 // U1: state update from the accepted solution (XQ holds its next pose)
 HD void ph_update(int t, int nb, const Lay& Y, double* L) {

@@ -60,17 +60,16 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
-// residual (+ Jacobians when JAC) at the point stored at (s_off, lam_off); returns the group's ||f||_2
+// residual (+ Jacobians when JAC) at the point s_off with multipliers lambda - alpha dlambda; returns the group's ||f||_2
 template <int G, bool JAC>
 __device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M, double dt,
-                                             int s_off, int lam_off, bool active PROF_ARG) {
-    if (active) ph_body_eval<JAC>(t, nb, Y, L, r, dt, s_off);
+                                             int s_off, double alpha, bool active PROF_ARG) {
+    double part = active ? ph_body_eval<JAC>(t, nb, Y, L, r, dt, s_off, alpha) : 0.0;
     __syncthreads();
     STAMP(PF_EVAL_BODY);
-    if (active) ph_joint_eval<JAC>(t, nb, Y, L, r, dt);
+    part += active ? ph_joint_eval<JAC>(t, nb, Y, L, r, dt) : 0.0;
     __syncthreads();
     STAMP(PF_EVAL_JOINT);
-    double part = active ? ph_force_map_norm(t, G, nb, Y, L, M->end_mask, lam_off) : 0.0;
     double nrm = sqrt(group_sum<G>(part));
     STAMP(PF_EVAL_MAP);
     PCOUNT(PF_EVALS);
@@ -84,11 +83,12 @@ __device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double
 template <int G>
 __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt, bool valid,
                                             bool* converged PROF_ARG) {
-    double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, Y.LAM, valid PROF_PASS);
+    double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
     bool done = !valid;
     int its = 0;
     const unsigned smask = M->start_mask, emask = M->end_mask;
     const int nchains = M->nchains;
+    int s_cur = Y.S, s_try = Y.ST, l_cur = Y.LAM, l_try = Y.LT;   // accepted / trial buffers swap roles on every acceptance
     for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
         if (!__any(!done)) break;
         PCOUNT(PF_NEWTON_ITERS);
@@ -103,7 +103,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
                 double lu[5];
                 int l = 0;
                 bool act = !done && ph_tri_elim(t, i, P, Y, L, lu, &l);
-                __syncthreads();
+                // no barrier here: the store overwrites what the same wavefront has already loaded (LDS is in order per wavefront)
                 if (act) ph_tri_store(t, l, Y, L, lu);
                 __syncthreads();
             }
@@ -125,13 +125,13 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         bool ls_done = done, jac_ok = true;
         for (int ls = 0; ls <= LINE_MAXIT; ls++) {
             if (!__any(!ls_done)) break;
-            double pd = ls_done ? 0.0 : ph_trial(t, G, nb, Y, L, alpha);
+            double pd = ls_done ? 0.0 : ph_trial(t, G, nb, Y, L, alpha, s_cur, s_try, l_cur, l_try);
             double nd2 = group_sum<G>(pd);
             if (ls == 0) nd = sqrt(nd2);
             __syncthreads();
             STAMP(PF_TRIAL);
-            double nf = (ls == 0) ? eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.ST, Y.LT, !ls_done PROF_PASS)
-                                  : eval_point<G, false>(t, nb, Y, L, r, M, dt, Y.ST, Y.LT, !ls_done PROF_PASS);
+            double nf = (ls == 0) ? eval_point<G, true>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS)
+                                  : eval_point<G, false>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS);
             if (!ls_done) {
                 normf1 = nf;
                 if (ls > 0) jac_ok = false;
@@ -140,8 +140,11 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
             __syncthreads();
         }
         bool need_jac = false;
+        // all groups of the wavefront swap together: groups that are already done copy nothing and keep their solution where
+        // it is, so the swap is only applied to a group's own view
         if (!done) {
-            ph_accept(t, G, nb, Y, L);
+            ph_accept(t, G, nb, Y, L, alpha);
+            { int q = s_cur; s_cur = s_try; s_try = q; q = l_cur; l_cur = l_try; l_try = q; }
             its = iter;
             if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
             normf0 = normf1;
@@ -149,8 +152,10 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         }
         __syncthreads();
         STAMP(PF_ACCEPT);
-        if (__any(need_jac)) eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, Y.LAM, need_jac PROF_PASS);
+        if (__any(need_jac)) eval_point<G, true>(t, nb, Y, L, r, M, dt, s_cur, 0.0, need_jac PROF_PASS);
     }
+    ph_copy_solution(t, G, nb, Y, L, s_cur, l_cur);
+    __syncthreads();
     *converged = done;
     return its;
 }

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     ph_forces(t, nb, Y, L, r, M);
     ph_knot_jac(t, nb, Y, L, r);
     __syncthreads();
+    ph_force_map(t, G, nb, Y, L, M->end_mask);
+    __syncthreads();
     bool done = false;
 #ifdef CCLQR_PROFILE
     Prof prof;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     int its = newton_solve<G>(t, nb, Y, L, r, M, dt, true, &done PROF_PASS);
     __syncthreads();
     // D_R^-1 and the next pose at the converged solution (the last line-search trial may have been residual-only)
-    ph_body_eval<true>(t, nb, Y, L, r, dt, Y.S);
+    ph_body_eval<true>(t, nb, Y, L, r, dt, Y.S, 0.0);
     __syncthreads();
     ph_lin_joint(t, nb, Y, JB, L, r);
     __syncthreads();

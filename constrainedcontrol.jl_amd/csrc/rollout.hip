@@ -73,6 +73,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         ph_forces(t, nb, Y, L, r, M);
         ph_knot_jac(t, nb, Y, L, r);
         __syncthreads();
+        ph_force_map(t, G, nb, Y, L, M->end_mask);
+        __syncthreads();
         STAMP(PF_FORCES);
         PCOUNT(PF_STEPS);
 

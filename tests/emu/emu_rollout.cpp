@@ -10,19 +10,19 @@
 using namespace cclqr;
 
 template <bool JAC>
-static double eval_point(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, int s_off, int lam_off) {
-    for (int t = 0; t < G; t++) ph_body_eval<JAC>(t, nb, Y, L, R[t], dt, s_off);
-    for (int t = 0; t < G; t++) ph_joint_eval<JAC>(t, nb, Y, L, R[t], dt);
+static double eval_point(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, int s_off, double alpha) {
     double acc = 0.0;
-    for (int t = 0; t < G; t++) acc += ph_force_map_norm(t, G, nb, Y, L, M->end_mask, lam_off);
+    for (int t = 0; t < G; t++) acc += ph_body_eval<JAC>(t, nb, Y, L, R[t], dt, s_off, alpha);
+    for (int t = 0; t < G; t++) acc += ph_joint_eval<JAC>(t, nb, Y, L, R[t], dt);
     return sqrt(acc);
 }
 
 // serial twin of cclqr_newton.h newton_solve<G> (one group)
 static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRegs>& R, const MechDev* M, double dt, bool* converged) {
-    double normf0 = eval_point<true>(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+    double normf0 = eval_point<true>(G, nb, Y, L, R, M, dt, Y.S, 0.0);
     bool done = false;
     int its = 0;
+    int s_cur = Y.S, s_try = Y.ST, l_cur = Y.LAM, l_try = Y.LT;
     for (int iter = 1; iter <= 100 && !done; iter++) {
         for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M->start_mask);
         for (int c = 0; c < M->nchains; c++) {
@@ -42,18 +42,20 @@ static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRe
         bool jac_ok = true;
         for (int ls = 0; ls <= 10; ls++) {
             double pd = 0.0;
-            for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha);
+            for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha, s_cur, s_try, l_cur, l_try);
             if (ls == 0) nd = sqrt(pd);
-            normf1 = (ls == 0) ? eval_point<true>(G, nb, Y, L, R, M, dt, Y.ST, Y.LT) : eval_point<false>(G, nb, Y, L, R, M, dt, Y.ST, Y.LT);
+            normf1 = (ls == 0) ? eval_point<true>(G, nb, Y, L, R, M, dt, s_try, alpha) : eval_point<false>(G, nb, Y, L, R, M, dt, s_try, alpha);
             if (ls > 0) jac_ok = false;
             if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
         }
-        for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L);
+        for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L, alpha);
+        { int q = s_cur; s_cur = s_try; s_try = q; q = l_cur; l_cur = l_try; l_try = q; }
         its = iter;
         if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
         normf0 = normf1;
-        if (!done && !jac_ok) eval_point<true>(G, nb, Y, L, R, M, dt, Y.S, Y.LAM);
+        if (!done && !jac_ok) eval_point<true>(G, nb, Y, L, R, M, dt, s_cur, 0.0);
     }
+    for (int t = 0; t < G; t++) ph_copy_solution(t, G, nb, Y, L, s_cur, l_cur);
     *converged = done;
     return its;
 }
@@ -103,6 +105,7 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     L[Y.UJ + C->cj[i]] += u;
                 }
             for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+            for (int t = 0; t < G; t++) ph_force_map(t, G, nb, Y, L, M->end_mask);
             bool done = false;
             int its = emu_newton(G, nb, Y, L, R, M, dt, &done);
             if (!done) bad = true;
@@ -143,10 +146,11 @@ extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu
     for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = zd[M->perm[l] * 13 + c]; }
     for (int i = 0; i < mu; i++) L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0;
     for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+            for (int t = 0; t < G; t++) ph_force_map(t, G, nb, Y, L, M->end_mask);
     bool done = false;
     emu_newton(G, nb, Y, L, R, M, dt, &done);
     if (!done) return -3;
-    for (int t = 0; t < G; t++) ph_body_eval<true>(t, nb, Y, L, R[t], dt, Y.S);
+    for (int t = 0; t < G; t++) ph_body_eval<true>(t, nb, Y, L, R[t], dt, Y.S, 0.0);
     for (int t = 0; t < G; t++) ph_lin_joint(t, nb, Y, JB, L, R[t]);
     for (int t = 0; t < G; t++) { ph_lin_rows_A(t, nb, Y, JB, L, R[t], M, O); ph_lin_rows_B(t, nb, Y, L, R[t], M, cj, O); }
     return 0;
