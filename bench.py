@@ -154,7 +154,46 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_and_flops(pkg, t, lqr, z0, T, value, kern_ms, n_inst))
+    if world == 1:
+        out["extra"] = extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T)
     print(json.dumps(out), flush=True)
+
+
+def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T):
+    """not the headline: configs[1] (lqr_cartpole.jl, 4096 random-init instances, 1000 steps, record=true) through the same kernel,
+    and the rate of the setup path (linearsystem + Riccati recursion on fp64 MFMA) measured while building the headline LQR"""
+    ex = pkg.examples.cartpole_n(1)
+    mech = ex["mech"]
+    t0 = time.time()
+    lq = pkg.LQR(mech, [1, 2], [3], ex["Q"], ex["R"], 10.0, xd=ex["xd"])
+    setup2 = time.time() - t0
+    rng = np.random.default_rng(0xC0FFEE)
+    n = 4096
+    z0 = pkg.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, n), rng.uniform(0, 1 / 3, (n, 1)))
+    mh = mech._cclqr_handle
+    ctrl = lq._ctrl_handle(mh)
+    z0_d = torch.from_numpy(z0).to(dev)
+    zT_d = torch.empty_like(z0_d)
+    st_d = torch.zeros(n, dtype=torch.int32, device=dev)
+    traj_d = torch.empty((n, 1000, 2, 13), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    run = lambda: capi.rollout_dev(mh, ctrl, n, 1000, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr(), zT_d.data_ptr(), st_d.data_ptr(), stream)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / 5
+    m = mu + ml
+    f_ric = 4 * mx ** 3 + 4 * mx ** 2 * m + 2 * mx * (ml ** 2 + m ** 2) + 2 / 3 * m ** 3 + 2 / 3 * ml ** 3    # SURVEY 8a row a5
+    nsteps = T - max(int(lqr.kbreak), 1)
+    return {"cartpole_cfg2": {"instances": n, "sim_steps": 1000, "value": n * 1000 / dt2, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt2,
+                              "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak)},
+            "riccati_setup": {"mx": mx, "backward_steps": nsteps, "flops_per_step": f_ric,
+                              "note": "LQR construction of the headline workload = linearize + %d-step recursion, one workgroup, fp64 MFMA; "
+                                      "wall time incl. host<->device copies" % nsteps,
+                              "gflops_lower_bound": f_ric * nsteps / setup_s / 1e9, "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}}
 
 
 def cpu_baseline_and_flops(pkg, t, lqr, z0, T, gpu_value, kern_ms, n_inst):

@@ -1,0 +1,165 @@
+# CCLQR.jl -- `ccall` shim between ConstrainedControl.jl and libcclqr.so (include/cclqr.h).
+#
+# STATUS: source only.  No Julia toolchain exists in the build/test pipeline of this repository, so this file has never been
+# executed; the ABI it binds IS exercised (by constrainedcontrol.jl_amd/_capi.py through ctypes).  Struct layouts below mirror
+# include/cclqr.h field by field.  The two functions that read ConstrainedDynamics internals (`mech_tables`) are the only
+# parts that depend on that package's field names (0.9.x); everything else is plain arrays.
+#
+# Drop-in points in the reference (janbruedigam/ConstrainedControl.jl v0.3.0):
+#   src/control/lqr.jl:63   A, Bu, Bλ, G = linearsystem(...)          ->  CCLQR.linearsystem(h, zd, ctrl, Fd)
+#   src/control/lqr.jl:39   Ku = dlqr(A, Bu, Bλ, G, Q, R, Ntemp)      ->  CCLQR.dlqr(A, Bu, Bλ, G, Q, R, Ntemp)
+#   src/control/lqr_tracking.jl:40  Ku = dlqr(mechanism, xd, ...)      ->  CCLQR.dlqr_tracking(h, zd, Fd, ctrl, Q, R, N)
+#   simulate!(mech, tend, lqr; record) on a batch                     ->  CCLQR.simulate_batch!(h, c, z0, steps; record, noise)
+module CCLQR
+
+using LinearAlgebra
+
+const lib = get(ENV, "CCLQR_LIB", joinpath(@__DIR__, "..", "constrainedcontrol.jl_amd", "libcclqr.so"))
+
+struct MechDesc            # cclqr_mech_desc
+    nb::Int32; ne::Int32
+    dt::Float64; g::Float64
+    mass::Ptr{Float64}; inertia::Ptr{Float64}
+    parent::Ptr{Int32}; child::Ptr{Int32}; type::Ptr{Int32}
+    p1::Ptr{Float64}; p2::Ptr{Float64}; axis::Ptr{Float64}; qoff::Ptr{Float64}
+end
+
+struct CtrlDesc            # cclqr_ctrl_desc
+    mu::Int32; ctrl_joint::Ptr{Int32}
+    nK::Int32; N::Int32; K::Ptr{Float64}
+    nsp::Int32; zd::Ptr{Float64}; Fd::Ptr{Float64}
+    fric::Ptr{Float64}; noise_scale::Float64
+end
+
+const REVOLUTE = Int32(0)
+const PRISMATIC = Int32(1)
+
+lasterror() = unsafe_string(ccall((:cclqr_last_error, lib), Cstring, ()))
+function check(rc::Integer)
+    rc == 0 && return nothing
+    msg = lasterror()
+    rc == -1 && throw(AssertionError(msg))          # CCLQR_EINVAL   <-> the reference's @assert (lqr.jl:59-60)
+    rc == -2 && throw(SingularException(0))         # CCLQR_ESINGULAR <-> LAPACK exception from lqr.jl:151,160
+    rc == -3 && (@info msg; return nothing)         # CCLQR_ENOCONV  <-> `@info "Riccati recursion did not converge."` (lqr.jl:41)
+    error("cclqr ($rc): $msg")
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mechanism -> flat tables.  Assumes ConstrainedDynamics 0.9.x field names: mechanism.bodies / eqconstraints / origin / Δt / g,
+# body.m, body.J, eqc.parentid, eqc.childids, eqc.constraints = (Translational, Rotational) with .vertices, .V3 (axis row),
+# .qoffset.  Body ids 1..Nb, joint ids Nb+1.. (examples/trackingLQR_triple_cartpole.jl:109-111).
+function mech_tables(mechanism)
+    bodies = collect(mechanism.bodies); eqcs = collect(mechanism.eqconstraints)
+    nb, ne = length(bodies), length(eqcs)
+    bodyindex = Dict(b.id => Int32(i - 1) for (i, b) in enumerate(bodies))
+    mass = Float64[b.m for b in bodies]
+    inertia = reduce(vcat, [vec(permutedims(Matrix(b.J))) for b in bodies])          # row-major 3x3 per body
+    parent = Int32[get(bodyindex, e.parentid, Int32(-1)) for e in eqcs]                # origin -> -1
+    child = Int32[bodyindex[e.childids[1]] for e in eqcs]
+    typ = Int32[length(e.constraints[1]) == 3 ? REVOLUTE : PRISMATIC for e in eqcs]   # Translational3+Rotational2 | Translational2+Rotational3
+    p1 = reduce(vcat, [Vector{Float64}(e.constraints[1].vertices[1]) for e in eqcs])
+    p2 = reduce(vcat, [Vector{Float64}(e.constraints[1].vertices[2]) for e in eqcs])
+    axis = reduce(vcat, [Vector{Float64}(vec(typ[i] == REVOLUTE ? e.constraints[2].V3 : e.constraints[1].V3)) for (i, e) in enumerate(eqcs)])
+    qoff = reduce(vcat, [Float64[q.s, q.v1, q.v2, q.v3] for q in (e.constraints[2].qoffset for e in eqcs)])
+    return (; nb, ne, dt = Float64(mechanism.Δt), g = Float64(mechanism.g), mass, inertia, parent, child, typ, p1, p2, axis, qoff)
+end
+
+mutable struct MechHandle
+    ptr::Ptr{Cvoid}
+    nb::Int
+    function MechHandle(t)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve t begin
+            d = MechDesc(t.nb, t.ne, t.dt, t.g, pointer(t.mass), pointer(t.inertia), pointer(t.parent), pointer(t.child), pointer(t.typ),
+                         pointer(t.p1), pointer(t.p2), pointer(t.axis), pointer(t.qoff))
+            check(ccall((:cclqr_mech_create, lib), Cint, (Ref{MechDesc}, Ref{Ptr{Cvoid}}), d, h))
+        end
+        obj = new(h[], t.nb)
+        finalizer(o -> ccall((:cclqr_mech_destroy, lib), Cint, (Ptr{Cvoid},), o.ptr), obj)
+        obj
+    end
+end
+MechHandle(mechanism, ::Val{:mechanism}) = MechHandle(mech_tables(mechanism))
+
+# body states as the 13 x Nb matrix the C side reads as [nb][13] = x(3) q(4) v(3) ω(3)
+pack_state(xd, qd, vd, ωd) = reduce(hcat, [Float64[x...; q.s; q.v1; q.v2; q.v3; v...; ω...] for (x, q, v, ω) in zip(xd, qd, vd, ωd)])
+
+# C is row-major, Julia column-major: a C matrix [r][c] is read here as a (c, r) array and transposed lazily.
+cmat(buf, r, c) = permutedims(reshape(buf, c, r))
+
+"linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) replacement (lqr.jl:63).  ctrl = 0-based joint indices."
+function linearsystem(h::MechHandle, zd::Matrix{Float64}, ctrl::Vector{Int32}, Fd::Vector{Float64})
+    nb = h.nb; mx, ml, mu = 12nb, 5nb, length(ctrl)
+    A = zeros(mx * mx); Bu = zeros(mx * max(mu, 1)); Bl = zeros(mx * ml); G = zeros(ml * mx)
+    check(ccall((:cclqr_linearize, lib), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                h.ptr, 1, zd, mu, ctrl, Fd, A, Bu, Bl, G))
+    cmat(A, mx, mx), cmat(Bu[1:mx*mu], mx, mu), cmat(Bl, mx, ml), cmat(G, ml, mx)
+end
+
+"dlqr(A,Bu,Bλ,G,Q,R,N) replacement (lqr.jl:141-184).  Q, R are the Δt-scaled block diagonals of lqr.jl:18-19.  Returns Ku[k][i] and the break index."
+function dlqr(A, Bu, Bλ, G, Q, R, N::Integer; tol = 1e-5)
+    mx, mu, ml = size(A, 1), size(Bu, 2), size(Bλ, 2)
+    rowmajor(M) = vec(permutedims(Matrix{Float64}(M)))
+    K = zeros(mx * mu * max(N - 1, 0)); kb = Ref{Int32}(0)
+    check(ccall((:cclqr_riccati, lib), Cint,
+                (Int32, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64,
+                 Ptr{Float64}, Ref{Int32}),
+                1, mx, mu, ml, rowmajor(A), rowmajor(Bu), rowmajor(Bλ), rowmajor(G), rowmajor(Q), rowmajor(R), N, tol, K, kb))
+    K3 = reshape(K, mx, mu, N - 1)                                   # C layout [N-1][mu][mx]
+    Ku = [[reshape(K3[:, i, k], 1, mx) for i = 1:mu] for k = 1:N-1]   # the layout of lqr.jl:145
+    Ku, Int(kb[])
+end
+
+"dlqr(mechanism, xd, vd, qd, ωd, Fτd, eqcids, Q, R, N) replacement (lqr_tracking.jl:73-122): zd is 13 x Nb x N, Fd is mu x N."
+function dlqr_tracking(h::MechHandle, zd::Array{Float64,3}, Fd::Matrix{Float64}, ctrl::Vector{Int32}, Q, R, N::Integer; tol = 1e-5)
+    mx, mu = 12h.nb, length(ctrl)
+    rowmajor(M) = vec(permutedims(Matrix{Float64}(M)))
+    K = zeros(mx * mu * (N - 1)); kb = Ref{Int32}(0)
+    check(ccall((:cclqr_riccati_tracking, lib), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ref{Int32}),
+                h.ptr, mu, ctrl, zd, Fd, rowmajor(Q), rowmajor(R), N, tol, K, kb))
+    K3 = reshape(K, mx, mu, N - 1)
+    [[reshape(K3[:, i, k], 1, mx) for i = 1:mu] for k = 1:N-1], Int(kb[])
+end
+
+mutable struct CtrlHandle
+    ptr::Ptr{Cvoid}
+end
+"Device controller tables from the fields of an LQR / TrackingLQR (lqr.jl:3-15, lqr_tracking.jl:3-15).
+ K: mx x mu x nK, zd: 13 x Nb x nsp, Fd: mu x nsp, N = horizon steps (0 for LQR{T,Inf}), ctrl = 0-based joint indices."
+function CtrlHandle(h::MechHandle, ctrl::Vector{Int32}, K::Array{Float64,3}, N::Integer, zd::Array{Float64,3}, Fd::Matrix{Float64};
+                    fric::Union{Nothing,Vector{Float64}} = nothing, noise_scale = 0.0)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ctrl K zd Fd fric begin
+        d = CtrlDesc(length(ctrl), pointer(ctrl), size(K, 3), N, pointer(K), size(zd, 3), pointer(zd), pointer(Fd),
+                     fric === nothing ? Ptr{Float64}(C_NULL) : pointer(fric), noise_scale)
+        check(ccall((:cclqr_ctrl_create, lib), Cint, (Ptr{Cvoid}, Ref{CtrlDesc}, Ref{Ptr{Cvoid}}), h.ptr, d, c))
+    end
+    obj = CtrlHandle(c[])
+    finalizer(o -> ccall((:cclqr_ctrl_destroy, lib), Cint, (Ptr{Cvoid},), o.ptr), obj)
+    obj
+end
+
+"Batched simulate!: z0 is 13 x Nb x n_inst; returns (traj 13 x Nb x steps x n_inst or nothing, zT, status)."
+function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, steps::Integer; record = true, noise = nothing, k0 = 1)
+    n = size(z0, 3)
+    traj = record ? zeros(13, h.nb, steps, n) : nothing
+    zT = similar(z0); status = zeros(Int32, n)
+    check(ccall((:cclqr_rollout, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                h.ptr, c.ptr, n, steps, k0, z0, noise === nothing ? C_NULL : noise, record ? traj : C_NULL, zT, status))
+    traj, zT, status
+end
+
+"Storage{T}(steps, Nb) view of instance n of a batched trajectory: storage.x[i][k] etc. (lqr_tracking.jl:32-35)."
+function storage_fields(traj::Array{Float64,4}, n::Integer)
+    nb, steps = size(traj, 2), size(traj, 3)
+    x = [[traj[1:3, i, k, n] for k = 1:steps] for i = 1:nb]
+    q = [[traj[4:7, i, k, n] for k = 1:steps] for i = 1:nb]
+    v = [[traj[8:10, i, k, n] for k = 1:steps] for i = 1:nb]
+    ω = [[traj[11:13, i, k, n] for k = 1:steps] for i = 1:nb]
+    (; x, q, v, ω)
+end
+
+end # module
