@@ -32,7 +32,8 @@ class MechDesc(C.Structure):
 
 class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
-                ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double)]
+                ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
+                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp)]
 
 
 _lib = None
@@ -115,7 +116,7 @@ class MechHandle:
 class CtrlHandle:
     """cclqr_ctrl*: device-resident controller tables"""
 
-    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0):
+    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, pid=None):
         nb = mech.tables.nb
         cj = i32(ctrl_joint).reshape(-1)
         mu = len(cj)
@@ -127,9 +128,13 @@ class CtrlHandle:
         Fd = f64(np.zeros((nsp, mu)) if Fd is None else Fd).reshape(nsp, mu)
         K = None if K is None else f64(K).reshape(-1, mu, 12 * nb)
         fric = None if fric is None else f64(fric).reshape(nb)
-        self._arrs = [cj, K, zd, Fd, fric]
+        pj = pP = pI = pD = pg = None
+        if pid is not None:
+            pj, pP, pI, pD, pg = i32(pid["joint"]).reshape(-1), f64(pid["P"]).reshape(-1), f64(pid["I"]).reshape(-1), f64(pid["D"]).reshape(-1), f64(pid["goal"]).reshape(-1)
+        self._arrs = [cj, K, zd, Fd, fric, pj, pP, pI, pD, pg]
         self.mu, self.N, self.nsp = mu, int(N), nsp
-        self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0], int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale))
+        self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0], int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale),
+                             0 if pj is None else len(pj), _i(pj), _d(pP), _d(pI), _d(pD), _d(pg))
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
 

@@ -51,6 +51,9 @@ struct CtrlDev {
     double fric[CCLQR_MAXL];  // viscous joint friction per link
     int has_fric;
     double noise_scale;
+    // PID on 1-DoF joints (pid.jl): per link, pid_on[l] != 0
+    int has_pid, pid_on[CCLQR_MAXL];
+    double pid_P[CCLQR_MAXL], pid_I[CCLQR_MAXL], pid_D[CCLQR_MAXL], pid_goal[CCLQR_MAXL];
 };
 
 // ---- LDS layout of one instance (offsets in doubles) ----
@@ -82,6 +85,8 @@ struct LaneRegs {
     int parent, childl, rotmask, type;
     // per-step invariants of the owned body: cT = m(-v/dt + ezg) - F ; cR = -(sq1 I - [w1]x) J w1 - 2 tau
     double cT[3], cR[3];
+    // PID state of the owned joint: integratederrors / lasterrors (pid.jl:10-11)
+    double pid_int, pid_last;
 };
 
 // ------------------------------------------------------------------ small algebra
@@ -150,6 +155,7 @@ HD void lane_load_consts(LaneRegs& r, const MechDev* M, int l) {
         for (int j = 0; j < 3; j++) r.sel[i][j] = M->sel[l][i][j];
     r.parent = M->parent[l]; r.childl = M->childl[l]; r.rotmask = M->rotmask[l]; r.type = M->type[l];
     for (int i = 0; i < 3; i++) { r.cT[i] = 0; r.cR[i] = 0; }
+    r.pid_int = 0.0; r.pid_last = 0.0;
 }
 
 // ------------------------------------------------------------------ joint: g and d g/d(x, phi) for both bodies
@@ -273,6 +279,39 @@ HD void ph_control_error(int t, int nb, const Lay& Y, double* L, const LaneRegs&
         u = -C->fric[t] * rel;
     }
     L[Y.UJ + t] = u;
+}
+
+// C1b: control_pid!(mechanism, pid, k) for the joint of link t (pid.jl:69-88): minimalCoordinates (angle about / offset along
+// the joint axis), wrapped error for revolutes (pid.jl:43-57), u = P e + I int(e) + D de/dt added to the joint input
+HD void ph_pid(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const CtrlDev* C, double dt, bool first) {
+    if (t >= nb || !C->pid_on[t]) return;
+    const int a = r.parent;
+    const double X0[3] = {0, 0, 0};
+    const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
+    const double* zb = L + Y.Z + 13 * t;
+    const double* qa = za ? za + 3 : QID_;
+    double th;
+    if (r.type == 0) {
+        double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
+        qmul(qac, zb + 3, rel);
+        qmul(rel, r.qoc, e);
+        th = 2.0 * atan2(r.axis[0] * e[1] + r.axis[1] * e[2] + r.axis[2] * e[3], e[0]);
+    } else {
+        double Ra[9], Rb[9], rp[3], w[3], gT[3];
+        rotmat(qa, Ra); rotmat(zb + 3, Rb);
+        mv3(Rb, r.p2, rp);
+        for (int i = 0; i < 3; i++) w[i] = zb[i] + rp[i] - (za ? za[i] : X0[i]);
+        mtv3(Ra, w, gT);
+        th = r.axis[0] * (gT[0] - r.p1[0]) + r.axis[1] * (gT[1] - r.p1[1]) + r.axis[2] * (gT[2] - r.p1[2]);
+    }
+    const double PI = 3.14159265358979323846;
+    double e = C->pid_goal[t] - th;
+    if (r.type == 0) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
+    if (first) r.pid_last = e;
+    r.pid_int += e * dt;
+    const double de = (e - r.pid_last) / dt;
+    L[Y.UJ + t] += C->pid_P[t] * e + C->pid_I[t] * r.pid_int + C->pid_D[t] * de;
+    r.pid_last = e;
 }
 
 // C2: partial dot product  sum_{t, t+G, ...} K[i][.] * DZ[.]  (caller reduces over the group)

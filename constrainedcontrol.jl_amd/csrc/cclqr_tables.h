@@ -125,6 +125,13 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
     }
     if (d->fric)
         for (int j = 0; j < nb; j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
+    for (int i = 0; i < d->npid; i++) {
+        int j = d->pid_joint ? d->pid_joint[i] : -1;
+        if (j < 0 || j >= nb || !d->pid_P || !d->pid_I || !d->pid_D || !d->pid_goal) { err = "PID joint out of range"; return CCLQR_EINVAL; }
+        int l = m->link_of_joint[j];
+        H.pid_on[l] = 1; H.has_pid = 1;
+        H.pid_P[l] = d->pid_P[i]; H.pid_I[l] = d->pid_I[i]; H.pid_D[l] = d->pid_D[i]; H.pid_goal[l] = d->pid_goal[i];
+    }
     T.zd.resize((size_t)d->nsp * nb * 13);
     for (int s = 0; s < d->nsp; s++)
         for (int l = 0; l < nb; l++) memcpy(&T.zd[((size_t)s * nb + l) * 13], d->zd + ((size_t)s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));

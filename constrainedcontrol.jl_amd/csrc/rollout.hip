@@ -68,6 +68,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 __syncthreads();
             }
         }
+        if (C->has_pid) {
+            if (valid) ph_pid(t, nb, Y, L, r, C, dt, k == 1);
+            __syncthreads();
+        }
         STAMP(PF_CONTROL);
         // ---------------- per-step invariants
         ph_forces(t, nb, Y, L, r, M);

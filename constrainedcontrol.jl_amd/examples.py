@@ -119,3 +119,14 @@ def sawyer(tables, g=0.0):
     return dict(mech=mech, bodies=mech.bodies, joints=mech.eqconstraints, Q=[np.eye(12) * 1000.0 for _ in range(nb)],
                 R=[np.ones((1, 1)) for _ in range(nb)], xd=[z[i, 0:3] for i in range(nb)], qd=[z[i, 3:7] for i in range(nb)],
                 ctrl=list(mech.eqconstraints), horizon=20.0, tend=20.0)
+
+
+def prismatic_slider():
+    """examples/lqr_prismatic.jl:8-30: Box(0.1,0.1,0.1,1) on Prismatic(origin, link1, ex), g = 0, start at Δx = [1,0,0];
+    minimal-coordinate LQR: Q = ones(1), R = ones(1), horizon 10 s (setpoint: joint coordinate 0)."""
+    origin = Origin()
+    link1 = Box(0.1, 0.1, 0.1, 1.0)
+    joint = EqualityConstraint(Prismatic(origin, link1, EX))
+    mech = Mechanism(origin, [link1], [joint], g=0.0)
+    setPosition(origin, link1, Δx=[1.0, 0.0, 0.0])
+    return dict(mech=mech, bodies=[link1], joints=[joint], Q=np.ones(1), R=np.ones(1), horizon=10.0)

@@ -15,7 +15,7 @@ import math
 import numpy as np
 
 from . import _capi
-from .mechanism import Mechanism, one_quaternion
+from .mechanism import Mechanism, minimal_to_maximal, one_quaternion
 
 
 def _blockdiag(blocks):
@@ -59,6 +59,10 @@ class LQR(Controller):
             ωd = kw.pop("wd")
         if "Ftd" in kw:
             Fτd = kw.pop("Ftd")
+        if "xθd" in kw:          # minimal-coordinate constructor keywords (lqr.jl:70-72)
+            xd = kw.pop("xθd")
+        if "vωd" in kw:
+            vd = kw.pop("vωd")
         if kw:
             raise TypeError("unexpected keyword(s): %s" % list(kw))
         if controlfunction is not None:
@@ -67,6 +71,19 @@ class LQR(Controller):
         if not isinstance(mechanism, Mechanism):
             raise TypeError("LQR(mechanism, bodyids, eqcids, Q, R, horizon; ...)")
         nb = len(mechanism.bodies)
+        if len(Q) and np.ndim(Q[0]) == 0:
+            # LQR(mechanism, controlledids, controlids, Q::Vector{T}, R::Vector{T}, horizon; xθd, vωd, Fτd)      lqr.jl:68-86
+            controlledids, controlids = bodyids, eqcids
+            xθd = np.zeros(len(controlledids)) if xd is None else np.asarray(xd, dtype=np.float64)
+            vωd = np.zeros(len(controlledids)) if vd is None else np.asarray(vd, dtype=np.float64)
+            Fτ = np.zeros(len(controlids)) if Fτd is None else np.asarray(Fτd, dtype=np.float64).reshape(-1)
+            assert len(controlledids) == len(Q) == len(xθd) == len(vωd) == nb, "Missmatched length for bodies"          # lqr.jl:76
+            assert len(controlids) == len(R) == len(Fτ), "Missmatched length for constraints"                          # lqr.jl:77
+            xd, vd, qd, ωd = minimal_to_maximal(mechanism, controlledids, xθd, vωd)                                    # lqr.jl:80
+            Q = [np.eye(12) * float(q) for q in Q]                                                                     # lqr.jl:82
+            R = [np.eye(1) * float(r) for r in R]                                                                      # lqr.jl:83
+            Fτd = [[f] for f in Fτ]                                                                                    # lqr.jl:85
+            bodyids = [b.id for b in mechanism.bodies]
         z3 = [np.zeros(3) for _ in range(nb)]
         xd = z3 if xd is None else xd                       # lqr.jl:51-55 defaults
         vd = z3 if vd is None else vd
@@ -212,6 +229,29 @@ class OpenLoop(Controller):
 
     def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
         return _capi.CtrlHandle(dev, self.ctrl_joints, K=None, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+
+
+class PID(Controller):
+    """PID{T,N}: P, I, D, eqcids, goals (integratederrors / lasterrors live on the device)   src/control/pid.jl:3-40
+    PID(mechanism, eqcid::Int, goal; P, I, D)  /  PID(mechanism, eqcids::Vector, goals::Vector; P, I, D)"""
+
+    def __init__(self, mechanism, eqcids, goals, P=None, I=None, D=None, controlfunction=None):
+        if controlfunction is not None:
+            raise NotImplementedError("custom controlfunction (pid.jl:16,27) cannot run on the device")
+        scalar = np.ndim(eqcids) == 0
+        ids = [int(eqcids)] if scalar else [int(e) for e in eqcids]
+        n = len(ids)
+        vec = lambda v: np.zeros(n) if v is None else np.asarray(v, dtype=np.float64).reshape(n)
+        self.mechanism = mechanism
+        self.eqcids = ids
+        self.goals, self.P, self.I, self.D = vec(goals), vec(P), vec(I), vec(D)
+        for e in ids:
+            assert len(mechanism.geteqconstraint(e)) == 5, "Only 1 DOF joints are supported"      # pid.jl:20,36
+        self.joints = [mechanism.joint_index(e) for e in ids]
+
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
+        return _capi.CtrlHandle(dev, [], K=None, N=0, fric=fric, noise_scale=noise_scale,
+                                pid=dict(joint=self.joints, P=self.P, I=self.I, D=self.D, goal=self.goals))
 
 
 def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None):

@@ -352,3 +352,43 @@ def mechanism_from_urdf_tables(tab, floating=False, g=-9.81, dt=0.01):
     for e in mech.eqconstraints:      # zero pose, root to leaf
         setJointPosition(mech, e, 0.0)
     return mech
+
+
+def minimal_to_maximal(mech, eqcids, xθ, vω):
+    """Maximal-coordinate setpoint (xd, vd, qd, ωd per body) from joint coordinates xθ and joint rates vω of the 1-DoF joints
+    `eqcids` (one per body) — what the 6-argument linearsystem returns besides A, Bu, Bλ, G (lqr.jl:80).  Forward kinematics root
+    to leaf; velocities by rigid-body kinematics (ω in the body frame, v of the COM in the world frame)."""
+    nb = len(mech.bodies)
+    coord = {int(e): (float(x), float(v)) for e, x, v in zip(eqcids, xθ, vω)}
+    saved = mech.state()
+    vel = {mech.origin.id: (np.zeros(3), np.zeros(3))}           # body id -> (v world, ω world)
+    todo = list(mech.eqconstraints)
+    while todo:
+        progressed = False
+        for e in list(todo):
+            j = e.joint
+            if j.body1.id not in vel:
+                continue
+            θ, θd = coord.get(e.id, (0.0, 0.0))
+            setJointPosition(mech, e, θ)
+            a, b = j.body1, j.body2
+            va, wa = vel[a.id]
+            qa, xa = a.state.qc, a.state.xc
+            axis_w = vrotate(j.axis / np.linalg.norm(j.axis), qa)
+            pj = xa + vrotate(j.p1, qa)                              # joint vertex in the world (parent side)
+            if j.kind == REVOLUTE:
+                wb = wa + axis_w * θd
+                vb = va + np.cross(wa, pj - xa) + np.cross(wb, b.state.xc - pj)
+            else:
+                wb = wa
+                vb = va + np.cross(wa, b.state.xc - xa) + axis_w * θd
+            vel[b.id] = (vb, wb)
+            b.state.vc = vb
+            b.state.ωc = vrotate(wb, qconj(b.state.qc))             # body frame
+            todo.remove(e)
+            progressed = True
+        if not progressed:
+            raise ValueError("joints do not form a tree")
+    z = mech.state()
+    mech.set_state(saved)
+    return ([z[i, 0:3] for i in range(nb)], [z[i, 7:10] for i in range(nb)], [z[i, 3:7] for i in range(nb)], [z[i, 10:13] for i in range(nb)])

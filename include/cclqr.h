@@ -60,6 +60,11 @@ typedef struct {
     const double *Fd;          /* [nsp][mu]  Fτd (lqr.jl:12, lqr_tracking.jl:12) */
     const double *fric;        /* [ne] viscous joint friction of examples/trackingLQR_triple_cartpole.jl:98-101, or NULL */
     double noise_scale;        /* cart noise amplitude, same file :98 (`randn()*2`); 0 = none */
+    /* PID{T,N} (src/control/pid.jl:3-40) on 1-DoF joints in minimal coordinates; control_pid! (pid.jl:69-88) runs every step.
+     * The integrated / last errors live for one launch (start a rollout with k0 = 1). npid = 0: none. */
+    int32_t npid;
+    const int32_t *pid_joint;  /* [npid] joint indices (eqcids) */
+    const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid]  P, I, D, goals (pid.jl:4-9) */
 } cclqr_ctrl_desc;
 
 typedef struct cclqr_mech cclqr_mech; /* opaque: device-resident mechanism tables */
@@ -70,7 +75,7 @@ int cclqr_version(void);
 int cclqr_device_count(int32_t *n);
 int cclqr_set_device(int32_t dev);
 
-/* Mechanism(...) constructor: validates the topology, orders links breadth-first, uploads the tables. */
+/* Mechanism(...) constructor: validates the topology, orders links chain by chain, uploads the tables. */
 int cclqr_mech_create(const cclqr_mech_desc *desc, cclqr_mech **out);
 int cclqr_mech_destroy(cclqr_mech *m);
 

@@ -29,6 +29,8 @@ struct CtrlDesc            # cclqr_ctrl_desc
     nK::Int32; N::Int32; K::Ptr{Float64}
     nsp::Int32; zd::Ptr{Float64}; Fd::Ptr{Float64}
     fric::Ptr{Float64}; noise_scale::Float64
+    npid::Int32; pid_joint::Ptr{Int32}
+    pid_P::Ptr{Float64}; pid_I::Ptr{Float64}; pid_D::Ptr{Float64}; pid_goal::Ptr{Float64}     # PID{T,N}, src/control/pid.jl:3-11
 end
 
 const REVOLUTE = Int32(0)
@@ -133,7 +135,8 @@ function CtrlHandle(h::MechHandle, ctrl::Vector{Int32}, K::Array{Float64,3}, N::
     c = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve ctrl K zd Fd fric begin
         d = CtrlDesc(length(ctrl), pointer(ctrl), size(K, 3), N, pointer(K), size(zd, 3), pointer(zd), pointer(Fd),
-                     fric === nothing ? Ptr{Float64}(C_NULL) : pointer(fric), noise_scale)
+                     fric === nothing ? Ptr{Float64}(C_NULL) : pointer(fric), noise_scale,
+                     0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))
         check(ccall((:cclqr_ctrl_create, lib), Cint, (Ptr{Cvoid}, Ref{CtrlDesc}, Ref{Ptr{Cvoid}}), h.ptr, d, c))
     end
     obj = CtrlHandle(c[])

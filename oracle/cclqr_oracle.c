@@ -659,6 +659,44 @@ void orc_step_fixed_lambda(const orc_mech_desc *d, const double *z, const double
     free(W);
 }
 
+/* minimalCoordinates(mechanism, eqc)[1]: Revolute -> angle of qa^-1 qb qoff^-1 about the axis, Prismatic -> offset along the axis */
+static double joint_coordinate(const mech_t *M, int j, const double *z) {
+    int a = M->parent[j], b = M->child[j];
+    const double *xa = a >= 0 ? z + 13 * a : X0, *qa = a >= 0 ? z + 13 * a + 3 : QID;
+    const double *xb = z + 13 * b, *qb = z + 13 * b + 3;
+    if (M->type[j] == ORC_REVOLUTE) {
+        double qac[4], qoc[4], t[4], e[4];
+        qconj(qa, qac); qconj(M->qoff[j], qoc);
+        qmul(qac, qb, t); qmul(t, qoc, e);
+        return 2.0 * atan2(M->ax[j][0] * e[1] + M->ax[j][1] * e[2] + M->ax[j][2] * e[3], e[0]);
+    }
+    double Ra[9], Rb[9], rp[3], w[3], gT[3];
+    rotmat(qa, Ra); rotmat(qb, Rb);
+    mat3vec(Rb, M->p2[j], rp);
+    for (int i = 0; i < 3; i++) w[i] = xb[i] + rp[i] - xa[i];
+    mat3Tvec(Ra, w, gT);
+    return M->ax[j][0] * (gT[0] - M->p1[j][0]) + M->ax[j][1] * (gT[1] - M->p1[j][1]) + M->ax[j][2] * (gT[2] - M->p1[j][2]);
+}
+void orc_minimal_coordinates(const orc_mech_desc *d, const double *z, double *theta) {
+    mech_t M;
+    if (mech_build(d, &M)) return;
+    for (int j = 0; j < M.ne; j++) theta[j] = joint_coordinate(&M, j, z);
+}
+/* control_pid!(mechanism, pid, k), pid.jl:69-88; integ/last = integratederrors / lasterrors of this instance */
+static void pid_core(const mech_t *M, const orc_ctrl_desc *c, const double *z, int k, double *integ, double *last, double *uj) {
+    const double PI = 3.14159265358979323846;
+    for (int i = 0; i < c->npid; i++) {
+        int j = c->pid_joint[i];
+        double e = c->pid_goal[i] - joint_coordinate(M, j, z);            /* stateError_pid, pid.jl:43-57 */
+        if (M->type[j] == ORC_REVOLUTE) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
+        if (k == 1) last[i] = e;                                            /* pid.jl:73 */
+        integ[i] += e * M->dt;                                              /* pid.jl:76 */
+        double de = (e - last[i]) / M->dt;                                  /* pid.jl:77 */
+        uj[j] += c->pid_P[i] * e + c->pid_I[i] * integ[i] + c->pid_D[i] * de; /* pid.jl:79 */
+        last[i] = e;                                                        /* pid.jl:81 */
+    }
+}
+
 /* ------------------------------------------------------------------ feedback law */
 /* lqr.jl:89-139 / lqr_tracking.jl:46-71 / trackingLQR_triple_cartpole.jl:76-115 */
 static void control_core(const mech_t *M, const orc_ctrl_desc *c, const double *z, int k, double noise_sample, double *uj) {
@@ -738,7 +776,8 @@ int orc_rollout(const orc_mech_desc *d, const orc_ctrl_desc *c, int64_t n_inst, 
         work_t *W = (work_t *)malloc(sizeof(work_t));
 #pragma omp for schedule(dynamic, 1)
         for (int64_t n = 0; n < n_inst; n++) {
-            double z[13 * MAXB], lam[5 * MAXB], uj[MAXB];
+            double z[13 * MAXB], lam[5 * MAXB], uj[MAXB], pid_integ[MAXB], pid_last[MAXB];
+            memset(pid_integ, 0, sizeof pid_integ); memset(pid_last, 0, sizeof pid_last);
             memcpy(z, z0 + n * nz, sizeof(double) * nz);
             memset(lam, 0, sizeof lam);
             int worst = 0, bad = 0;
@@ -746,6 +785,7 @@ int orc_rollout(const orc_mech_desc *d, const orc_ctrl_desc *c, int64_t n_inst, 
                 if (traj) memcpy(traj + ((size_t)n * steps + (k - 1)) * nz, z, sizeof(double) * nz);
                 double ns = (c->noise && c->noise_scale != 0.0) ? c->noise[(size_t)n * steps + (k - 1)] : 0.0;
                 control_core(&M, c, z, k, ns, uj);
+                if (c->npid > 0) pid_core(&M, c, z, k, pid_integ, pid_last, uj);
                 int it = step_core(&M, z, lam, uj, W, 0);
                 if (it < 0) { bad = 1; it = -it; }
                 if (it > worst) worst = it;

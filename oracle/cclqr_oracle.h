@@ -62,6 +62,11 @@ typedef struct {
     const double *Fd;          /* [nsp][mu] feed-forward */
     const double *fric;        /* [ne] viscous joint friction (trackingLQR_triple_cartpole.jl:98-101) or NULL */
     double noise_scale;        /* multiplies noise[] on every controlled joint (same file :98) */
+    /* PID{T,N} on 1-DoF joints in minimal coordinates, src/control/pid.jl:3-88 (npid = 0: none) */
+    int32_t npid;
+    const int32_t *pid_joint;  /* [npid] joint indices */
+    const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid] */
+    /* (fields above = cclqr_ctrl_desc; the injected noise array is oracle-only and therefore last) */
     const double *noise;       /* [n_inst][steps] injected standard-normal samples or NULL */
 } orc_ctrl_desc;
 
@@ -74,6 +79,9 @@ void orc_step_fixed_lambda(const orc_mech_desc *m, const double *z, const double
 
 /* constraint values g (5*ne) at state z */
 void orc_constraints(const orc_mech_desc *m, const double *z, double *g);
+
+/* minimalCoordinates(mechanism, eqc)[1] of every joint (angle about / offset along the joint axis), pid.jl:45,55 */
+void orc_minimal_coordinates(const orc_mech_desc *m, const double *z, double *theta);
 
 /* feedback law: writes uj[ne] for step k (1-based) */
 void orc_control(const orc_mech_desc *m, const orc_ctrl_desc *c, const double *z, int k, double noise_sample, double *uj);

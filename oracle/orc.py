@@ -23,7 +23,8 @@ class MechDesc(C.Structure):
 
 class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
-                ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double), ("noise", _dp)]
+                ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
+                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp), ("noise", _dp)]
 
 
 def build(force=False):
@@ -85,7 +86,8 @@ def mech_desc(t):
     return _Keep(d, arrs)
 
 
-def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None):
+def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None, pid=None):
+    """pid = dict(joint=[...], P=[...], I=[...], D=[...], goal=[...]) adds a PID law (pid.jl) on those joints"""
     cj = _i32(ctrl_joint)
     mu = len(cj)
     K = _f64(K)
@@ -93,7 +95,12 @@ def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_sc
     Fd = _f64(Fd if Fd is not None else np.zeros((zd.shape[0], mu))).reshape(zd.shape[0], mu)
     nK = 0 if K is None else K.reshape(-1, mu, 12 * nb).shape[0]
     arrs = dict(cj=cj, K=K, zd=zd, Fd=Fd, fric=_f64(fric), noise=_f64(noise))
-    d = CtrlDesc(mu, _i(cj), nK, int(N), _d(K), zd.shape[0], _d(zd), _d(Fd), _d(arrs["fric"]), float(noise_scale), _d(arrs["noise"]))
+    npid = 0
+    if pid is not None:
+        arrs.update(pj=_i32(pid["joint"]), pP=_f64(pid["P"]), pI=_f64(pid["I"]), pD=_f64(pid["D"]), pg=_f64(pid["goal"]))
+        npid = len(arrs["pj"])
+    d = CtrlDesc(mu, _i(cj), nK, int(N), _d(K), zd.shape[0], _d(zd), _d(Fd), _d(arrs["fric"]), float(noise_scale),
+                 npid, _i(arrs.get("pj")), _d(arrs.get("pP")), _d(arrs.get("pI")), _d(arrs.get("pD")), _d(arrs.get("pg")), _d(arrs["noise"]))
     return _Keep(d, arrs)
 
 
@@ -125,6 +132,13 @@ def constraints(t, z):
     g = np.zeros(5 * t.ne)
     lib().orc_constraints(C.byref(m.desc), _d(_f64(z)), _d(g))
     return g
+
+
+def minimal_coordinates(t, z):
+    m = mech_desc(t)
+    th = np.zeros(t.ne)
+    lib().orc_minimal_coordinates(C.byref(m.desc), _d(_f64(z)), _d(th))
+    return th
 
 
 def control(t, ctrl, z, k, noise_sample=0.0):

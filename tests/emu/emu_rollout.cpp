@@ -104,6 +104,7 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     if (noise && C->noise_scale != 0.0) u += C->noise_scale * noise[(size_t)inst * steps + (k - k0)];
                     L[Y.UJ + C->cj[i]] += u;
                 }
+            if (C->has_pid) for (int t = 0; t < G; t++) ph_pid(t, nb, Y, L, R[t], C, dt, k == 1);
             for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
             for (int t = 0; t < G; t++) ph_force_map(t, G, nb, Y, L, M->end_mask);
             bool done = false;

@@ -172,3 +172,16 @@ def test_emulated_two_chains(cclqr, orc, emu):
     _, traj, st = emu_rollout(emu, orc, t2, c, z0, 30)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-10
+
+
+def test_emulated_pid(cclqr, orc, emu):
+    """control_pid! (pid.jl:69-88) as a device law: cart + double pendulum, all three joints under PID"""
+    ex = cclqr.examples.cartpole_n(2)
+    t = ex["mech"].tables()
+    z0 = cclqr.examples.cartpole_states(2, [0.1, -0.2], [[0.3, -0.2], [3.0, 0.4]])
+    pid = dict(joint=[0, 1, 2], P=[20.0, 30.0, 15.0], I=[5.0, 10.0, 2.0], D=[4.0, 6.0, 1.5], goal=[0.0, 0.4, -3.0])
+    c = orc.ctrl_desc(3, [], K=None, N=0, pid=pid)
+    _, traj_o, st_o = orc.rollout(t, c, z0, 120, record=True)
+    _, traj, st = emu_rollout(emu, orc, t, c, z0, 120)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10

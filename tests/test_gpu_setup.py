@@ -194,3 +194,34 @@ def test_sawyer_config4_pipeline(cclqr, orc):
     _, traj, sto = orc.rollout(t, oc, z0, 150, record=True)
     assert (st.status > 0).all() and (sto > 0).all()
     assert np.abs(st.z - traj).max() < 1e-9
+
+
+def test_minimal_coordinate_lqr_prismatic(cclqr, orc):
+    """examples/lqr_prismatic.jl: LQR(mech, getid.(constraints), getid.(constraints), Q::Vector, R::Vector, 10.)  (lqr.jl:68-86)"""
+    ex = cclqr.examples.prismatic_slider()
+    mech = ex["mech"]
+    ids = [cclqr.getid(j) for j in ex["joints"]]
+    lqr = cclqr.LQR(mech, ids, ids, ex["Q"], ex["R"], 10.0)
+    assert lqr.K.shape == (999, 1, 12) and np.allclose(lqr.zd[0, 0, 0:3], 0) and np.allclose(lqr.Q, np.eye(12) * 0.01)
+    z0 = mech.state()
+    st = cclqr.simulate(mech, 10.0, lqr)
+    assert abs(st.zT[0, 0, 0]) < 1e-2 and abs(st.z[0, 0, 0, 0] - 1.0) < 1e-12          # slides from x = 1 to the setpoint
+    t = mech.tables()
+    oc = orc.ctrl_desc(1, [0], K=lqr.K, N=lqr.N, zd=lqr.zd)
+    _, traj, _ = orc.rollout(t, oc, z0[None], 1000, record=True)
+    assert np.abs(st.z - traj).max() < 1e-9
+
+
+def test_pid_controller(cclqr, orc):
+    """examples/pid_pendulum.jl through the mirror: PID(mech, joint.id, pi/2, P=10, I=10, D=5); batch of start angles"""
+    ex = cclqr.examples.pendulum(θ0=0.0)
+    mech = ex["mech"]
+    pid = cclqr.PID(mech, cclqr.getid(ex["joints"][0]), np.pi / 2, P=10.0, I=10.0, D=5.0)
+    z0 = np.stack([cclqr.examples.pendulum(θ0=a)["mech"].state() for a in (0.0, 0.5, -1.0, 3.0, -3.0)])
+    st = cclqr.simulate(mech, 10.0, pid, z0=z0)
+    t = mech.tables()
+    oc = orc.ctrl_desc(1, [], K=None, N=0, pid=dict(joint=[0], P=[10.0], I=[10.0], D=[5.0], goal=[np.pi / 2]))
+    zo, traj, sto = orc.rollout(t, oc, z0, 1000, record=True)
+    assert (st.status > 0).all() and (sto > 0).all()
+    assert np.abs(st.z - traj).max() < 1e-9
+    assert all(abs(np.angle(np.exp(1j * (orc.minimal_coordinates(t, st.zT[i])[0] - np.pi / 2)))) < 1e-2 for i in range(5))   # modulo 2π

@@ -159,3 +159,26 @@ def test_sawyer_fixture_matches_reference_urdf_when_present(cclqr):
         assert cclqr.parse_urdf(ref) == tab
     ex = cclqr.examples.sawyer(tab)
     assert len(ex["mech"].bodies) == 7 and ex["mech"].tables().ml == 35      # Nb = 7, mλ = 35
+
+
+def test_minimal_to_maximal_kinematics(cclqr, orc):
+    """6-argument linearsystem's setpoint conversion (lqr.jl:80): joint coordinates/rates -> consistent maximal state"""
+    ex = cclqr.examples.cartpole_n(3)
+    mech = ex["mech"]
+    ids = [cclqr.getid(j) for j in ex["joints"]]
+    θ = np.array([0.3, 0.2, -0.4, 0.1])
+    θd = np.array([0.5, -1.0, 0.7, 0.2])
+    xd, vd, qd, ωd = cclqr.minimal_to_maximal(mech, ids, θ, θd)
+    t = mech.tables()
+    z = np.zeros((4, 13))
+    for i in range(4):
+        z[i, 0:3], z[i, 3:7], z[i, 7:10], z[i, 10:13] = xd[i], qd[i], vd[i], ωd[i]
+    assert np.abs(orc.constraints(t, z)).max() < 1e-14
+    assert np.allclose(z, np.concatenate([cclqr.examples.cartpole_states(3, [0.3], [[0.2, -0.4, 0.1]])[0][:, :7], z[:, 7:]], axis=1))
+    # velocities are the time derivative of the forward kinematics
+    h = 1e-6
+    xp = cclqr.minimal_to_maximal(mech, ids, θ + h * θd, θd)[0]
+    xm = cclqr.minimal_to_maximal(mech, ids, θ - h * θd, θd)[0]
+    for i in range(4):
+        assert np.allclose((xp[i] - xm[i]) / (2 * h), vd[i], atol=1e-8)
+    assert np.allclose(ωd[1], [θd[1], 0, 0]) and np.allclose(ωd[3], [θd[1] + θd[2] + θd[3], 0, 0])

@@ -224,3 +224,24 @@ def test_reference_constants_and_quirks(cclqr, orc):
     assert abs(u[0] - (-0.1 * 0.2 + 2.0 * 0.25)) < 1e-12       # cart: -0.1 v_y + 2 randn
     assert abs(u[1] - (-0.1 * 0.4)) < 1e-12                    # pole: -0.1 (omega_x - 0)
     assert np.all(orc.control(t, cf, z, 5, noise_sample=0.25) == 0.0)
+
+
+def test_pid_pendulum_reaches_goal(cclqr, orc):
+    """examples/pid_pendulum.jl:28-34: PID(mech, joint.id, pi/2, P = 10., I = 10., D = 5.), simulate!(mech, 10., pid): the
+    integral term holds the pendulum at the goal against gravity.  Also pins minimalCoordinates (pid.jl:45,55) and the wrap."""
+    ex = cclqr.examples.pendulum(θ0=0.0)
+    t = ex["mech"].tables()
+    z0 = ex["mech"].state()
+    assert abs(orc.minimal_coordinates(t, z0)[0]) < 1e-15
+    for θ in (0.3, -2.5, 3.0):
+        assert abs(orc.minimal_coordinates(t, cclqr.examples.pendulum(θ0=θ)["mech"].state())[0] - θ) < 1e-14
+    c = orc.ctrl_desc(1, [], K=None, N=0, pid=dict(joint=[0], P=[10.0], I=[10.0], D=[5.0], goal=[np.pi / 2]))
+    zT, traj, st = orc.rollout(t, c, z0[None], 1000, record=True)
+    assert (st > 0).all()
+    assert abs(orc.minimal_coordinates(t, zT[0])[0] - np.pi / 2) < 1e-3 and np.abs(zT[0, 0, 10:13]).max() < 1e-2
+    # first step: derivative term is zero (lasterrors = currenterrors at k == 1, pid.jl:73) -> u = P e + I e dt
+    z1, _, _ = orc.step(t, z0, np.zeros(5), np.array([10.0 * np.pi / 2 + 10.0 * np.pi / 2 * 0.01]))
+    assert np.abs(z1 - traj[0, 1]).max() < 1e-13
+    # prismatic coordinate
+    exs = cclqr.examples.prismatic_slider()
+    assert abs(orc.minimal_coordinates(exs["mech"].tables(), exs["mech"].state())[0] - 1.0) < 1e-15
