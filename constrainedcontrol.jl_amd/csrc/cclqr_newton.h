@@ -84,7 +84,7 @@ template <int G>
 __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt, bool valid,
                                             bool* converged PROF_ARG) {
     double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
-    bool done = !valid;
+    bool done = !valid, failed = false;
     int its = 0;
     const unsigned smask = M->start_mask, emask = M->end_mask;
     const int nchains = M->nchains;
@@ -147,6 +147,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
             { int q = s_cur; s_cur = s_try; s_try = q; q = l_cur; l_cur = l_try; l_try = q; }
             its = iter;
             if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
+            if (!(normf1 < 1e300)) { done = true; failed = true; }   // non-finite residual: the instance has left the domain of the integrator
             normf0 = normf1;
             need_jac = !done && !jac_ok;
         }
@@ -156,7 +157,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
     }
     ph_copy_solution(t, G, nb, Y, L, s_cur, l_cur);
     __syncthreads();
-    *converged = done;
+    *converged = done && !failed;
     return its;
 }
 

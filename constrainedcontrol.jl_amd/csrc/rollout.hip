@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     __syncthreads();
 
     int worst = 0;
-    bool bad = false;
+    bool bad = false, dead = false;    // dead: a step produced a non-finite residual; the instance is frozen from then on
     for (int kk = 0; kk < a.steps; kk++) {
         const int k = a.k0 + kk;
         if (a.traj && valid)
@@ -84,9 +84,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool done = false;
-        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid, &done PROF_PASS);
-        if (valid) { if (!done) bad = true; if (its > worst) worst = its; }
-        if (valid) ph_update(t, nb, Y, L);
+        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid && !dead, &done PROF_PASS);
+        if (valid && !dead) {
+            if (!done) bad = true;
+            if (its > worst) worst = its;
+            if (!done && its < NEWTON_MAXIT) dead = true;   // stopped early on a non-finite residual
+            else ph_update(t, nb, Y, L);
+        }
         __syncthreads();
     }
     if (valid) {

@@ -91,3 +91,25 @@ def test_ragged_and_empty_batches(cclqr):
     assert empty.shape == (0, 2, 13)
     same, _, _ = capi.rollout(mech, ctrl, z0, 0)  # zero steps: state passes through
     assert np.array_equal(same, z0)
+
+
+def test_diverging_instances_are_flagged_not_ground_through(cclqr):
+    """an ill-posed controller (huge random gains on a 13-body upright chain) drives instances out of the integrator's domain:
+    they must come back flagged (status < 0) quickly instead of spending 100 Newton iterations on every remaining step"""
+    import time
+    capi = cclqr._capi
+    n_links = 12
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = np.zeros((n_links + 1, 13))
+    zd[:, 3] = 1
+    zd[1:, 2] = np.arange(n_links) + 0.5
+    rng = np.random.default_rng(0)
+    K = rng.normal(size=(999, 1, 12 * t.nb)) * 1e6
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, 256), rng.uniform(-0.1, 0.1, (256, n_links)))
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=1000, zd=zd)
+    t0 = time.time()
+    zT, _, st = capi.rollout(mech, ctrl, z0, 1000)
+    assert time.time() - t0 < 20.0
+    assert (st < 0).all()
