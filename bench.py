@@ -58,17 +58,22 @@ def main():
     ap.add_argument("--no-record", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="rehearsal of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collective runs over gloo "
+                         "(RCCL refuses two ranks on one device); the JSON line is marked and is not a scaling measurement")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     pkg = graft.load_package()
     capi = pkg._capi
-    rank, world, local = pkg.dist.init_from_env()
+    rank, world, local = pkg.dist.init_from_env(backend="gloo" if args.rehearse_shared_gpu else None)
     if world != args.gpus and world > 1:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
+    if args.rehearse_shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     capi.set_device(local)
     dev = torch.device("cuda", local)
@@ -135,13 +140,16 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            if tj.get("config") == {"links": n_links, "instances_per_gpu": n_inst, "sim_steps": T, "record": record}:
+                traffic = tj.get("hbm_bytes_per_launch")      # PMC-measured for exactly this launch shape (profiles/README.md)
         except Exception:
             traffic = None
     out = {
         "metric": "LQR sim steps/sec (whole node) on N-link cartpole batch", "value": value, "unit": "instance-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "rehearsal_shared_gpu": bool(args.rehearse_shared_gpu),
         "config": {"workload": "lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, "
                                "y0~U(-0.5,0.5) phi_i~U(-0.2,0.2)" % (n_links, nb, T * t.dt),
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,

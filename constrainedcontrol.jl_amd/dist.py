@@ -50,11 +50,14 @@ def gather_to_root(local, n_total, rank, world, dst=0):
         pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
     pad = pad.contiguous()
+    dev = pad.device
+    if dist.get_backend() == "gloo" and pad.is_cuda:
+        pad = pad.cpu()          # gloo rehearsal of the GPU path: the collective itself runs on host buffers
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0).to(dev)
 
 
 def max_over_ranks(value, device=None):
@@ -62,7 +65,7 @@ def max_over_ranks(value, device=None):
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
