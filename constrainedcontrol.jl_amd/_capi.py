@@ -39,12 +39,33 @@ class CtrlDesc(C.Structure):
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and links it by the name
+    `libamdhip64.so`; libcclqr.so needs `libamdhip64.so.7`.  If libcclqr.so is loaded first the system copy comes in, torch later
+    adds its bundled copy, and the second runtime reports `no ROCm-capable device`.  Loading torch's copy first (when torch is
+    installed; torch itself is NOT imported) makes both resolve to the same runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """load libcclqr.so; raises if it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)"""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libcclqr.so is missing at %s: the HIP extension must be built (no CPU fallback exists)" % LIB_PATH)
+        _preload_shared_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.cclqr_last_error.restype = C.c_char_p
         for name in EXPORTS[1:]:

@@ -64,3 +64,38 @@ def test_tracking_friction_noise(cclqr, orc):
     zT, traj, st = capi.rollout(mech, ctrl, z0, N, noise=noise, record=True)
     assert (st > 0).all()
     assert np.abs(traj - traj_o).max() < TOL
+
+
+def test_chained_device_launches_equal_one_launch(cclqr, orc):
+    """step-per-launch / MPC-style use of cclqr_rollout_dev: state and multipliers round-trip HBM between launches (k0 continuation);
+    40 + 1 + 59 steps in three launches == 100 steps in one launch, bit for bit, on device pointers and a non-default stream"""
+    import torch
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(3)
+    t = ex["mech"].tables()
+    zd = upright_setpoint(3)
+    K = _gains(orc, ex, t, zd, N=150)
+    rng = np.random.default_rng(5)
+    n = 37
+    z0 = cclqr.examples.cartpole_states(3, rng.uniform(-0.5, 0.5, n), rng.uniform(-1, 1, (n, 3)) * 0.01)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=150, zd=zd)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        z0_d = torch.from_numpy(z0).to(dev)
+        one = torch.empty_like(z0_d)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        traj = torch.empty((n, 100, t.nb, 13), dtype=torch.float64, device=dev)
+        capi.rollout_dev(mech, ctrl, n, 100, 1, z0_d.data_ptr(), 0, 0, 0, traj.data_ptr(), one.data_ptr(), st.data_ptr(), stream.cuda_stream)
+        lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+        a, b, c = torch.empty_like(z0_d), torch.empty_like(z0_d), torch.empty_like(z0_d)
+        capi.rollout_dev(mech, ctrl, n, 40, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr(), stream.cuda_stream)
+        capi.rollout_dev(mech, ctrl, n, 1, 41, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr(), stream.cuda_stream)
+        capi.rollout_dev(mech, ctrl, n, 59, 42, b.data_ptr(), lam.data_ptr(), 0, 0, 0, c.data_ptr(), st.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert torch.equal(c, one)
+    assert torch.equal(a, traj[:, 40]) and torch.equal(b, traj[:, 41])
+    octrl = orc.ctrl_desc(t.nb, [0], K=K, N=150, zd=zd)
+    zo, _, _ = orc.rollout(t, octrl, z0, 100)
+    assert np.abs(one.cpu().numpy() - zo).max() < TOL
