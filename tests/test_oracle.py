@@ -245,3 +245,33 @@ def test_pid_pendulum_reaches_goal(cclqr, orc):
     # prismatic coordinate
     exs = cclqr.examples.prismatic_slider()
     assert abs(orc.minimal_coordinates(exs["mech"].tables(), exs["mech"].state())[0] - 1.0) < 1e-15
+
+
+def test_upright_long_chain_is_ill_posed_in_the_reference_algorithm(cclqr, orc):
+    """Evidence for DESIGN.md 'Workloads': with the script's upright setpoint (examples/lqr_cartpole_n_pendulum.jl:45-50) the
+    reference's own recursion (lqr.jl:141-184, restated line by line) produces gains that grow by orders of magnitude per added
+    link, and fp64 rollouts from the script's initial-condition range diverge; the hanging equilibrium of the same mechanism is
+    well-posed.  (N = 12 here keeps the CPU recursion short; N = 16 gives |K| ~ 8.7e10.)"""
+    kmax = {}
+    for n in (3, 6, 12):
+        ex = cclqr.examples.cartpole_n(n)
+        t = ex["mech"].tables()
+        zd = upright_setpoint(n)
+        A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
+        N = 1000 if n < 12 else 300
+        K, kb = orc.riccati(A, Bu, Bl, G, sl.block_diag(*ex["Q"]) * t.dt, sl.block_diag(*ex["R"]) * t.dt, N)
+        kmax[n] = np.abs(K[0]).max()
+    assert kmax[3] < 1e4 and kmax[6] > 1e4 and kmax[12] > 1e7
+    ctrl = orc.ctrl_desc(t.nb, [0], K=K, N=300, zd=zd)
+    z0 = cclqr.examples.cartpole_states(12, [0.5], np.full((1, 12), 1e-4))   # 0.0057 degrees per joint
+    _, _, st = orc.rollout(t, ctrl, z0, 299)
+    assert st[0] < 0                                           # Newton hits its cap / leaves the domain: the rollout is lost
+    # same mechanism about the hanging equilibrium: modest gains, every step converges
+    zh = cclqr.examples.cartpole_states(12, [0.0], np.array([[np.pi] + [0.0] * 11]))[0]
+    A, Bu, Bl, G = orc.linearize(t, zh, [0], np.zeros(1))
+    Kh, _ = orc.riccati(A, Bu, Bl, G, sl.block_diag(*ex["Q"]) * t.dt, sl.block_diag(*ex["R"]) * t.dt, 120)
+    assert np.abs(Kh).max() < 100
+    phi = np.full((1, 12), 0.1)
+    phi[0, 0] += np.pi
+    _, _, sth = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=Kh, N=120, zd=zh), cclqr.examples.cartpole_states(12, [0.5], phi), 119)
+    assert sth[0] > 0
