@@ -139,7 +139,7 @@ HD double fast_rcp(double x) {
 }
 HD void inv3(const double* A, double* Ai) {
     double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
-    double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
+    double id = fast_rcp(A[0] * c0 + A[1] * c1 + A[2] * c2);
     Ai[0] = c0 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Ai[3] = c1 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
@@ -374,7 +374,7 @@ HD void ph_knot_jac(int t, int nb, const Lay& Y, double* L, const LaneRegs& r) {
 
 // N(w) = (dt^2/4)(sq I - [w]x + w w'/sq):  d phi+ = N d w+
 HD void make_N(const double* w2, double sq2, double dt, double* N) {
-    double k = 0.25 * dt * dt, isq = 1.0 / sq2;
+    double k = 0.25 * dt * dt, isq = fast_rcp(sq2);
     N[0] = k * (sq2 + w2[0] * w2[0] * isq); N[1] = k * (w2[2] + w2[0] * w2[1] * isq);  N[2] = k * (-w2[1] + w2[0] * w2[2] * isq);
     N[3] = k * (-w2[2] + w2[1] * w2[0] * isq); N[4] = k * (sq2 + w2[1] * w2[1] * isq); N[5] = k * (w2[0] + w2[1] * w2[2] * isq);
     N[6] = k * (w2[1] + w2[2] * w2[0] * isq);  N[7] = k * (-w2[0] + w2[2] * w2[1] * isq); N[8] = k * (sq2 + w2[2] * w2[2] * isq);
@@ -394,7 +394,8 @@ HD double ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r
     const double* w2 = s + 3;
     double* xq = L + Y.XQ + 7 * t;
     for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
-    double sq2 = sqrt(4.0 / (dt * dt) - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
+    const double inv_dt = fast_rcp(dt), m_dt = r.m * inv_dt;     // one refined reciprocal instead of four IEEE divisions
+    double sq2 = sqrt(4.0 * inv_dt * inv_dt - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
     double wb[4] = {0.5 * dt * sq2, 0.5 * dt * w2[0], 0.5 * dt * w2[1], 0.5 * dt * w2[2]};
     qmul(z + 3, wb, xq + 3);
     double Jw2[3], c2[3];
@@ -402,7 +403,7 @@ HD double ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r
     double* d = L + Y.D + 6 * t;
     double acc = 0.0;
     for (int i = 0; i < 3; i++) {
-        double dT = r.m * s[i] / dt + r.cT[i] - cf[i], dR = sq2 * Jw2[i] + c2[i] + r.cR[i] - cf[3 + i];
+        double dT = m_dt * s[i] + r.cT[i] - cf[i], dR = sq2 * Jw2[i] + c2[i] + r.cR[i] - cf[3 + i];
         d[i] = dT; d[3 + i] = dR;
         acc += dT * dT + dR * dR;
     }
@@ -410,7 +411,7 @@ HD double ph_body_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& r
     // D_R = (sq2 I + [w2]x) J - [J w2]x - (J w2) w2'/sq2
     double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2}, SJ[9], Dr[9], Di[9], N[9];
     mm3(S, r.J, SJ);
-    double isq = 1.0 / sq2;
+    double isq = fast_rcp(sq2);
     double Sj[9] = {0, -Jw2[2], Jw2[1], Jw2[2], 0, -Jw2[0], -Jw2[1], Jw2[0], 0};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Dr[i * 3 + j] = SJ[i * 3 + j] - Sj[i * 3 + j] - Jw2[i] * w2[j] * isq;
