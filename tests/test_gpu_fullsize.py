@@ -113,3 +113,75 @@ def test_diverging_instances_are_flagged_not_ground_through(cclqr):
     zT, _, st = capi.rollout(mech, ctrl, z0, 1000)
     assert time.time() - t0 < 20.0
     assert (st < 0).all()
+
+
+def test_cfg5_tracking_16384_friction_noise(cclqr):
+    """configs[4]: trackingLQR_triple_cartpole.jl, 16384 instances, 1000-step horizon, the script's friction + noise law
+    (examples/trackingLQR_triple_cartpole.jl:93-111) about the swing-up trajectory generated by its open-loop input U."""
+    import os
+    U = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triple_cartpole_U.npy"))
+    ex = cclqr.examples.triple_cartpole()
+    mech = ex["mech"]
+    j1 = ex["ctrl"][0]
+    z00 = mech.state()
+    s0 = cclqr.simulate(mech, cclqr.Storage(1000, 4), cclqr.OpenLoop(mech, [j1.id], U.reshape(1000, 1)))
+    tl = cclqr.TrackingLQR(mech, s0, [[[U[k]]] for k in range(1000)], [j1.id], ex["Q"], ex["R"])
+    n = 16384
+    noise = np.random.default_rng(0xC0FFEE).normal(size=(n, 1000))
+    z0 = np.tile(z00, (n, 1, 1))
+
+    def spread(ctrl, scale):
+        mech.set_state(z00)
+        st = cclqr.simulate(mech, cclqr.Storage(1000, 4), ctrl, record=False, z0=z0, fric=ex["fric"], noise=noise, noise_scale=scale)
+        assert (st.status > 0).all()
+        ang = np.degrees(2 * np.arctan2(st.zT[:, 1:, 4], st.zT[:, 1:, 3]))
+        return st, np.abs((ang - 180 + 180) % 360 - 180)
+
+    st_q, e_quiet = spread(tl, 0.0)
+    assert np.array_equal(st_q.zT, np.tile(st_q.zT[:1], (n, 1, 1)))          # no noise: 16384 identical instances, bit for bit
+    st_t, e_track = spread(tl, 2.0)
+    st_o, e_open = spread(cclqr.OpenLoop(mech, [j1.id], U.reshape(1000, 1)), 2.0)
+    # the tracking law rejects the cart noise: the noise-induced spread of the final pole angles shrinks several-fold
+    assert (e_track.std(axis=0) < 0.35 * e_open.std(axis=0)).all()
+    assert np.percentile(e_track, 90, axis=0).max() < np.percentile(e_open, 90, axis=0).max()
+    assert np.abs(st_t.zT[:, 0, 1]).mean() < np.abs(st_o.zT[:, 0, 1]).mean()
+    assert np.abs(np.linalg.norm(st_t.zT[:, :, 3:7], axis=2) - 1).max() < 1e-11
+
+
+def test_cfg4_sawyer_8192_full_horizon(cclqr, orc):
+    """configs[3]: lqr_sawyer.jl, 8192 instances, horizon 20 s (N = 2000: 1999-step recursion at mx = 84, mu = 7, ml = 35), g = 0,
+    joint angles ~ U(-0.05, 0.05) about the zero pose; every arm is driven back to the setpoint"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    lqr = cclqr.LQR(mech, [cclqr.getid(b) for b in mech.bodies], [cclqr.getid(e) for e in mech.eqconstraints], ex["Q"], ex["R"], 20.0,
+                    xd=ex["xd"], qd=ex["qd"])
+    assert lqr.K.shape == (1999, 7, 84)
+    zd = mech.state()
+    rng = np.random.default_rng(4)
+    base = []
+    for n in range(64):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.05, 0.05))
+        base.append(mech.state())
+    z0 = np.tile(np.stack(base), (128, 1, 1))                                # 8192 instances
+    st = cclqr.simulate(mech, 20.0, lqr, record=False, z0=z0)
+    assert st.steps == 2000
+    ok = st.status > 0
+    # lqr_sawyer.jl:1 "Currently somewhat broken": with the script's weights a fraction of the random starts whips the 0.33 kg wrist
+    # link up to ~100 rad/s and leaves the integrator's domain.  Those instances come back flagged; the oracle loses the same ones.
+    assert 0.5 < ok.mean() < 1.0
+    assert np.array_equal(st.status.reshape(128, 64), np.tile(st.status[:64], (128, 1)))         # deterministic across the tiling
+    assert np.array_equal(st.zT[:64][ok[:64]], st.zT[64:128][ok[:64]])
+    good = st.zT[ok]
+    assert np.abs(good[:, :, 0:3] - zd[None, :, 0:3]).max() < 1e-3 and np.abs(good[:, :, 7:]).max() < 1e-2
+    t = mech.tables()
+    assert max(float(np.abs(orc.constraints(t, g)).max()) for g in good[::997]) < 1e-12
+    bad_i = list(np.where(~ok[:64])[0][:2])
+    good_i = list(np.where(ok[:64])[0][:2])
+    oc = orc.ctrl_desc(7, list(range(7)), K=lqr.K, N=lqr.N, zd=lqr.zd)
+    zo, _, sto = orc.rollout(t, oc, z0[bad_i + good_i], 2000)
+    assert (sto[:2] < 0).all() and (sto[2:] > 0).all()
+    assert np.abs(zo[2:] - st.zT[good_i]).max() < 1e-9
