@@ -15,7 +15,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_geometry"]
+           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset"]
 
 
 class CclqrError(RuntimeError):
@@ -33,7 +33,8 @@ class MechDesc(C.Structure):
 class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
                 ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
-                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp)]
+                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp),
+                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64)]
 
 
 _lib = None
@@ -137,7 +138,7 @@ class MechHandle:
 class CtrlHandle:
     """cclqr_ctrl*: device-resident controller tables"""
 
-    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, pid=None):
+    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, pid=None, noise_seed=None):
         nb = mech.tables.nb
         cj = i32(ctrl_joint).reshape(-1)
         mu = len(cj)
@@ -155,7 +156,8 @@ class CtrlHandle:
         self._arrs = [cj, K, zd, Fd, fric, pj, pP, pI, pD, pg]
         self.mu, self.N, self.nsp = mu, int(N), nsp
         self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0], int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale),
-                             0 if pj is None else len(pj), _i(pj), _d(pP), _d(pI), _d(pD), _d(pg))
+                             0 if pj is None else len(pj), _i(pj), _d(pP), _d(pI), _d(pD), _d(pg),
+                             0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed))
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
 
@@ -183,6 +185,10 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
     check(lib().cclqr_rollout(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
                               _i(status)))
     return zT, traj, status
+
+
+def set_instance_offset(first_instance):
+    check(lib().cclqr_set_instance_offset(C.c_int64(int(first_instance))))
 
 
 def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0):

@@ -52,6 +52,8 @@ struct CtrlDev {
     int has_fric;
     double noise_scale;
     // PID on 1-DoF joints (pid.jl): per link, pid_on[l] != 0
+    int noise_philox;             // 1: counter-based noise (Philox-4x32-10 + Box-Muller), SURVEY 8d
+    unsigned noise_key0;
     int has_pid, pid_on[CCLQR_MAXL];
     double pid_P[CCLQR_MAXL], pid_I[CCLQR_MAXL], pid_D[CCLQR_MAXL], pid_goal[CCLQR_MAXL];
 };
@@ -143,6 +145,24 @@ HD void inv3(const double* A, double* Ai) {
     Ai[0] = c0 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Ai[3] = c1 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// ------------------------------------------------------------------ counter-based standard normal (Philox-4x32-10 + Box-Muller)
+HD void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; r++) {
+        unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+HD double philox_normal(unsigned key0, unsigned long long instance, int k) {
+    unsigned x[4];
+    philox4x32_10((unsigned)(k - 1), 0u, 0u, 0u, key0, (unsigned)instance, x);
+    const double u1 = ((double)x[0] + 0.5) * (1.0 / 4294967296.0), u2 = ((double)x[1] + 0.5) * (1.0 / 4294967296.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
 }
 
 // ------------------------------------------------------------------ link constants -> lane registers

@@ -125,6 +125,8 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
     }
     if (d->fric)
         for (int j = 0; j < nb; j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
+    H.noise_philox = d->noise_philox ? 1 : 0;
+    H.noise_key0 = (unsigned)(d->noise_seed & 0xffffffffu) ^ (unsigned)(d->noise_seed >> 32);
     for (int i = 0; i < d->npid; i++) {
         int j = d->pid_joint ? d->pid_joint[i] : -1;
         if (j < 0 || j >= nb || !d->pid_P || !d->pid_I || !d->pid_D || !d->pid_goal) { err = "PID joint out of range"; return CCLQR_EINVAL; }

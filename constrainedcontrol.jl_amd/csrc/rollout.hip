@@ -62,7 +62,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 double s = group_sum<G>(part);
                 if (t == 0 && valid) {
                     double u = (C->Fd ? C->Fd[(size_t)ksp * C->mu + i] : 0.0) - s;
-                    if (a.noise && C->noise_scale != 0.0) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
+                    if (C->noise_scale != 0.0) {
+                        if (a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
+                        else if (C->noise_philox) u += C->noise_scale * philox_normal(C->noise_key0, (unsigned long long)(a.inst0 + inst), k);
+                    }
                     L[Y.UJ + C->cj[i]] += u;
                 }
                 __syncthreads();

@@ -156,8 +156,8 @@ class LQR(Controller):
                      horizon, Δt)
         return self
 
-    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
-        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0, noise_seed=None):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale, noise_seed=noise_seed)
 
 
 class Storage:
@@ -207,8 +207,8 @@ class TrackingLQR(Controller):
         self.N = N
         self.NK = 12 * nb
 
-    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
-        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0, noise_seed=None):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=self.K, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale, noise_seed=noise_seed)
 
 
 class OpenLoop(Controller):
@@ -227,8 +227,8 @@ class OpenLoop(Controller):
         zd[..., 3] = 1.0
         self.zd = zd
 
-    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
-        return _capi.CtrlHandle(dev, self.ctrl_joints, K=None, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale)
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0, noise_seed=None):
+        return _capi.CtrlHandle(dev, self.ctrl_joints, K=None, N=self.N, zd=self.zd, Fd=self.Fd, fric=fric, noise_scale=noise_scale, noise_seed=noise_seed)
 
 
 class PID(Controller):
@@ -249,16 +249,19 @@ class PID(Controller):
             assert len(mechanism.geteqconstraint(e)) == 5, "Only 1 DOF joints are supported"      # pid.jl:20,36
         self.joints = [mechanism.joint_index(e) for e in ids]
 
-    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0):
-        return _capi.CtrlHandle(dev, [], K=None, N=0, fric=fric, noise_scale=noise_scale,
+    def _ctrl_handle(self, dev, fric=None, noise_scale=0.0, noise_seed=None):
+        return _capi.CtrlHandle(dev, [], K=None, N=0, fric=fric, noise_scale=noise_scale, noise_seed=noise_seed,
                                 pid=dict(joint=self.joints, P=self.P, I=self.I, D=self.D, goal=self.goals))
 
 
-def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None):
+def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None, noise_seed=None,
+             first_instance=0):
     """simulate!(mechanism, tend::Real | storage::Storage, controller; record)  -> Storage
 
     z0 [n_inst][nb][13]: batch of initial states (default: the mechanism's current body states, one instance).
-    fric [ne], noise [n_inst][steps], noise_scale: the friction/noise law of examples/trackingLQR_triple_cartpole.jl:93-111.
+    fric [ne], noise [n_inst][steps] (injected samples) or noise_seed (device-side Philox-4x32 stream per instance), noise_scale:
+    the friction/noise law of examples/trackingLQR_triple_cartpole.jl:93-111.  first_instance: global index of z0[0] when z0 is one
+    rank's shard of a larger batch (the Philox stream of an instance is keyed by its global index).
     After the call the mechanism's bodies hold instance 0's final state (simulate! mutates the mechanism)."""
     if isinstance(tend_or_storage, Storage):
         steps = tend_or_storage.steps
@@ -267,11 +270,15 @@ def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=
     nb = len(mechanism.bodies)
     z0 = mechanism.state()[None] if z0 is None else np.asarray(z0, dtype=np.float64).reshape(-1, nb, 13)
     dev = _device_mech(mechanism)
-    if noise is not None and noise_scale is None:
+    if (noise is not None or noise_seed is not None) and noise_scale is None:
         noise_scale = 1.0
-    ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale)
-    zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record)
-    ctrl.close()
+    ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale, noise_seed=noise_seed)
+    _capi.set_instance_offset(first_instance)
+    try:
+        zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record)
+    finally:
+        _capi.set_instance_offset(0)
+        ctrl.close()
     mechanism.set_state(zT[0])
     if isinstance(tend_or_storage, Storage) and record:
         tend_or_storage.z = traj

@@ -65,6 +65,11 @@ typedef struct {
     int32_t npid;
     const int32_t *pid_joint;  /* [npid] joint indices (eqcids) */
     const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid]  P, I, D, goals (pid.jl:4-9) */
+    /* `randn()` of trackingLQR_triple_cartpole.jl:98,125 as a reproducible counter-based stream: when noise_philox != 0
+     * and no noise array is passed, sample (instance n, step k) = Box-Muller of Philox-4x32-10(counter = (k-1, 0, 0, 0),
+     * key = (noise_seed low 32 bits ^ high 32 bits, n)), times noise_scale. */
+    int32_t noise_philox;
+    uint64_t noise_seed;
 } cclqr_ctrl_desc;
 
 typedef struct cclqr_mech cclqr_mech; /* opaque: device-resident mechanism tables */
@@ -75,11 +80,11 @@ int cclqr_version(void);
 int cclqr_device_count(int32_t *n);
 int cclqr_set_device(int32_t dev);
 
-/* Mechanism(...) constructor: validates the topology, orders links chain by chain, uploads the tables. */
+/* Mechanism(...) constructor (examples/lqr_cartpole.jl:32): validates the topology, orders links chain by chain, uploads the tables. */
 int cclqr_mech_create(const cclqr_mech_desc *desc, cclqr_mech **out);
 int cclqr_mech_destroy(cclqr_mech *m);
 
-/* LQR(...) / TrackingLQR(...) result as a device object consumed by cclqr_rollout*. */
+/* LQR(...) (lqr.jl:17-48) / TrackingLQR(...) (lqr_tracking.jl:17-44) result as a device object consumed by cclqr_rollout*. */
 int cclqr_ctrl_create(const cclqr_mech *m, const cclqr_ctrl_desc *desc, cclqr_ctrl **out);
 int cclqr_ctrl_destroy(cclqr_ctrl *c);
 
@@ -114,6 +119,10 @@ int cclqr_rollout(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int3
 int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0_dev,
                       double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
                       int32_t *status_dev, void *stream);
+
+/* Global index of instance 0 of the following rollout launches of this thread (default 0).  Only matters for noise_philox: the
+ * noise stream of an instance is keyed by its GLOBAL index, so rank r of a sharded batch sets its shard's first index here. */
+int cclqr_set_instance_offset(int64_t first_instance);
 
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py) */
 int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);

@@ -31,6 +31,7 @@ struct CtrlDesc            # cclqr_ctrl_desc
     fric::Ptr{Float64}; noise_scale::Float64
     npid::Int32; pid_joint::Ptr{Int32}
     pid_P::Ptr{Float64}; pid_I::Ptr{Float64}; pid_D::Ptr{Float64}; pid_goal::Ptr{Float64}     # PID{T,N}, src/control/pid.jl:3-11
+    noise_philox::Int32; noise_seed::UInt64                                                    # reproducible stand-in for randn()
 end
 
 const REVOLUTE = Int32(0)
@@ -136,7 +137,7 @@ function CtrlHandle(h::MechHandle, ctrl::Vector{Int32}, K::Array{Float64,3}, N::
     GC.@preserve ctrl K zd Fd fric begin
         d = CtrlDesc(length(ctrl), pointer(ctrl), size(K, 3), N, pointer(K), size(zd, 3), pointer(zd), pointer(Fd),
                      fric === nothing ? Ptr{Float64}(C_NULL) : pointer(fric), noise_scale,
-                     0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))
+                     0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, UInt64(0))
         check(ccall((:cclqr_ctrl_create, lib), Cint, (Ptr{Cvoid}, Ref{CtrlDesc}, Ref{Ptr{Cvoid}}), h.ptr, d, c))
     end
     obj = CtrlHandle(c[])

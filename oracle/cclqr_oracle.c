@@ -697,6 +697,27 @@ static void pid_core(const mech_t *M, const orc_ctrl_desc *c, const double *z, i
     }
 }
 
+/* Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), the counter-based generator SURVEY 8d names */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += W0; k1 += W1;
+    }
+    for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+
+/* standard-normal sample (instance n, step k) of the reproducible noise stream: Box-Muller on the first two words */
+double orc_philox_normal(uint64_t seed, uint64_t instance, int k) {
+    uint32_t ctr[4] = {(uint32_t)(k - 1), 0, 0, 0}, key[2] = {(uint32_t)(seed & 0xffffffffu) ^ (uint32_t)(seed >> 32), (uint32_t)instance}, x[4];
+    orc_philox4x32(ctr, key, x);
+    double u1 = ((double)x[0] + 0.5) / 4294967296.0, u2 = ((double)x[1] + 0.5) / 4294967296.0;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
 /* ------------------------------------------------------------------ feedback law */
 /* lqr.jl:89-139 / lqr_tracking.jl:46-71 / trackingLQR_triple_cartpole.jl:76-115 */
 static void control_core(const mech_t *M, const orc_ctrl_desc *c, const double *z, int k, double noise_sample, double *uj) {
@@ -783,7 +804,11 @@ int orc_rollout(const orc_mech_desc *d, const orc_ctrl_desc *c, int64_t n_inst, 
             int worst = 0, bad = 0;
             for (int k = 1; k <= steps; k++) {
                 if (traj) memcpy(traj + ((size_t)n * steps + (k - 1)) * nz, z, sizeof(double) * nz);
-                double ns = (c->noise && c->noise_scale != 0.0) ? c->noise[(size_t)n * steps + (k - 1)] : 0.0;
+                double ns = 0.0;
+                if (c->noise_scale != 0.0) {
+                    if (c->noise) ns = c->noise[(size_t)n * steps + (k - 1)];
+                    else if (c->noise_philox) ns = orc_philox_normal(c->noise_seed, (uint64_t)n, k);
+                }
                 control_core(&M, c, z, k, ns, uj);
                 if (c->npid > 0) pid_core(&M, c, z, k, pid_integ, pid_last, uj);
                 int it = step_core(&M, z, lam, uj, W, 0);

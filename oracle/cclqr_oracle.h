@@ -66,6 +66,8 @@ typedef struct {
     int32_t npid;
     const int32_t *pid_joint;  /* [npid] joint indices */
     const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid] */
+    int32_t noise_philox;      /* != 0 and noise == NULL: Philox-4x32-10 + Box-Muller stream per instance */
+    uint64_t noise_seed;
     /* (fields above = cclqr_ctrl_desc; the injected noise array is oracle-only and therefore last) */
     const double *noise;       /* [n_inst][steps] injected standard-normal samples or NULL */
 } orc_ctrl_desc;
@@ -103,6 +105,10 @@ int orc_riccati(int32_t mx, int32_t mu, int32_t ml, const double *A, const doubl
 /* dlqr(mechanism, xd,...,N), lqr_tracking.jl:73-122.  zd [N][nb][13], Fd [N][mu], K [N-1][mu][mx] */
 int orc_riccati_tracking(const orc_mech_desc *m, int32_t mu, const int32_t *ctrl_joint, const double *zd, const double *Fd,
                          const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
+
+/* Philox-4x32-10 block function and the standard-normal sample (instance, step k) derived from it (noise_philox above) */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_philox_normal(uint64_t seed, uint64_t instance, int k);
 
 /* flop counter (instrumented build only: -DORC_COUNT_FLOPS), see SURVEY 8d */
 double orc_flops_get(void);

@@ -24,7 +24,8 @@ class MechDesc(C.Structure):
 class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
                 ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
-                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp), ("noise", _dp)]
+                ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp),
+                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64), ("noise", _dp)]
 
 
 def build(force=False):
@@ -86,7 +87,7 @@ def mech_desc(t):
     return _Keep(d, arrs)
 
 
-def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None, pid=None):
+def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None, pid=None, noise_seed=None):
     """pid = dict(joint=[...], P=[...], I=[...], D=[...], goal=[...]) adds a PID law (pid.jl) on those joints"""
     cj = _i32(ctrl_joint)
     mu = len(cj)
@@ -100,7 +101,8 @@ def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_sc
         arrs.update(pj=_i32(pid["joint"]), pP=_f64(pid["P"]), pI=_f64(pid["I"]), pD=_f64(pid["D"]), pg=_f64(pid["goal"]))
         npid = len(arrs["pj"])
     d = CtrlDesc(mu, _i(cj), nK, int(N), _d(K), zd.shape[0], _d(zd), _d(Fd), _d(arrs["fric"]), float(noise_scale),
-                 npid, _i(arrs.get("pj")), _d(arrs.get("pP")), _d(arrs.get("pI")), _d(arrs.get("pD")), _d(arrs.get("pg")), _d(arrs["noise"]))
+                 npid, _i(arrs.get("pj")), _d(arrs.get("pP")), _d(arrs.get("pI")), _d(arrs.get("pD")), _d(arrs.get("pg")),
+                 0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed), _d(arrs["noise"]))
     return _Keep(d, arrs)
 
 
@@ -196,6 +198,20 @@ def riccati_tracking(t, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5):
     if rc != 0:
         raise RuntimeError("orc_riccati_tracking failed: %d" % rc)
     return K, kb.value
+
+
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox4x32(c, k, out)
+    return list(out)
+
+
+def philox_normal(seed, instance, k):
+    L = lib()
+    L.orc_philox_normal.restype = C.c_double
+    return L.orc_philox_normal(C.c_uint64(seed), C.c_uint64(instance), C.c_int(k))
 
 
 def flops_reset():

@@ -101,7 +101,10 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     double s = 0.0;
                     if (C->K) for (int t = 0; t < G; t++) s += ph_gain_partial(t, G, nb, Y, L, C->K + ((size_t)kidx * C->mu + i) * 12 * nb);
                     double u = (C->Fd ? C->Fd[(size_t)ksp * C->mu + i] : 0.0) - s;
-                    if (noise && C->noise_scale != 0.0) u += C->noise_scale * noise[(size_t)inst * steps + (k - k0)];
+                    if (C->noise_scale != 0.0) {
+                        if (noise) u += C->noise_scale * noise[(size_t)inst * steps + (k - k0)];
+                        else if (C->noise_philox) u += C->noise_scale * philox_normal(C->noise_key0, (unsigned long long)inst, k);
+                    }
                     L[Y.UJ + C->cj[i]] += u;
                 }
             if (C->has_pid) for (int t = 0; t < G; t++) ph_pid(t, nb, Y, L, R[t], C, dt, k == 1);

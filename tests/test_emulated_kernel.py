@@ -67,6 +67,27 @@ def test_emulated_tracking_friction_noise(cclqr, orc, emu):
     assert np.abs(traj - traj_o).max() < 1e-10
 
 
+def test_emulated_philox_noise(cclqr, orc, emu):
+    """counter-based noise (noise_philox): the kernels' Philox/Box-Muller (csrc/cclqr_dev.h, run on the host here) against the oracle's"""
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N, ninst = 30, 4
+    z00 = ex["mech"].state()
+    zd = np.tile(z00, (N, 1, 1))
+    K = np.random.default_rng(2).normal(size=(N - 1, 1, 48)) * 0.3
+    c = orc.ctrl_desc(4, [0], K=K, N=N, zd=zd, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+    z0 = np.tile(z00, (ninst, 1, 1))
+    _, traj_o, _ = orc.rollout(t, c, z0, N, record=True)
+    _, traj, _ = emu_rollout(emu, orc, t, c, z0, N)
+    assert np.abs(traj_o[0] - traj_o[1]).max() > 1e-3       # instances got different streams
+    assert np.abs(traj - traj_o).max() < 1e-10
+    # and the stream is what an injected array of orc.philox_normal samples gives
+    noise = np.array([[orc.philox_normal(0xC0FFEE, n, k) for k in range(1, N + 1)] for n in range(ninst)])
+    c2 = orc.ctrl_desc(4, [0], K=K, N=N, zd=zd, fric=ex["fric"], noise_scale=2.0, noise=noise)
+    _, traj_2, _ = orc.rollout(t, c2, z0, N, record=True)
+    assert np.array_equal(traj_2, traj_o)
+
+
 def test_body_order_permutation(cclqr, orc, emu):
     """bodies listed leaf-first: the kernels' breadth-first link order differs from the caller's body/joint numbering"""
     ex = cclqr.examples.cartpole_n(2)

@@ -66,6 +66,33 @@ def test_tracking_friction_noise(cclqr, orc):
     assert np.abs(traj - traj_o).max() < TOL
 
 
+def test_philox_noise_and_instance_offset(cclqr, orc):
+    """noise_philox: device-generated Philox-4x32 / Box-Muller stream per GLOBAL instance == the oracle's; a shard launched with
+    cclqr_set_instance_offset reproduces its slice of the whole batch bit for bit"""
+    capi = cclqr._capi
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N, ninst = 120, 50
+    z00 = ex["mech"].state()
+    zd = np.tile(z00, (N, 1, 1))
+    K = np.random.default_rng(2).normal(size=(N - 1, 1, 48)) * 0.3
+    kw = dict(K=K, N=N, zd=zd, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+    z0 = np.tile(z00, (ninst, 1, 1))
+    _, traj_o, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0, N, record=True)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], **kw)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, N, record=True)
+    assert (st > 0).all()
+    assert np.abs(traj[0] - traj[1]).max() > 1e-3
+    assert np.abs(traj - traj_o).max() < TOL
+    try:
+        capi.set_instance_offset(20)
+        zT_s, _, _ = capi.rollout(mech, ctrl, z0[20:35], N)
+    finally:
+        capi.set_instance_offset(0)
+    assert np.array_equal(zT_s, zT[20:35])
+
+
 def test_chained_device_launches_equal_one_launch(cclqr, orc):
     """step-per-launch / MPC-style use of cclqr_rollout_dev: state and multipliers round-trip HBM between launches (k0 continuation);
     40 + 1 + 59 steps in three launches == 100 steps in one launch, bit for bit, on device pointers and a non-default stream"""

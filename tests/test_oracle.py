@@ -275,3 +275,15 @@ def test_upright_long_chain_is_ill_posed_in_the_reference_algorithm(cclqr, orc):
     phi[0, 0] += np.pi
     _, _, sth = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=Kh, N=120, zd=zh), cclqr.examples.cartpole_states(12, [0.5], phi), 119)
     assert sth[0] > 0
+
+
+def test_philox_known_answers(orc):
+    """Philox-4x32-10 against the Random123 known-answer vectors (kat_vectors: zeros, ones, digits of pi), and the derived
+    normal stream's moments"""
+    assert orc.philox4x32([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    x = np.array([orc.philox_normal(0xC0FFEE, i, k) for i in range(100) for k in range(1, 201)])
+    assert abs(x.mean()) < 0.03 and abs(x.std() - 1) < 0.03
+    # streams of different instances / seeds are distinct
+    assert orc.philox_normal(0xC0FFEE, 0, 1) != orc.philox_normal(0xC0FFEE, 1, 1) != orc.philox_normal(0xC0FFED, 1, 1)
