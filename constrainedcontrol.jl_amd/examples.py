@@ -121,6 +121,42 @@ def sawyer(tables, g=0.0):
                 ctrl=list(mech.eqconstraints), horizon=20.0, tend=20.0)
 
 
+def acrobot():
+    """examples/lqr_acrobot.jl:8-50 — two links on revolutes about x, only the SECOND joint actuated: link1 Box(0.1,0.1,1,1) with
+    p2=[0,0,0.5]; link2 Box(0.1,0.1,2,1) hung at p1=-[0,0,0.5] / p2=[0,0,1]; start RotX(π-0.1), RotX(0.1); setpoint both RotX(π),
+    xd=[[0,0,0.5],[0,0,2]]; Q1[7,7]=Q1[10,10]=4, Q2[7,7]=Q2[10,10]=1, R=1, horizon 10 s."""
+    p2a, p2b = np.array([0.0, 0.0, 0.5]), np.array([0.0, 0.0, 1.0])
+    origin = Origin()
+    link1 = Box(0.1, 0.1, 1.0, 1.0)
+    link2 = Box(0.1, 0.1, 2.0, 1.0)
+    joint1 = EqualityConstraint(Revolute(origin, link1, EX, p2=p2a))
+    joint2 = EqualityConstraint(Revolute(link1, link2, EX, p1=-p2a, p2=p2b))
+    mech = Mechanism(origin, [link1, link2], [joint1, joint2], g=-9.81)
+    setPosition(origin, link1, p2=p2a, Δq=Quaternion(RotX(np.pi - 0.1)))
+    setPosition(link1, link2, p1=-p2a, p2=p2b, Δq=Quaternion(RotX(0.1)))
+    Q = [np.zeros((12, 12)), np.zeros((12, 12))]
+    Q[0][6, 6] = Q[0][9, 9] = 4.0
+    Q[1][6, 6] = Q[1][9, 9] = 1.0
+    return dict(mech=mech, bodies=[link1, link2], joints=[joint1, joint2], Q=Q, R=[np.ones((1, 1))], ctrl=[joint2],
+                xd=[np.array([0.0, 0.0, 0.5]), np.array([0.0, 0.0, 2.0])], qd=[Quaternion(RotX(np.pi))] * 2, horizon=10.0, tend=10.0)
+
+
+def double_pendulum(φ1=0.0, φ2=0.0):
+    """examples/pid_doublependulum.jl:5-38 — two Box(0.1,0.1,1,1) links on revolutes about x (p2=[0,0,0.5]; p1=-p2, p2), default
+    gravity; PID goals [π/2, -π/4], P=[10,10], I=[10,10], D=[5,5], 10 s."""
+    p2 = np.array([0.0, 0.0, 0.5])
+    origin = Origin()
+    link1 = Box(0.1, 0.1, 1.0, 1.0)
+    link2 = Box(0.1, 0.1, 1.0, 1.0)
+    joint1 = EqualityConstraint(Revolute(origin, link1, EX, p2=p2))
+    joint2 = EqualityConstraint(Revolute(link1, link2, EX, p1=-p2, p2=p2))
+    mech = Mechanism(origin, [link1, link2], [joint1, joint2])
+    setPosition(origin, link1, p2=p2, Δq=Quaternion(RotX(φ1)))
+    setPosition(link1, link2, p1=-p2, p2=p2, Δq=Quaternion(RotX(φ2)))
+    return dict(mech=mech, bodies=[link1, link2], joints=[joint1, joint2], goals=[np.pi / 2, -np.pi / 4], P=[10.0, 10.0], I=[10.0, 10.0],
+                D=[5.0, 5.0], tend=10.0)
+
+
 def prismatic_slider():
     """examples/lqr_prismatic.jl:8-30: Box(0.1,0.1,0.1,1) on Prismatic(origin, link1, ex), g = 0, start at Δx = [1,0,0];
     minimal-coordinate LQR: Q = ones(1), R = ones(1), horizon 10 s (setpoint: joint coordinate 0)."""

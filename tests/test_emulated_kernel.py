@@ -206,3 +206,26 @@ def test_emulated_pid(cclqr, orc, emu):
     _, traj, st = emu_rollout(emu, orc, t, c, z0, 120)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-10
+
+
+def test_emulated_acrobot_and_pid_double_pendulum(cclqr, orc, emu):
+    """examples/lqr_acrobot.jl (second joint actuated only) and examples/pid_doublependulum.jl (two PID joints) through the kernels' phases"""
+    ex = cclqr.examples.acrobot()
+    t = ex["mech"].tables()
+    zd = np.zeros((2, 13))
+    zd[:, 0:3], zd[:, 3:7] = np.array(ex["xd"]), np.array(ex["qd"])
+    A, Bu, Bl, G = orc.linearize(t, zd, [1], np.zeros(1))
+    K, _ = orc.riccati(A, Bu, Bl, G, sl.block_diag(*ex["Q"]) * t.dt, sl.block_diag(*ex["R"]) * t.dt, 300)
+    oc = orc.ctrl_desc(2, [1], K=K, N=300, zd=zd)
+    z0 = ex["mech"].state()[None]
+    zo, traj_o, _ = orc.rollout(t, oc, z0, 250, record=True)
+    _, traj, st = emu_rollout(emu, orc, t, oc, z0, 250)
+    assert (st > 0).all() and np.abs(traj - traj_o).max() < 1e-9
+
+    ex = cclqr.examples.double_pendulum()
+    t = ex["mech"].tables()
+    z0 = np.stack([cclqr.examples.double_pendulum(a, b)["mech"].state() for a, b in ((0.0, 0.0), (0.4, -0.3))])
+    oc = orc.ctrl_desc(2, [], K=None, N=0, pid=dict(joint=[0, 1], P=ex["P"], I=ex["I"], D=ex["D"], goal=ex["goals"]))
+    _, traj_o, _ = orc.rollout(t, oc, z0, 300, record=True)
+    _, traj, st = emu_rollout(emu, orc, t, oc, z0, 300)
+    assert (st > 0).all() and np.abs(traj - traj_o).max() < 1e-9

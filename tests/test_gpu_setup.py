@@ -225,3 +225,42 @@ def test_pid_controller(cclqr, orc):
     assert (st.status > 0).all() and (sto > 0).all()
     assert np.abs(st.z - traj).max() < 1e-9
     assert all(abs(np.angle(np.exp(1j * (orc.minimal_coordinates(t, st.zT[i])[0] - np.pi / 2)))) < 1e-2 for i in range(5))   # modulo 2π
+
+
+def test_acrobot_underactuated_lqr(cclqr, orc):
+    """examples/lqr_acrobot.jl through the mirror: only the elbow joint is actuated (eqcids = [constraints[2]]); gains against the
+    oracle's pipeline, closed-loop rollout against the oracle, and the upright setpoint is held"""
+    ex = cclqr.examples.acrobot()
+    mech = ex["mech"]
+    lqr = cclqr.LQR(mech, [cclqr.getid(b) for b in ex["bodies"]], [cclqr.getid(j) for j in ex["ctrl"]], ex["Q"], ex["R"], ex["horizon"],
+                    xd=ex["xd"], qd=ex["qd"])
+    assert lqr.K.shape == (999, 1, 24) and lqr.ctrl_joints == [1]
+    t = mech.tables()
+    A, Bu, Bl, G = orc.linearize(t, lqr.zd[0], [1], np.zeros(1))
+    K_o, kb = orc.riccati(A, Bu, Bl, G, lqr.Q, lqr.R, 1000)
+    assert np.abs(lqr.K - K_o).max() < 1e-6 * max(1.0, np.abs(K_o).max())
+    z0 = mech.state()
+    st = cclqr.simulate(mech, 10, lqr, record=True)
+    oc = orc.ctrl_desc(2, [1], K=lqr.K, N=lqr.N, zd=lqr.zd)
+    _, traj, sto = orc.rollout(t, oc, z0[None], 1000, record=True)
+    assert (st.status > 0).all() and (sto > 0).all()
+    assert np.abs(st.z - traj).max() < 1e-8
+    th = orc.minimal_coordinates(t, st.zT[0])
+    assert abs(np.angle(np.exp(1j * (th[0] - np.pi)))) < 0.05 and abs(th[1]) < 0.05       # balanced upright from 0.1 rad off
+
+
+def test_pid_double_pendulum(cclqr, orc):
+    """examples/pid_doublependulum.jl: PID(mech, getfield.(constraints,:id), [pi/2;-pi/4], P=[10,10], I=[10,10], D=[5,5])"""
+    ex = cclqr.examples.double_pendulum()
+    mech = ex["mech"]
+    pid = cclqr.PID(mech, [cclqr.getid(j) for j in ex["joints"]], ex["goals"], P=ex["P"], I=ex["I"], D=ex["D"])
+    z0 = np.stack([cclqr.examples.double_pendulum(a, b)["mech"].state() for a, b in ((0.0, 0.0), (0.4, -0.3), (-0.8, 0.5))])
+    st = cclqr.simulate(mech, ex["tend"], pid, z0=z0)
+    t = mech.tables()
+    oc = orc.ctrl_desc(2, [], K=None, N=0, pid=dict(joint=[0, 1], P=ex["P"], I=ex["I"], D=ex["D"], goal=ex["goals"]))
+    zo, traj, sto = orc.rollout(t, oc, z0, 1000, record=True)
+    assert (st.status > 0).all() and (sto > 0).all()
+    assert np.abs(st.z - traj).max() < 1e-8
+    for i in range(3):
+        th = orc.minimal_coordinates(t, st.zT[i])
+        assert abs(th[0] - np.pi / 2) < 0.05 and abs(th[1] + np.pi / 4) < 0.05
