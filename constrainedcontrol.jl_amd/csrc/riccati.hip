@@ -2,9 +2,9 @@
 // time-varying twin dlqr(mechanism, ...) of src/control/lqr_tracking.jl:73-122 (A,Bu,Bλ,G indexed by knot).
 //
 // One workgroup (8 wavefronts) per independent problem, persistent over k = N-1 ... 1: the sweep is sequential in k, so all
-// parallelism inside a problem is in the dense algebra of one step.  The mx x mx products (Abar = A - Bu Ku - Bλ Kλ,
-// P Abar, Abar' (P Abar)) run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, 16x16 tiles per wavefront); M \ b is an
-// in-kernel LU with partial pivoting (Julia's `\` on a square matrix) followed by one-column-per-thread substitution.
+// parallelism inside a problem is in the dense algebra of one step.  The mx x mx products (P [A' | D], Abar' (P Abar)) run on the
+// fp64 matrix cores (v_mfma_f64_16x16x4_f64, 16x16 tiles per wavefront); the linear solves are in-kernel LUs with partial
+// pivoting (Julia's `\` on a square matrix) followed by one-column-per-thread substitution.
 // Statement-by-statement correspondence with lqr.jl is marked with the line numbers.
 #include "cclqr_internal.h"
 #include <math.h>
@@ -167,33 +167,39 @@ __device__ void wg_lu_solve(int n, MP LU, int lda, const int* piv, double* B, in
     __syncthreads();
 }
 
+// Workspace of one problem.  The recursion runs in its PROJECTED form: with E = (G Bλ)^-1 G Bu and F = (G Bλ)^-1 G A,
+//   D  = Bu - Bλ E            (lqr.jl:151, the reference's D)
+//   A' = A  - Bλ F            (dynamics projected onto the constraint manifold)
+// the second block row of M Kk = b (lqr.jl:154-160) gives Kλ = F - E Ku, and substituting it into the first block row leaves
+//   (R + D' P D) Ku = D' P A' ,   Abar = A - Bu Ku - Bλ Kλ = A' - D Ku        (lqr.jl:160,169)
+// i.e. the same Kk and Abar as the reference's (mu+ml)-square solve, at the cost of a mu-square one; E, F, D, A' do not depend on P,
+// so a time-invariant problem computes them once.  Only Ku is stored by the reference (lqr.jl:162-164), Kλ is never formed.
 struct RicWork {
-    double *GBl, *GBlT, *GBu, *Yt, *BlT, *BuT, *D, *GA, *DtP, *Mm, *bb, *Abar, *T, *P, *Pn, *KRK;
+    double *GBl, *X, *AD, *W, *TS, *S, *Ku, *Abar, *P, *Pn, *KRK;
     int* piv;
 };
 __host__ __device__ inline size_t ric_carve(int mx, int mu, int ml, double* base, RicWork* w) {
-    const size_t m = mu + ml;
+    const size_t na = (size_t)mx + mu;
     size_t o = 0;
     auto take = [&](size_t n) { double* p = base ? base + o : nullptr; o += (n + 1) & ~(size_t)1; return p; };
-    double *GBl = take((size_t)ml * ml), *GBlT = take((size_t)ml * ml), *GBu = take((size_t)ml * mu), *Yt = take((size_t)ml * mx),
-           *BlT = take((size_t)ml * mx), *BuT = take((size_t)mu * mx), *D = take((size_t)mx * mu), *GA = take((size_t)ml * mx),
-           *DtP = take((size_t)mu * mx), *Mm = take(m * m), *bb = take(m * mx), *Abar = take((size_t)mx * mx), *T = take((size_t)mx * mx),
-           *P = take((size_t)mx * mx), *Pn = take((size_t)mx * mx), *KRK = take((size_t)mu * mx), *piv = take(2 * (m + ml) + 2 * m + 16);
-    if (w) { w->GBl = GBl; w->GBlT = GBlT; w->GBu = GBu; w->Yt = Yt; w->BlT = BlT; w->BuT = BuT; w->D = D; w->GA = GA; w->DtP = DtP; w->Mm = Mm;
-             w->bb = bb; w->Abar = Abar; w->T = T; w->P = P; w->Pn = Pn; w->KRK = KRK; w->piv = (int*)piv; }
+    double *GBl = take((size_t)ml * ml), *X = take((size_t)ml * na), *AD = take((size_t)mx * na), *W = take((size_t)mx * na),
+           *TS = take((size_t)mu * na), *S = take((size_t)mu * mu), *Ku = take((size_t)mu * mx), *Abar = take((size_t)mx * mx),
+           *P = take((size_t)mx * mx), *Pn = take((size_t)mx * mx), *KRK = take((size_t)mu * mx), *piv = take((size_t)ml + mu + 16);
+    if (w) { w->GBl = GBl; w->X = X; w->AD = AD; w->W = W; w->TS = TS; w->S = S; w->Ku = Ku; w->Abar = Abar; w->P = P; w->Pn = Pn;
+             w->KRK = KRK; w->piv = (int*)piv; }
     return o;
 }
 size_t ric_work_doubles(int mx, int mu, int ml) { return ric_carve(mx, mu, ml, nullptr, nullptr); }
 
 #ifdef CCLQR_PROFILE
-enum { RP_PRE, RP_DTP, RP_MB, RP_LU, RP_SOLVE, RP_ABAR, RP_PP, RP_NORM, RP_STEPS, RP_N };
+enum { RP_PRE, RP_PA, RP_GAIN, RP_UPD, RP_PP, RP_NORM, RP_STEPS, RP_N };
 static __device__ unsigned long long g_rprof[RP_N];
 #define RSTAMP(c) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t1_ = __builtin_readcyclecounter(); g_rprof[c] += t1_ - rt0; rt0 = t1_; } } while (0)
 #else
 #define RSTAMP(c)
 #endif
 
-#define RIC_LDS_M 96   // M (m x m) is kept in LDS for the pivoted LU when m <= 96 (72 KB)
+#define RIC_LDS_M 96   // G Bλ (ml x ml) is kept in LDS for its pivoted LU when ml <= 96 (72 KB)
 
 template <bool LDSM>
 __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
@@ -206,13 +212,12 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
     __shared__ int red_i[4];
     __shared__ int sing;
     const int prob = blockIdx.x, tid = threadIdx.x;
-    const int mx = a.mx, mu = a.mu, ml = a.ml, m = mu + ml, N = a.N;
+    const int mx = a.mx, mu = a.mu, ml = a.ml, N = a.N, na = mx + mu;
     RicWork w;
     ric_carve(mx, mu, ml, a.work + (size_t)prob * ric_carve(mx, mu, ml, nullptr, nullptr), &w);
-    MP Mm = LDSM ? (MP)lds_M : (MP)w.Mm;
-    MP Xs = LDSM ? (MP)lds_M + (size_t)m * m : (MP) nullptr;
+    MP GBl = LDSM ? (MP)lds_M : (MP)w.GBl;
+    MP Xs = LDSM ? (MP)lds_M + (size_t)ml * ml : (MP) nullptr;
     const int CB = LDSM ? a.lds_cols : 0;
-    double* Msmall = w.Mm;   // global scratch for the mu x m upper block written by the MFMA products (then copied into M)
     const size_t nlin = a.time_varying ? (size_t)(N - 1) : 1;
     const double* Ab = a.A + (size_t)prob * nlin * mx * mx;
     const double* Bub = a.Bu + (size_t)prob * nlin * mx * mu;
@@ -224,70 +229,68 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
     __syncthreads();
     double* P = w.P;
     double* Pn = w.Pn;
+    const int tr = tid >> 5, tc = tid & 31;   // 16 x 32 thread grid for the elementwise passes (no per-element index division)
     int k = 0, status = 0;
     for (k = N - 1; k >= 1; k--) {                                       // for outer k=N-1:-1:1                    lqr.jl:150
         const size_t li = a.time_varying ? (size_t)(k - 1) : 0;
         const double *A = Ab + li * mx * mx, *Bu = Bub + li * mx * mu, *Bl = Blb + li * mx * ml, *G = Gb + li * ml * mx;
         if (a.time_varying || k == N - 1) {
-            // D = Bu - Bλ/(G*Bλ)*G*Bu                                                                              lqr.jl:151
-            for (int e = tid; e < ml * mx; e += RIC_THREADS) { int r = e / mx, c = e % mx; w.BlT[e] = Bl[(size_t)c * ml + r]; }
-            for (int e = tid; e < mu * mx; e += RIC_THREADS) { int r = e / mx, c = e % mx; w.BuT[e] = Bu[(size_t)c * mu + r]; }
-            for (int e = tid; e < mx * mu; e += RIC_THREADS) w.D[e] = Bu[e];
+            // AD = [A' | D] = [A | Bu] - Bλ (G Bλ)^-1 G [A | Bu]                                                    lqr.jl:151,154-155,158
+            for (int i = tr; i < mx; i += RIC_THREADS / 32) {
+                for (int j = tc; j < mx; j += 32) w.AD[(size_t)i * na + j] = A[(size_t)i * mx + j];
+                for (int j = tc; j < mu; j += 32) w.AD[(size_t)i * na + mx + j] = Bu[(size_t)i * mu + j];
+            }
             __syncthreads();
             if (ml > 0) {
-                wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, w.GBl, ml);   // M22 = G*Bλ                         lqr.jl:155
-                wg_gemm<false>(ml, mu, mx, 1.0, G, mx, Bu, mu, 0.0, w.GBu, mu);   // M21 = G*Bu                         lqr.jl:154
-                wg_gemm<false>(ml, mx, mx, 1.0, G, mx, A, mx, 0.0, w.GA, mx);     // G*A (lower block of b)             lqr.jl:158
-                for (int e = tid; e < ml * ml; e += RIC_THREADS) { int r = e / ml, c = e % ml; w.GBlT[e] = w.GBl[(size_t)c * ml + r]; }
-                for (int e = tid; e < ml * mx; e += RIC_THREADS) w.Yt[e] = w.BlT[e];
-                __syncthreads();
-                wg_lu<double*>(ml, w.GBlT, ml, w.piv + m + 1, &sing, red_v, red_i);          // (G Bλ)' Y' = Bλ'
-                wg_lu_solve<double*>(ml, w.GBlT, ml, w.piv + m + 1, w.Yt, mx, mx, nullptr, 0);
-                wg_gemm<true>(mx, mu, ml, -1.0, w.Yt, mx, w.GBu, mu, 1.0, w.D, mu);
+                wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, w.GBl, ml);          // M22 = G*Bλ                  lqr.jl:155
+                wg_gemm<false>(ml, na, mx, 1.0, G, mx, w.AD, na, 0.0, w.X, na);          // [G*A | G*Bu]               lqr.jl:158,154
+                if (LDSM) { for (int e = tid; e < ml * ml; e += RIC_THREADS) GBl[e] = w.GBl[e]; __syncthreads(); }
+                wg_lu<MP>(ml, GBl, ml, w.piv, &sing, red_v, red_i);
+                if (!sing) {
+                    wg_lu_solve<MP>(ml, GBl, ml, w.piv, w.X, na, na, Xs, CB);            // X = [F | E]
+                    wg_gemm<false>(mx, na, ml, -1.0, Bl, ml, w.X, na, 1.0, w.AD, na);
+                }
             }
         }
         if (sing) { status = CCLQR_ESINGULAR_; break; }
         RSTAMP(RP_PRE);
-        // M = [R + D'PBu  D'PBλ; G*Bu  G*Bλ] ; b = [D'*Pk; G]*A                                                    lqr.jl:152-158
-        wg_gemm<true>(mu, mx, mx, 1.0, w.D, mu, P, mx, 0.0, w.DtP, mx);
-        RSTAMP(RP_DTP);
-        // upper block [R + D'P Bu, D'P Bλ] through the MFMA products into global scratch, then M is assembled where the LU runs
-        for (int e = tid; e < mu * mu; e += RIC_THREADS) Msmall[(size_t)(e / mu) * m + e % mu] = a.R[e];
-        for (int e = tid; e < ml * mx; e += RIC_THREADS) w.bb[(size_t)mu * mx + e] = w.GA[e];
+        // W = Pk [A' | D]   (Pk symmetric)
+        wg_gemm<true>(mx, na, mx, 1.0, P, mx, w.AD, na, 0.0, w.W, na);
+        RSTAMP(RP_PA);
+        // TS = D' W = [D' Pk A' | D' Pk D] ;  S = R + D' Pk D ;  Ku = S \ (D' Pk A')                               lqr.jl:152-160
+        wg_gemm<true>(mu, na, mx, 1.0, w.AD + mx, na, w.W, na, 0.0, w.TS, na);
+        for (int e = tid; e < mu * mu; e += RIC_THREADS) w.S[e] = a.R[e] + w.TS[(size_t)(e / mu) * na + mx + e % mu];
+        for (int e = tid; e < mu * mx; e += RIC_THREADS) w.Ku[e] = w.TS[(size_t)(e / mx) * na + e % mx];
         __syncthreads();
-        wg_gemm<false>(mu, mu, mx, 1.0, w.DtP, mx, Bu, mu, 1.0, Msmall, m);
-        if (ml > 0) wg_gemm<false>(mu, ml, mx, 1.0, w.DtP, mx, Bl, ml, 0.0, Msmall + mu, m);
-        wg_gemm<false>(mu, mx, mx, 1.0, w.DtP, mx, A, mx, 0.0, w.bb, mx);
-        if (LDSM) for (int e = tid; e < mu * m; e += RIC_THREADS) Mm[e] = Msmall[e];
-        for (int e = tid; e < ml * mu; e += RIC_THREADS) Mm[(size_t)(mu + e / mu) * m + e % mu] = w.GBu[e];
-        for (int e = tid; e < ml * ml; e += RIC_THREADS) Mm[(size_t)(mu + e / ml) * m + mu + e % ml] = w.GBl[e];
-        __syncthreads();
-        RSTAMP(RP_MB);
-        // Kk = M\b                                                                                                  lqr.jl:160
-        wg_lu<MP>(m, Mm, m, w.piv, &sing, red_v, red_i);
+        wg_lu<double*>(mu, w.S, mu, w.piv + ml + 4, &sing, red_v, red_i);
         if (sing) { status = CCLQR_ESINGULAR_; break; }
-        RSTAMP(RP_LU);
-        wg_lu_solve<MP>(m, Mm, m, w.piv, w.bb, mx, mx, Xs, CB);
-        double* Kk = w.bb;
-        RSTAMP(RP_SOLVE);
-        for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k - 1) * mu * mx + e] = Kk[e];   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
-        // Abar = A-Bu*Kuk-Bλ*Kλk                                                                                    lqr.jl:169
-        for (int e = tid; e < mx * mx; e += RIC_THREADS) w.Abar[e] = A[e];
-        // KRK = R Kuk (mu x mx), tiny
+        wg_lu_solve<double*>(mu, w.S, mu, w.piv + ml + 4, w.Ku, mx, mx, nullptr, 0);
+        const double* Ku = w.Ku;
+        for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k - 1) * mu * mx + e] = Ku[e];   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
+        // KRK = R Kuk (mu x mx)
         for (int e = tid; e < mu * mx; e += RIC_THREADS) {
             int i = e / mx, c = e % mx; double s = 0.0;
-            for (int q = 0; q < mu; q++) s += a.R[i * mu + q] * Kk[(size_t)q * mx + c];
+            for (int q = 0; q < mu; q++) s += a.R[i * mu + q] * Ku[(size_t)q * mx + c];
             w.KRK[e] = s;
         }
-        for (int e = tid; e < mx * mx; e += RIC_THREADS) Pn[e] = a.Q[e];
+        RSTAMP(RP_GAIN);
+        // Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) ;  W <- Pk Abar = Pk A' - (Pk D) Kuk ;  Pn = Q
+        for (int i = tr; i < mx; i += RIC_THREADS / 32) {
+            const double* ADi = w.AD + (size_t)i * na;
+            double* Wi = w.W + (size_t)i * na;
+            for (int j = tc; j < mx; j += 32) {
+                double ab = ADi[j], pw = Wi[j];
+                for (int q = 0; q < mu; q++) { const double kq = Ku[(size_t)q * mx + j]; ab -= ADi[mx + q] * kq; pw -= Wi[mx + q] * kq; }
+                w.Abar[(size_t)i * mx + j] = ab;
+                Wi[j] = pw;
+                Pn[(size_t)i * mx + j] = a.Q[(size_t)i * mx + j];
+            }
+        }
         __syncthreads();
-        wg_gemm<true>(mx, mx, mu, -1.0, w.BuT, mx, Kk, mx, 1.0, w.Abar, mx);
-        if (ml > 0) wg_gemm<true>(mx, mx, ml, -1.0, w.BlT, mx, Kk + (size_t)mu * mx, mx, 1.0, w.Abar, mx);
-        RSTAMP(RP_ABAR);
+        RSTAMP(RP_UPD);
         // Pkp1 = Q + Kuk'*R*Kuk + Abar'*Pk*Abar                                                                     lqr.jl:170
-        wg_gemm<true>(mx, mx, mu, 1.0, Kk, mx, w.KRK, mx, 1.0, Pn, mx);
-        wg_gemm<true>(mx, mx, mx, 1.0, P, mx, w.Abar, mx, 0.0, w.T, mx);    // Pk Abar (Pk symmetric)
-        wg_gemm<true>(mx, mx, mx, 1.0, w.Abar, mx, w.T, mx, 1.0, Pn, mx);
+        wg_gemm<true>(mx, mx, mu, 1.0, Ku, mx, w.KRK, mx, 1.0, Pn, mx);
+        wg_gemm<true>(mx, mx, mx, 1.0, w.Abar, mx, w.W, na, 1.0, Pn, mx);
         RSTAMP(RP_PP);
         // if norm(Pk-Pkp1) < 1e-5  break                                                                            lqr.jl:172-174
         double acc = 0.0;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
 
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
-    const int m = a.mu + a.ml;
+    const int m = a.ml, na = a.mx + a.mu;
     RicArgs a2 = a;
     size_t lds = 0;
     a2.lds_cols = 0;
@@ -327,9 +330,9 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
         const size_t budget = 150 * 1024;                 // of the 160 KB per CU; the rest is static LDS
         size_t cols = (budget - (size_t)m * m * sizeof(double)) / ((size_t)m * sizeof(double));
         if (cols > RIC_THREADS) cols = RIC_THREADS;
-        if (cols > (size_t)a.mx) cols = a.mx;
+        if (cols > (size_t)na) cols = na;
         a2.lds_cols = (int)cols;
-        lds = ((size_t)m * m + (size_t)m * cols) * sizeof(double);   // M for the pivoted LU + one batch of right-hand-side columns
+        lds = ((size_t)m * m + (size_t)m * cols) * sizeof(double);   // G Bλ for the pivoted LU + one batch of right-hand-side columns
     }
     if (lds > 0) {
         hipError_t e = hipFuncSetAttribute((const void*)riccati_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

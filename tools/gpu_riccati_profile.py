@@ -18,10 +18,10 @@ capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, 3)   # warm
 capi.lib().cclqr_ric_prof_read(buf, 1)
 t0 = time.time(); K, kb = capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, N); dt = time.time() - t0
 capi.lib().cclqr_ric_prof_read(buf, 1)
-v = np.array(list(buf), dtype=np.float64); steps = max(v[8], 1); tot = v[:8].sum()
+v = np.array(list(buf), dtype=np.float64); steps = max(v[6], 1); tot = v[:6].sum()
 m = mu + ml
 F = 4 * mx**3 + 4 * mx**2 * m + 2 * mx * (ml**2 + m**2) + 2 / 3 * m**3 + 2 / 3 * ml**3
 kbs = np.atleast_1d(kb); done = (N - np.maximum(kbs, 1) + 1).sum()
 print("%s mx=%d mu=%d ml=%d nprob=%d N=%d: %.3fs total, %.3f ms/backward-step/problem-wave, kbreak %s, %.1f GFLOP/s (F_ric=%.3g)" % (name, mx, mu, ml, nprob, N, dt, 1e3 * dt / max(1, N - kbs.min()), kbs[:3], F * done / dt / 1e9, F))
-for i, n in enumerate(["precompute", "D'P", "M,b assembly", "LU(M)", "solve M\\b", "Abar", "P Abar, Abar'(P Abar)", "norm"]):
+for i, n in enumerate(["precompute A',D", "P [A'|D]", "gain (mu x mu solve)", "Abar, P Abar updates", "Abar'(P Abar)", "norm"]):
     print("  %-24s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / steps))
