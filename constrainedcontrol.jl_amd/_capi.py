@@ -15,7 +15,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset"]
+           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path"]
 
 
 class CclqrError(RuntimeError):
@@ -185,6 +185,11 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
     check(lib().cclqr_rollout(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
                               _i(status)))
     return zT, traj, status
+
+
+def riccati_path(path):
+    """0 auto, 1 persistent workgroup per problem, 2 tiled over the device"""
+    check(lib().cclqr_riccati_path(C.c_int32(int(path))))
 
 
 def set_instance_offset(first_instance):

@@ -194,32 +194,40 @@ static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varyin
                        const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak) {
     const size_t nK = (size_t)nprob * (N > 1 ? N - 1 : 0) * mu * mx;
     double *dQ = nullptr, *dR = nullptr, *dK = nullptr, *dwork = nullptr;
-    int *dkb = nullptr, *dst = nullptr;
+    int *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
     std::vector<int> st(nprob), kb(nprob);
-    const size_t wd = ric_work_doubles(mx, mu, ml);
+    RicArgs a;
+    a.nprob = nprob; a.mx = mx; a.mu = mu; a.ml = ml; a.N = N; a.time_varying = time_varying; a.tol = tol;
+    const size_t wd = ric_total_work_doubles(a);
     hipError_t e = hipMalloc((void**)&dQ, (size_t)mx * mx * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&dK, (nK + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dwork, (size_t)nprob * wd * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dwork, wd * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dstop, nprob * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&dkb, nprob * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&dst, nprob * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(dQ, Q, (size_t)mx * mx * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && mu > 0) e = hipMemcpy(dR, R, (size_t)mu * mu * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(dK, 0, (nK + 1) * sizeof(double));
-    RicArgs a;
-    a.nprob = nprob; a.mx = mx; a.mu = mu; a.ml = ml; a.N = N; a.time_varying = time_varying; a.tol = tol;
+    a.stop = dstop;
     a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.Q = dQ; a.R = dR; a.K = dK; a.kbreak = dkb; a.status = dst; a.work = dwork;
     if (e == hipSuccess) e = launch_riccati(a, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && nK) e = hipMemcpy(K, dK, nK * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(kb.data(), dkb, nprob * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nprob * sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dK); (void)hipFree(dwork); (void)hipFree(dkb); (void)hipFree(dst);
+    (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dK); (void)hipFree(dwork); (void)hipFree(dkb); (void)hipFree(dst); (void)hipFree(dstop);
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati: ") + hipGetErrorString(e));
     for (int p = 0; p < nprob; p++) {
         if (kbreak) kbreak[p] = kb[p];
         if (st[p] != 0) return fail(CCLQR_ESINGULAR, "G*Bl or M is singular in problem " + std::to_string(p));
     }
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_riccati_path(int32_t path) {
+    if (path < 0 || path > 2) return fail(CCLQR_EINVAL, "riccati path must be 0 (auto), 1 (persistent) or 2 (tiled)");
+    set_riccati_path(path);
     return CCLQR_OK;
 }
 

@@ -320,8 +320,393 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
     if (tid == 0) { a.kbreak[prob] = k; a.status[prob] = status; }
 }
 
+// =====================================================================================================================
+// TILED path: one backward step = three launches over a grid of 32x32 tiles (x problems), so a single large problem uses
+// the whole device instead of one CU, and a batch of problems fills it with tiles rather than with whole recursions:
+//   ric_project_kernel   (once per knot)   [A' | D]                                             -> AD
+//   ric_pa_kernel        W = Pk [A' | D]                                                        (tiles of W)
+//   ric_gain_update_kernel   break test of the previous step; S = R + D'PkD; Ku = S \ D'PkA' -> K[k];
+//                        Abar = A' - D Ku ; Pk Abar = W_A' - W_D Ku                              (row blocks)
+//   ric_pn_kernel        Pkp1 = Q + Ku'RKu + Abar'(Pk Abar); per-tile |Pk - Pkp1|^2             (tiles of P)
+// Each tile is computed by four wavefronts that split the k range and are summed in a fixed order through LDS; the norm is
+// summed per tile and then over tiles in index order, so results do not depend on scheduling.  A problem that has met the
+// break criterion (lqr.jl:172) raises its `stop` flag and its later launches return at once.
+#define TILE_THREADS 256
+#define RIC_TILED_MIN_MX 48
+struct RicGrid {
+    int nprob, mx, mu, ml, N, nlin, na, tm, tn;
+    double tol;
+    const double *A, *Bu, *Bl, *G, *Q, *R;
+    double *AD, *W, *Abar, *P, *Ku, *KRK, *part, *TSp, *scratch, *K;
+    int *stop, *kbreak, *status;
+};
+
+template <bool LDSM>
+__global__ __launch_bounds__(RIC_THREADS) void ric_project_kernel(RicGrid a, int lds_cols) {
+    extern __shared__ double lds_M[];
+    typedef typename std::conditional<LDSM, lds_double*, double*>::type MP;
+    __shared__ double red_v[RIC_WAVES];
+    __shared__ int red_i[4];
+    __shared__ int sing;
+    const int knot = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
+    const int mx = a.mx, mu = a.mu, ml = a.ml, na = a.na;
+    const size_t lin = (size_t)prob * a.nlin + knot;
+    const double *A = a.A + lin * mx * mx, *Bu = a.Bu + lin * mx * mu, *Bl = a.Bl + lin * mx * ml, *G = a.G + lin * ml * mx;
+    double* AD = a.AD + lin * mx * na;
+    double* sc = a.scratch + lin * (((size_t)ml * ml + (size_t)ml * na + 3) & ~(size_t)1);
+    double* GBlg = sc;
+    double* X = sc + (((size_t)ml * ml + 1) & ~(size_t)1);
+    int* piv = (int*)(a.scratch + (size_t)a.nprob * a.nlin * (((size_t)ml * ml + (size_t)ml * na + 3) & ~(size_t)1)) + lin * (ml + 2);
+    MP GBl = LDSM ? (MP)lds_M : (MP)GBlg;
+    MP Xs = LDSM ? (MP)lds_M + (size_t)ml * ml : (MP) nullptr;
+    if (tid == 0) sing = 0;
+    const int tr = tid >> 5, tc = tid & 31;
+    for (int i = tr; i < mx; i += RIC_THREADS / 32) {
+        for (int j = tc; j < mx; j += 32) AD[(size_t)i * na + j] = A[(size_t)i * mx + j];
+        for (int j = tc; j < mu; j += 32) AD[(size_t)i * na + mx + j] = Bu[(size_t)i * mu + j];
+        if (knot == 0) for (int j = tc; j < mx; j += 32) a.P[((size_t)prob * mx + i) * mx + j] = a.Q[(size_t)i * mx + j];   // Pk = Q  lqr.jl:147
+    }
+    __syncthreads();
+    if (ml > 0) {
+        wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, GBlg, ml);                   // G*Bλ                         lqr.jl:155
+        wg_gemm<false>(ml, na, mx, 1.0, G, mx, AD, na, 0.0, X, na);                      // [G*A | G*Bu]                 lqr.jl:158,154
+        if (LDSM) { for (int e = tid; e < ml * ml; e += RIC_THREADS) GBl[e] = GBlg[e]; __syncthreads(); }
+        wg_lu<MP>(ml, GBl, ml, piv, &sing, red_v, red_i);
+        if (sing) { if (tid == 0) { a.status[prob] = CCLQR_ESINGULAR_; a.stop[prob] = 1; a.kbreak[prob] = knot + 1; } return; }
+        wg_lu_solve<MP>(ml, GBl, ml, piv, X, na, na, Xs, LDSM ? lds_cols : 0);           // X = (G Bλ)^-1 G [A | Bu]
+        wg_gemm<false>(mx, na, ml, -1.0, Bl, ml, X, na, 1.0, AD, na);                    // [A' | D]                     lqr.jl:151
+    }
+}
+
+// 32x32 tile of op(A)' B summed over k, split over the four wavefronts of the workgroup (wave w takes the k-groups of 4 with
+// index = w mod 4), then reduced through LDS in wave order.  la(k, h) / lb(k, h) return operand elements A[k][i0+16h+li] / B[k][j0+16h+li]
+// (already masked to 0 outside the matrix).  On return red[e], e = row*32 + col, holds the tile; all threads have synchronised.
+template <class FA, class FB>
+__device__ inline void tile_mfma_splitk(int K, FA la, FB lb, double (*red)[1024]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    v4d acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+    const int ngroups = (K + 3) >> 2;
+    // CH k-groups per wavefront and pass (4 CH loads in flight before the first MFMA): passes of 8 while they are full, then of 2
+    auto pass = [&](auto chtag, int g0) {
+        constexpr int CH = decltype(chtag)::value;
+        double av[CH][2], bv[CH][2];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int k = 4 * (g0 + 4 * u) + lk;
+            const bool kok = (g0 + 4 * u) < ngroups && k < K;
+#pragma unroll
+            for (int h = 0; h < 2; h++) { av[u][h] = kok ? la(k, h) : 0.0; bv[u][h] = kok ? lb(k, h) : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+#pragma unroll
+            for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+                for (int hj = 0; hj < 2; hj++) acc[hi][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][hi], bv[u][hj], acc[hi][hj], 0, 0, 0);
+    };
+    int g0 = wave;
+    for (; g0 + 4 * 7 < ngroups; g0 += 4 * 8) pass(std::integral_constant<int, 8>{}, g0);
+    for (; g0 < ngroups; g0 += 4 * 2) pass(std::integral_constant<int, 2>{}, g0);
+#pragma unroll
+    for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+        for (int hj = 0; hj < 2; hj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave][(16 * hi + lk + 4 * r) * 32 + 16 * hj + li] = acc[hi][hj][r];
+    __syncthreads();
+}
+
+// has problem `prob` already stopped, or does the step before this one (k+1) meet the break criterion?  (uniform over the workgroup)
+__device__ inline bool ric_stopped(const RicGrid& a, int prob, int k, int ntile_p, int* flag) {
+    if (threadIdx.x < 64) {             // first wavefront: strided partial sums, then a butterfly -- the same order in every workgroup
+        int st = a.stop[prob];
+        if (!st && k < a.N - 1) {
+            const double* part = a.part + ((size_t)((k + 1) & 1) * a.nprob + prob) * ntile_p;
+            double tot = 0.0;
+            for (int t = threadIdx.x; t < ntile_p; t += 64) tot += part[t];
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (sqrt(tot) < a.tol) st = 2;                                            // if norm(Pk-Pkp1) < 1e-5  break   lqr.jl:172-174
+        }
+        if (threadIdx.x == 0) *flag = st;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void ric_pa_kernel(RicGrid a, int k) {
+    __shared__ double red[4][1024];
+    extern __shared__ double Dl[];      // D rows of this tile, [32][mu]
+    __shared__ int flag;
+    const int prob = blockIdx.y, tid = threadIdx.x, lane = tid & 63, li = lane & 15;
+    const int mx = a.mx, na = a.na;
+    if (ric_stopped(a, prob, k, a.tm * a.tm, &flag)) return;
+    const int i0 = (blockIdx.x / a.tn) << 5, j0 = (blockIdx.x % a.tn) << 5;
+    const double* P = a.P + ((size_t)((a.N - 1 - k) & 1) * a.nprob + prob) * mx * mx;
+    const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
+    double* W = a.W + (size_t)prob * mx * na;
+    const bool iok[2] = {i0 + li < mx, i0 + 16 + li < mx}, jok[2] = {j0 + li < na, j0 + 16 + li < na};
+    const int mu = a.mu, ti = blockIdx.x / a.tn;
+    for (int t = tid; t < 32 * mu; t += TILE_THREADS) { const int r = t / mu, q = t % mu; Dl[t] = (i0 + r < mx) ? AD[(size_t)(i0 + r) * na + mx + q] : 0.0; }
+    tile_mfma_splitk(mx,
+        [&](int kk, int h) { return iok[h] ? P[(size_t)kk * mx + i0 + 16 * h + li] : 0.0; },      // Pk symmetric
+        [&](int kk, int h) { return jok[h] ? AD[(size_t)kk * na + j0 + 16 * h + li] : 0.0; }, red);
+    for (int e = tid; e < 1024; e += TILE_THREADS) {
+        const int i = i0 + (e >> 5), j = j0 + (e & 31);
+        const double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        red[0][e] = v;
+        if (i < mx && j < na) W[(size_t)i * na + j] = v;
+    }
+    __syncthreads();
+    // this tile's rows of D' W (summed over the row tiles, in order, by the gain kernel)
+    for (int t = tid; t < mu * 32; t += TILE_THREADS) {
+        const int q = t >> 5, c = t & 31;
+        if (j0 + c >= na) continue;
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; r++) sacc += Dl[r * mu + q] * red[0][r * 32 + c];
+        a.TSp[(((size_t)prob * a.tm + ti) * mu + q) * na + j0 + c] = sacc;
+    }
+}
+
+// S = R + D' Pk D ; Ku = S \ (D' Pk A')   (= the first mu rows of M \ b, lqr.jl:152-164), then
+// Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) and Pk Abar = W_A' - W_D Kuk for RU rows per workgroup.
+// Every workgroup of a problem derives the same Ku from the tile partials of D'W (mu x mu solve: cheaper than a launch);
+// workgroup 0 publishes it (K[k], Ku, R Ku) and owns the stop flag.
+#define RU 16
+__global__ __launch_bounds__(TILE_THREADS) void ric_gain_update_kernel(RicGrid a, int k) {
+    extern __shared__ double gl[];      // TS [mu][na] | S [mu][mu] | piv [mu]
+    __shared__ int flag, sing;
+    const int prob = blockIdx.y, tid = threadIdx.x;
+    const int mx = a.mx, mu = a.mu, na = a.na;
+    const bool lead = blockIdx.x == 0;
+    if (ric_stopped(a, prob, k, a.tm * a.tm, &flag)) {
+        if (lead && tid == 0 && flag == 2) { a.stop[prob] = 1; a.kbreak[prob] = k + 1; }
+        return;
+    }
+    double* TS = gl;
+    double* S = gl + (size_t)mu * na;
+    int* piv = (int*)(S + (size_t)mu * mu);
+    if (tid == 0) sing = 0;
+    for (int e = tid; e < mu * na; e += TILE_THREADS) {
+        const double* tp = a.TSp + (size_t)prob * a.tm * mu * na + e;
+        double sacc = 0.0;
+        for (int ti = 0; ti < a.tm; ti++) sacc += tp[(size_t)ti * mu * na];
+        TS[e] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < mu * mu; e += TILE_THREADS) S[e] = a.R[e] + TS[(size_t)(e / mu) * na + mx + e % mu];
+    __syncthreads();
+    for (int c = 0; c < mu; c++) {                       // LU with partial pivoting, mu <= 32
+        if (tid == 0) {
+            double best = -1.0; int bi = c;
+            for (int r = c; r < mu; r++) { double v = fabs(S[r * mu + c]); if (v > best) { best = v; bi = r; } }
+            piv[c] = bi;
+            if (!(best > 0.0)) sing = 1;
+        }
+        __syncthreads();
+        if (sing) break;
+        const int p = piv[c];
+        if (p != c && tid < mu) { double t = S[c * mu + tid]; S[c * mu + tid] = S[p * mu + tid]; S[p * mu + tid] = t; }
+        __syncthreads();
+        if (tid > c && tid < mu) S[tid * mu + c] /= S[c * mu + c];
+        __syncthreads();
+        for (int e = tid; e < (mu - c - 1) * (mu - c - 1); e += TILE_THREADS) {
+            const int r = c + 1 + e / (mu - c - 1), j = c + 1 + e % (mu - c - 1);
+            S[r * mu + j] -= S[r * mu + c] * S[c * mu + j];
+        }
+        __syncthreads();
+    }
+    if (sing) { if (lead && tid == 0) { a.status[prob] = CCLQR_ESINGULAR_; a.stop[prob] = 1; a.kbreak[prob] = k; } return; }
+    double* Ku = a.Ku + (size_t)prob * mu * mx;
+    double* KRK = a.KRK + (size_t)prob * mu * mx;
+    double* Kout = a.K + ((size_t)prob * (a.N - 1) + (k - 1)) * mu * mx;
+    for (int j = tid; j < mx; j += TILE_THREADS) {
+        for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[(size_t)c * na + j]; TS[(size_t)c * na + j] = TS[(size_t)p * na + j]; TS[(size_t)p * na + j] = t; } }
+        for (int i = 1; i < mu; i++) { double sacc = TS[(size_t)i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[(size_t)r * na + j]; TS[(size_t)i * na + j] = sacc; }
+        for (int i = mu - 1; i >= 0; i--) {
+            double sacc = TS[(size_t)i * na + j];
+            for (int r = i + 1; r < mu; r++) sacc -= S[i * mu + r] * TS[(size_t)r * na + j];
+            TS[(size_t)i * na + j] = sacc / S[i * mu + i];
+        }
+        if (lead) {
+            for (int q = 0; q < mu; q++) { const double v = TS[(size_t)q * na + j]; Ku[(size_t)q * mx + j] = v; Kout[(size_t)q * mx + j] = v; }   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
+            for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += a.R[q * mu + r] * TS[(size_t)r * na + j]; KRK[(size_t)q * mx + j] = sacc; }
+        }
+    }
+    __syncthreads();
+    const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
+    double* W = a.W + (size_t)prob * mx * na;
+    double* Abar = a.Abar + (size_t)prob * mx * mx;
+    // D and Pk D rows of this block into LDS (S, piv are dead now), then all loads of a column before the arithmetic
+    double* DP = S;                     // [RU][2 mu]; S has mu*mu doubles, the tail of the dynamic allocation covers the rest
+    const int i_base = blockIdx.x * RU;
+    for (int t = tid; t < RU * mu; t += TILE_THREADS) {
+        const int r = t / mu, q = t % mu, i = i_base + r;
+        DP[r * 2 * mu + q] = (i < mx) ? AD[(size_t)i * na + mx + q] : 0.0;
+        DP[r * 2 * mu + mu + q] = (i < mx) ? W[(size_t)i * na + mx + q] : 0.0;
+    }
+    __syncthreads();
+    for (int j = tid; j < mx; j += TILE_THREADS) {
+        double ab[RU], pw[RU];
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const int i = i_base + r;
+            ab[r] = (i < mx) ? AD[(size_t)i * na + j] : 0.0;
+            pw[r] = (i < mx) ? W[(size_t)i * na + j] : 0.0;
+        }
+        for (int q = 0; q < mu; q++) {
+            const double kq = TS[(size_t)q * na + j];
+#pragma unroll
+            for (int r = 0; r < RU; r++) { ab[r] -= DP[r * 2 * mu + q] * kq; pw[r] -= DP[r * 2 * mu + mu + q] * kq; }
+        }
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const int i = i_base + r;
+            if (i < mx) { Abar[(size_t)i * mx + j] = ab[r]; W[(size_t)i * na + j] = pw[r]; }
+        }
+    }
+}
+
+// Pkp1 = Q + Kuk'*R*Kuk + Abar'*(Pk*Abar) (lqr.jl:170), tiles of P; the per-tile |Pk - Pkp1|^2 feeds the break test
+__global__ __launch_bounds__(TILE_THREADS) void ric_pn_kernel(RicGrid a, int k) {
+    __shared__ double red[4][1024];
+    extern __shared__ double kt[];      // KuI [mu][32] | KRKJ [mu][32]
+    __shared__ double wsum[4];
+    __shared__ int flag;
+    const int prob = blockIdx.y, tid = threadIdx.x, lane = tid & 63, li = lane & 15;
+    const int mx = a.mx, mu = a.mu, na = a.na;
+    if (a.stop[prob]) return;           // the gain kernel of this step has already evaluated the break test
+    (void)flag;
+    const int i0 = (blockIdx.x / a.tm) << 5, j0 = (blockIdx.x % a.tm) << 5;
+    const double* P = a.P + ((size_t)((a.N - 1 - k) & 1) * a.nprob + prob) * mx * mx;
+    double* Pn = a.P + ((size_t)((a.N - k) & 1) * a.nprob + prob) * mx * mx;
+    const double* W = a.W + (size_t)prob * mx * na;
+    const double* Ku = a.Ku + (size_t)prob * mu * mx;
+    const double* KRK = a.KRK + (size_t)prob * mu * mx;
+    double *KuI = kt, *KRKJ = kt + mu * 32;
+    for (int e = tid; e < mu * 32; e += TILE_THREADS) {
+        const int q = e >> 5, c = e & 31;
+        KuI[e] = (i0 + c < mx) ? Ku[(size_t)q * mx + i0 + c] : 0.0;
+        KRKJ[e] = (j0 + c < mx) ? KRK[(size_t)q * mx + j0 + c] : 0.0;
+    }
+    const double* Abar = a.Abar + (size_t)prob * mx * mx;
+    const bool iok[2] = {i0 + li < mx, i0 + 16 + li < mx}, jok[2] = {j0 + li < mx, j0 + 16 + li < mx};
+    tile_mfma_splitk(mx,
+        [&](int kk, int h) { return iok[h] ? Abar[(size_t)kk * mx + i0 + 16 * h + li] : 0.0; },
+        [&](int kk, int h) { return jok[h] ? W[(size_t)kk * na + j0 + 16 * h + li] : 0.0; }, red);
+    double acc = 0.0;
+    for (int e = tid; e < 1024; e += TILE_THREADS) {
+        const int ii = e >> 5, jj = e & 31, i = i0 + ii, j = j0 + jj;
+        if (i < mx && j < mx) {
+            double v = a.Q[(size_t)i * mx + j];
+            for (int q = 0; q < mu; q++) v += KuI[q * 32 + ii] * KRKJ[q * 32 + jj];
+            v += ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+            Pn[(size_t)i * mx + j] = v;
+            const double d = P[(size_t)i * mx + j] - v;
+            acc += d * d;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) wsum[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) a.part[((size_t)(k & 1) * a.nprob + prob) * (a.tm * a.tm) + blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+// Ku[k2] = Ku[k2+1] below the break index (lqr.jl:179-181) and the loop variable's final value
+__global__ void ric_backfill_kernel(RicGrid a) {
+    const int prob = blockIdx.x, tid = threadIdx.x;
+    const int mu = a.mu, mx = a.mx, N = a.N;
+    __shared__ int kb;
+    if (tid == 0) {
+        int k = a.stop[prob] ? a.kbreak[prob] : (N - 1 >= 1 ? 1 : 0);
+        if (!a.stop[prob] && N - 1 >= 1) {
+            // the test after the last step (k = 1) is a break at k = 1 as well: same index, nothing to do
+        }
+        a.kbreak[prob] = k;
+        kb = k;
+    }
+    __syncthreads();
+    if (a.status[prob] != 0) return;
+    double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
+    for (int k2 = kb - 1; k2 >= 1; k2--) {
+        for (int e = tid; e < mu * mx; e += blockDim.x) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
+        __syncthreads();
+    }
+}
+
+static int g_ric_path = 0;   // 0 auto, 1 persistent workgroup per problem, 2 tiled
+void set_riccati_path(int p) { g_ric_path = p; }
+
+size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_varying) {
+    const size_t nlin = time_varying ? (size_t)(N > 1 ? N - 1 : 1) : 1, na = (size_t)mx + mu, tm = (mx + 31) / 32;
+    const size_t sc = (((size_t)ml * ml + (size_t)ml * na + 3) & ~(size_t)1);
+    return (size_t)nprob * (nlin * mx * na + mx * na + 3 * (size_t)mx * mx + 2 * (size_t)mu * mx + 2 * tm * tm + tm * mu * na + nlin * sc + nlin * (ml + 2) + 8) + 64;
+}
+
+static hipError_t launch_riccati_tiled(const RicArgs& a, double* work, int* stop, hipStream_t stream) {
+    RicGrid g;
+    g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
+    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol;
+    g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = stop;
+    const size_t np = a.nprob, nlin = g.nlin, mx = a.mx, na = g.na, mu = a.mu, ml = a.ml;
+    double* o = work;
+    g.AD = o; o += np * nlin * mx * na;
+    g.W = o; o += np * mx * na;
+    g.Abar = o; o += np * mx * mx;
+    g.P = o; o += 2 * np * mx * mx;
+    g.Ku = o; o += np * mu * mx;
+    g.KRK = o; o += np * mu * mx;
+    g.part = o; o += 2 * np * g.tm * g.tm;
+    g.TSp = o; o += np * g.tm * mu * na;
+    g.scratch = o;
+    hipError_t e = hipMemsetAsync(stop, 0, np * sizeof(int), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a.status, 0, np * sizeof(int), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a.kbreak, 0, np * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    size_t lds = 0; int cols = 0;
+    if (ml <= RIC_LDS_M && ml > 0) {
+        const size_t budget = 150 * 1024;
+        size_t c = (budget - ml * ml * sizeof(double)) / (ml * sizeof(double));
+        if (c > RIC_THREADS) c = RIC_THREADS;
+        if (c > na) c = na;
+        cols = (int)c;
+        lds = (ml * ml + ml * c) * sizeof(double);
+    }
+    if (lds > 0) {
+        e = hipFuncSetAttribute((const void*)ric_project_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ric_project_kernel<true>, dim3(g.nlin, a.nprob), dim3(RIC_THREADS), lds, stream, g, cols);
+    } else {
+        hipLaunchKernelGGL(ric_project_kernel<false>, dim3(g.nlin, a.nprob), dim3(RIC_THREADS), 0, stream, g, 0);
+    }
+    const size_t lds_gain = (mu * na + mu * mu + 2 * RU * mu) * sizeof(double) + (mu + 2) * sizeof(int), lds_pn = 2 * mu * 32 * sizeof(double);
+    if (lds_gain > 48 * 1024) {
+        e = hipFuncSetAttribute((const void*)ric_gain_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gain);
+        if (e != hipSuccess) return e;
+    }
+    for (int k = a.N - 1; k >= 1; k--) {                                 // for outer k=N-1:-1:1                    lqr.jl:150
+        hipLaunchKernelGGL(ric_pa_kernel, dim3(g.tm * g.tn, a.nprob), dim3(TILE_THREADS), 32 * mu * sizeof(double), stream, g, k);
+        hipLaunchKernelGGL(ric_gain_update_kernel, dim3((a.mx + RU - 1) / RU, a.nprob), dim3(TILE_THREADS), lds_gain, stream, g, k);
+        hipLaunchKernelGGL(ric_pn_kernel, dim3(g.tm * g.tm, a.nprob), dim3(TILE_THREADS), lds_pn, stream, g, k);
+    }
+    hipLaunchKernelGGL(ric_backfill_kernel, dim3(a.nprob), dim3(TILE_THREADS), 0, stream, g);
+    return hipGetLastError();
+}
+
+static bool ric_use_tiled(const RicArgs& a) {
+    if (g_ric_path == 1) return false;
+    if (g_ric_path == 2) return true;
+    return a.mx >= RIC_TILED_MIN_MX;     // small problems are launch-latency bound: keep them in one persistent workgroup
+}
+
+size_t ric_total_work_doubles(const RicArgs& a) {
+    return ric_use_tiled(a) ? ric_grid_work_doubles(a.nprob, a.mx, a.mu, a.ml, a.N, a.time_varying)
+                            : (size_t)a.nprob * ric_work_doubles(a.mx, a.mu, a.ml);
+}
+
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
+    if (ric_use_tiled(a)) return launch_riccati_tiled(a, a.work, a.stop, stream);
     const int m = a.ml, na = a.mx + a.mu;
     RicArgs a2 = a;
     size_t lds = 0;
