@@ -199,7 +199,7 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T):
     return {"cartpole_cfg2": {"instances": n, "sim_steps": 1000, "value": n * 1000 / dt2, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt2,
                               "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak)},
             "riccati_setup": {"mx": mx, "backward_steps": nsteps, "flops_per_step": f_ric,
-                              "note": "LQR construction of the headline workload = linearize + %d-step recursion, one workgroup, fp64 MFMA; "
+                              "note": "LQR construction of the headline workload = linearize + %d-step recursion (projected form, tiled over the device, fp64 MFMA); "
                                       "wall time incl. host<->device copies" % nsteps,
                               "gflops_lower_bound": f_ric * nsteps / setup_s / 1e9, "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}}
 
