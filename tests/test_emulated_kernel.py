@@ -229,3 +229,20 @@ def test_emulated_acrobot_and_pid_double_pendulum(cclqr, orc, emu):
     _, traj_o, _ = orc.rollout(t, oc, z0, 300, record=True)
     _, traj, st = emu_rollout(emu, orc, t, oc, z0, 300)
     assert (st > 0).all() and np.abs(traj - traj_o).max() < 1e-9
+
+
+def test_emulated_maximum_size_32_bodies(cclqr, orc, emu):
+    """the largest mechanism the device path takes (CCLQR_MAXL = 32 links: cart + 31 links) and the first one it refuses"""
+    ex = cclqr.examples.cartpole_n(31)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, 31)
+    rng = np.random.default_rng(8)
+    K = rng.normal(size=(1, 1, 12 * 32)) * 0.02
+    phi = rng.uniform(-1, 1, (1, 31)) * 0.15
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(31, [0.2], phi)
+    oc = orc.ctrl_desc(32, [0], K=K, N=0, zd=zd)
+    _, traj_o, st_o = orc.rollout(t, oc, z0, 12, record=True)
+    _, traj, st = emu_rollout(emu, orc, t, oc, z0, 12)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10

@@ -185,3 +185,36 @@ def test_cfg4_sawyer_8192_full_horizon(cclqr, orc):
     zo, _, sto = orc.rollout(t, oc, z0[bad_i + good_i], 2000)
     assert (sto[:2] < 0).all() and (sto[2:] > 0).all()
     assert np.abs(zo[2:] - st.zT[good_i]).max() < 1e-9
+
+
+def test_maximum_mechanism_size_32_bodies(cclqr, orc):
+    """CCLQR_MAXL = 32 links (cart + 31 links; mx = 384, ml = 160): linearisation, the tiled Riccati sweep and a batched rollout against
+    the oracle; 33 bodies are refused with CCLQR_EUNSUPPORTED"""
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(31)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, 31)
+    mech = capi.MechHandle(t)
+    A, Bu, Bl, G = (m[0] for m in capi.linearize(mech, zd[None], [0], np.zeros((1, 1))))
+    Ao, Buo, Blo, Go = orc.linearize(t, zd, [0], np.zeros(1))
+    for X, Xo in ((A, Ao), (Bu, Buo), (Bl, Blo), (G, Go)):
+        assert np.abs(X - Xo).max() < 1e-8 * max(1.0, np.abs(Xo).max())
+    Q, R = np.eye(384) * t.dt, np.eye(1) * t.dt
+    N = 40
+    K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N)
+    Ko, kbo = orc.riccati(Ao, Buo, Blo, Go, Q, R, N)
+    assert kb == kbo and np.abs(K - Ko).max() < 1e-7 * max(1.0, np.abs(Ko).max())
+    rng = np.random.default_rng(8)
+    n = 96
+    phi = rng.uniform(-1, 1, (n, 31)) * 0.1
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(31, rng.uniform(-0.3, 0.3, n), phi)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=N, zd=zd)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, 30, record=True)
+    zo, traj_o, sto = orc.rollout(t, orc.ctrl_desc(32, [0], K=K, N=N, zd=zd), z0, 30, record=True)
+    assert (st > 0).all() and (sto > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-9
+    big = cclqr.examples.cartpole_n(32)["mech"].tables()
+    with pytest.raises(capi.CclqrError) as e:
+        capi.MechHandle(big)
+    assert e.value.code == capi.EUNSUPPORTED
