@@ -148,20 +148,16 @@ HD void inv3(const double* A, double* Ai) {
 }
 
 // ------------------------------------------------------------------ counter-based standard normal (Philox-4x32-10 + Box-Muller)
-HD void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+HD double philox_normal(unsigned key0, unsigned long long instance, int k) {
     const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    unsigned c0 = (unsigned)(k - 1), c1 = 0u, c2 = 0u, c3 = 0u, k0 = key0, k1 = (unsigned)instance;
     for (int r = 0; r < 10; r++) {
-        unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
-        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += W0; k1 += W1;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-HD double philox_normal(unsigned key0, unsigned long long instance, int k) {
-    unsigned x[4];
-    philox4x32_10((unsigned)(k - 1), 0u, 0u, 0u, key0, (unsigned)instance, x);
-    const double u1 = ((double)x[0] + 0.5) * (1.0 / 4294967296.0), u2 = ((double)x[1] + 0.5) * (1.0 / 4294967296.0);
+    const double u1 = ((double)c0 + 0.5) * (1.0 / 4294967296.0), u2 = ((double)c1 + 0.5) * (1.0 / 4294967296.0);
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
 }
 
@@ -459,8 +455,6 @@ HD double ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& 
     return acc;
 }
 
-HD int link_parent(const MechDev* M, int l) { return ((M->start_mask >> l) & 1u) ? -1 : l - 1; }
-HD int link_child(const MechDev* M, int l) { return ((M->end_mask >> l) & 1u) ? -1 : l + 1; }
 
 // F3 (once per step, after the knot Jacobians): C_b = Gk_b(own joint)' lambda_b + Gk_a(child joint)' lambda_child
 HD void ph_force_map(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
@@ -591,8 +585,11 @@ HD bool ph_tri_elim(int t, int i, const TriPlan& P, const Lay& Y, double* L, dou
     if (i >= (front ? P.nB : P.nA)) return false;
     const int l = front ? P.cs + i : P.cs + P.cn - 1 - i;
     const int q = front ? l + 1 : l - 1;
-    const int oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * l;   // S_{q,l}
-    const int oLQ = front ? Y.SPJ + 25 * q : Y.SJP + 25 * l;   // S_{l,q}
+    // S_{q,l} / S_{l,q}: front 1 reads (SJP, SPJ) of q, front 0 (SPJ, SJP) of l.  Offsets by arithmetic on `front`: a lane-varying
+    // select between two layout offsets is turned into a scratch-memory table by the compiler
+    const int dsp = Y.SPJ - Y.SJP, ob = 25 * (l + front * (q - l));
+    const int oQL = Y.SJP + (1 - front) * dsp + ob;
+    const int oLQ = Y.SJP + front * dsp + ob;
     const bool isy = col == 5;
     // ---- loads: own right-hand side (a column of S_lq, or r_l), own target (a column of S_qq, or r_q), S_ql, S_ll
     const int orhs = isy ? Y.R + 5 * l : oLQ + col, srhs = isy ? 1 : 5;

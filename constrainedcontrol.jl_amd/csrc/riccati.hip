@@ -72,7 +72,7 @@ __device__ void wg_gemm(int M, int N, int K, double alpha, const double* __restr
 
 // in-place LU with partial pivoting of the n x n matrix A (row major, lda); piv[c] = pivot row of column c.  *sing set if a pivot is 0.
 template <typename MP>
-__device__ void wg_lu(int n, MP A, int lda, int* piv, int* sing, double* red_v, int* red_i) {
+__device__ void wg_lu(int n, MP A, int lda, int* piv, int* sing) {
     const int tid = threadIdx.x;
     for (int c = 0; c < n; c++) {
         // pivot search by the first wavefront
@@ -83,7 +83,7 @@ __device__ void wg_lu(int n, MP A, int lda, int* piv, int* sing, double* red_v, 
                 double ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (tid == 0) { piv[c] = bi; if (!(best > 0.0)) *sing = 1; red_v[0] = best; }
+            if (tid == 0) { piv[c] = bi; if (!(best > 0.0)) *sing = 1; }
         }
         __syncthreads();
         const int p = piv[c];
@@ -105,7 +105,6 @@ __device__ void wg_lu(int n, MP A, int lda, int* piv, int* sing, double* red_v, 
         }
         __syncthreads();
     }
-    (void)red_i;
 }
 // solve (LU) X = B for nrhs columns, B (n x nrhs, ldb) in place; one column per thread.
 // With Xs != nullptr the columns are processed in batches of CB staged in LDS (Xs[i*CB + thread]: conflict-free), so the
@@ -209,7 +208,6 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
     unsigned long long rt0 = __builtin_readcyclecounter();
 #endif
     __shared__ double red_v[RIC_WAVES];
-    __shared__ int red_i[4];
     __shared__ int sing;
     const int prob = blockIdx.x, tid = threadIdx.x;
     const int mx = a.mx, mu = a.mu, ml = a.ml, N = a.N, na = mx + mu;
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
                 wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, w.GBl, ml);          // M22 = G*Bλ                  lqr.jl:155
                 wg_gemm<false>(ml, na, mx, 1.0, G, mx, w.AD, na, 0.0, w.X, na);          // [G*A | G*Bu]               lqr.jl:158,154
                 if (LDSM) { for (int e = tid; e < ml * ml; e += RIC_THREADS) GBl[e] = w.GBl[e]; __syncthreads(); }
-                wg_lu<MP>(ml, GBl, ml, w.piv, &sing, red_v, red_i);
+                wg_lu<MP>(ml, GBl, ml, w.piv, &sing);
                 if (!sing) {
                     wg_lu_solve<MP>(ml, GBl, ml, w.piv, w.X, na, na, Xs, CB);            // X = [F | E]
                     wg_gemm<false>(mx, na, ml, -1.0, Bl, ml, w.X, na, 1.0, w.AD, na);
@@ -262,7 +260,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
         for (int e = tid; e < mu * mu; e += RIC_THREADS) w.S[e] = a.R[e] + w.TS[(size_t)(e / mu) * na + mx + e % mu];
         for (int e = tid; e < mu * mx; e += RIC_THREADS) w.Ku[e] = w.TS[(size_t)(e / mx) * na + e % mx];
         __syncthreads();
-        wg_lu<double*>(mu, w.S, mu, w.piv + ml + 4, &sing, red_v, red_i);
+        wg_lu<double*>(mu, w.S, mu, w.piv + ml + 4, &sing);
         if (sing) { status = CCLQR_ESINGULAR_; break; }
         wg_lu_solve<double*>(mu, w.S, mu, w.piv + ml + 4, w.Ku, mx, mx, nullptr, 0);
         const double* Ku = w.Ku;
@@ -345,8 +343,6 @@ template <bool LDSM>
 __global__ __launch_bounds__(RIC_THREADS) void ric_project_kernel(RicGrid a, int lds_cols) {
     extern __shared__ double lds_M[];
     typedef typename std::conditional<LDSM, lds_double*, double*>::type MP;
-    __shared__ double red_v[RIC_WAVES];
-    __shared__ int red_i[4];
     __shared__ int sing;
     const int knot = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
     const int mx = a.mx, mu = a.mu, ml = a.ml, na = a.na;
@@ -371,7 +367,7 @@ __global__ __launch_bounds__(RIC_THREADS) void ric_project_kernel(RicGrid a, int
         wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, GBlg, ml);                   // G*Bλ                         lqr.jl:155
         wg_gemm<false>(ml, na, mx, 1.0, G, mx, AD, na, 0.0, X, na);                      // [G*A | G*Bu]                 lqr.jl:158,154
         if (LDSM) { for (int e = tid; e < ml * ml; e += RIC_THREADS) GBl[e] = GBlg[e]; __syncthreads(); }
-        wg_lu<MP>(ml, GBl, ml, piv, &sing, red_v, red_i);
+        wg_lu<MP>(ml, GBl, ml, piv, &sing);
         if (sing) { if (tid == 0) { a.status[prob] = CCLQR_ESINGULAR_; a.stop[prob] = 1; a.kbreak[prob] = knot + 1; } return; }
         wg_lu_solve<MP>(ml, GBl, ml, piv, X, na, na, Xs, LDSM ? lds_cols : 0);           // X = (G Bλ)^-1 G [A | Bu]
         wg_gemm<false>(mx, na, ml, -1.0, Bl, ml, X, na, 1.0, AD, na);                    // [A' | D]                     lqr.jl:151

@@ -156,6 +156,12 @@ function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, ste
     traj, zT, status
 end
 
+"Riccati launch shape: 0 = by problem size, 1 = one persistent workgroup per problem, 2 = tiled over the device (same results)."
+riccati_path!(path::Integer) = check(ccall((:cclqr_riccati_path, lib), Cint, (Int32,), path))
+
+"Global index of instance 1 of the following simulate_batch! calls (Philox noise streams are keyed by global instance index)."
+instance_offset!(first::Integer) = check(ccall((:cclqr_set_instance_offset, lib), Cint, (Int64,), first))
+
 "Storage{T}(steps, Nb) view of instance n of a batched trajectory: storage.x[i][k] etc. (lqr_tracking.jl:32-35)."
 function storage_fields(traj::Array{Float64,4}, n::Integer)
     nb, steps = size(traj, 2), size(traj, 3)
