@@ -42,6 +42,19 @@ void orc_flops_reset(void) {
     g_flops = 0.0;
 #endif
 }
+/* Newton statistics of the instrumented build: [0..15] line-search halvings summed per iteration index, [16..31] iterations reaching that
+ * index, [32..47] histogram of -log10(alpha |ds|) of each solve's LAST iteration (bin b: 1e-(b+1) <= . < 1e-b), [48..58] histogram of halvings in the last iteration */
+#ifdef ORC_COUNT_FLOPS
+static double g_nstat[64];
+#pragma omp threadprivate(g_nstat)
+#endif
+void orc_newton_stats(double *out, int reset) {
+#ifdef ORC_COUNT_FLOPS
+    for (int i = 0; i < 64; i++) { out[i] = g_nstat[i]; if (reset) g_nstat[i] = 0.0; }
+#else
+    (void)out; (void)reset;
+#endif
+}
 
 /* ------------------------------------------------------------------ small dense helpers (row major) */
 /* C(m x n) = beta*C + alpha * op(A) * op(B);  ta/tb: 0 = as is, 1 = transposed. lda/ldb/ldc = row strides */
@@ -549,12 +562,13 @@ static int newton(const mech_t *M, const double *z, double *s, double *lam, work
         residual(M, z, s, lam, W, 1);
         if (tree_ldu_solve(M, W, ds, dl)) return -it;
         double alpha = 1.0, normf1 = 0.0;
+        int halvings = 0;
         for (int ls = 0; ls <= LINE_MAXIT; ls++) {
             for (int i = 0; i < 6 * nb; i++) st[i] = s[i] - alpha * ds[i];
             for (int i = 0; i < 5 * ne; i++) lt[i] = lam[i] - alpha * dl[i];
             FL(2 * 11 * nb);
             normf1 = residual(M, z, st, lt, W, 0);
-            if (normf1 > normf0 && ls < LINE_MAXIT) alpha *= 0.5; else break;
+            if (normf1 > normf0 && ls < LINE_MAXIT) { alpha *= 0.5; halvings++; } else break;
         }
         double nd = 0.0;
         for (int i = 0; i < 6 * nb; i++) nd += ds[i] * ds[i];
@@ -562,6 +576,12 @@ static int newton(const mech_t *M, const double *z, double *s, double *lam, work
         nd = alpha * sqrt(nd);
         memcpy(s, st, sizeof(double) * 6 * nb);
         memcpy(lam, lt, sizeof(double) * 5 * ne);
+#ifdef ORC_COUNT_FLOPS
+        { int ii = it < 16 ? it - 1 : 15; g_nstat[ii] += halvings; g_nstat[16 + ii] += 1.0;
+          if (normf1 < NEWTON_EPS && nd < NEWTON_EPS) { int b = nd > 0 ? (int)floor(-log10(nd)) : 15; if (b < 0) b = 0; if (b > 15) b = 15; g_nstat[32 + b] += 1.0; g_nstat[48 + halvings] += 1.0; } }
+#else
+        (void)halvings;
+#endif
         if (normf1 < NEWTON_EPS && nd < NEWTON_EPS) return it;
         normf0 = normf1;
     }

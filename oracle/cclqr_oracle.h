@@ -113,6 +113,8 @@ double orc_philox_normal(uint64_t seed, uint64_t instance, int k);
 /* flop counter (instrumented build only: -DORC_COUNT_FLOPS), see SURVEY 8d */
 double orc_flops_get(void);
 void orc_flops_reset(void);
+/* Newton / line-search statistics of the calling thread (instrumented build only; layout documented at the definition) */
+void orc_newton_stats(double *out64, int reset);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,15 @@ def philox_normal(seed, instance, k):
     return L.orc_philox_normal(C.c_uint64(seed), C.c_uint64(instance), C.c_int(k))
 
 
+def newton_stats(reset=True):
+    """instrumented build only: (halvings per iteration index [16], solves reaching that index [16], histogram of -log10(alpha|d|) of the
+    last iteration [16], histogram of halvings in the last iteration [11]) accumulated by the calling thread"""
+    out = (C.c_double * 64)()
+    lib(True).orc_newton_stats(out, C.c_int(1 if reset else 0))
+    v = np.array(list(out))
+    return v[0:16], v[16:32], v[32:48], v[48:59]
+
+
 def flops_reset():
     lib(True).orc_flops_reset()
 
