@@ -97,8 +97,8 @@ extern "C" int cclqr_set_instance_offset(int64_t first_instance) { g_inst0 = fir
 
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
-    if (lanes) *lanes = rollout_lanes_per_instance(m->nb);
-    if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb);
+    if (lanes) *lanes = rollout_lanes_per_instance(m->nb, m->host.tree);
+    if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs);
     return CCLQR_OK;
 }
 
@@ -109,11 +109,11 @@ extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
-    if (rollout_lds_bytes(m->nb) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    if (rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = noise;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = g_inst0;
-    HIPCHK(launch_rollout(a, m->nb, (hipStream_t)stream));
+    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, (hipStream_t)stream));
     return CCLQR_OK;
 }
 
@@ -154,7 +154,7 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     if (nk == 0) return CCLQR_OK;
     const int nb = m->nb;
     const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb;
-    if (linearize_lds_bytes(nb) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    if (linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     LinArgs a;
     memset(&a, 0, sizeof(a));
     a.M = m->dev; a.nk = nk; a.mu = mu;
@@ -175,7 +175,7 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
     a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
-    if (e == hipSuccess) e = launch_linearize(a, nb, nullptr);
+    if (e == hipSuccess) e = launch_linearize(a, nb, m->host.tree, m->host.npairs, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(A, dA, nk * mx * mx * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mu > 0) e = hipMemcpy(Bu, dBu, nk * mx * mu * sizeof(double), hipMemcpyDeviceToHost);
@@ -279,7 +279,7 @@ extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int
     if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
     a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
-    if (e == hipSuccess) e = launch_linearize(a, nb, nullptr);
+    if (e == hipSuccess) e = launch_linearize(a, nb, m->host.tree, m->host.npairs, nullptr);
     if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nk * sizeof(int), hipMemcpyDeviceToHost);
     int rc = CCLQR_OK;
     if (e == hipSuccess) {

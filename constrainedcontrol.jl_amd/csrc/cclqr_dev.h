@@ -18,6 +18,8 @@
 #include <stdint.h>
 
 #define CCLQR_MAXL 32          // links per mechanism supported by the device path
+#define CCLQR_MAXK 4           // child joints per body (general trees)
+#define CCLQR_MAXP 48          // sibling pairs (joints that share their parent body)
 #define HD __host__ __device__ __forceinline__
 
 namespace cclqr {
@@ -39,6 +41,18 @@ struct MechDev {
     double m[CCLQR_MAXL], J[CCLQR_MAXL][9];
     double p1[CCLQR_MAXL][3], p2[CCLQR_MAXL][3], axis[CCLQR_MAXL][3], qoc[CCLQR_MAXL][4]; // qoc = conj(qoffset)
     double sel[CCLQR_MAXL][5][3]; // row r of the joint = sel[r] . (translational | rotational 3-vector)
+    // ---- general trees (tree != 0: some body carries several child joints; links are numbered depth-first, first child = l+1).
+    // The Schur complement on the multipliers then couples the joints around a body pairwise (siblings), and the solve is the
+    // table-driven elimination below instead of the chains' two-front sweep.
+    int tree;
+    int nchild[CCLQR_MAXL], child[CCLQR_MAXL][CCLQR_MAXK];   // child links of body l
+    int npairs, pair_i[CCLQR_MAXP], pair_j[CCLQR_MAXP];      // sibling pairs i < j: LDS blocks SS[2p] = S_ij, SS[2p+1] = S_ji
+    // elimination program, links in reverse order: when l is eliminated its remaining neighbours are x_0 .. x_{nn-1}
+    // (the parent joint and the siblings with a smaller index); all offsets are LDS offsets of 5x5 blocks in the instance layout
+    int el_nn[CCLQR_MAXL], el_x[CCLQR_MAXL][CCLQR_MAXK];
+    int el_lx[CCLQR_MAXL][CCLQR_MAXK];                 // S_{l,x_g}   (holds Z_{l,x_g} = S_ll^-1 S_{l,x_g} afterwards)
+    int el_xl[CCLQR_MAXL][CCLQR_MAXK];                 // S_{x_g,l}
+    int el_t[CCLQR_MAXL][CCLQR_MAXK][CCLQR_MAXK];      // [g'][g]: S_{x_g',x_g}
 };
 
 // ---- controller tables in device memory ----
@@ -61,10 +75,10 @@ struct CtrlDev {
 // ---- LDS layout of one instance (offsets in doubles) ----
 // NB holds N(w+) D_R^-1 (so that the joint evaluation emits W = G_v D^-1 directly)
 struct Lay {
-    int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, C, CD, DZ, total;
+    int Z, S, ST, LAM, LT, DS, DL, XQ, NB, DINV, DTM, D, G, R, GKA, GKB, GVA, GVB, SJJ, SJP, SPJ, UJ, C, CD, SS, DZ, total;
 };
 #define BLK 31   // stride of a 5x6 block (30 used; odd stride keeps ds_read_b64 conflict-free across lanes)
-HD Lay make_layout(int nb) {
+HD Lay make_layout(int nb, int nss = 0) {   // nss: sibling blocks (2 per sibling pair), general trees only
     Lay L; int o = 0;
     L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;
     L.LAM = o; o += 5 * nb;  L.LT = o; o += 5 * nb;  L.DS = o; o += 6 * nb;  L.DL = o; o += 5 * nb;
@@ -75,6 +89,7 @@ HD Lay make_layout(int nb) {
     L.UJ = o; o += nb;
     L.C = o; o += 6 * nb;    // G_k' lambda at the accepted point
     L.CD = o; o += 6 * nb;   // G_k' dlambda of the current Newton step
+    L.SS = o; o += 25 * nss;
     L.DZ = L.GVA;            // control error aliases the (dead at control time) Gv storage: 12 nb <= 31 nb
     L.total = o | 1;         // odd instance stride
     return L;
@@ -338,6 +353,7 @@ HD double ph_gain_partial(int t, int G, int nb, const Lay& Y, const double* L, c
 }
 
 // F1: joint inputs -> force/torque on the owned body, per-step invariants, solution guess (SURVEY 8a-bis 'Joint input')
+template <bool TREE = false>
 HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M) {
     if (t >= nb) return;
     const double dt = M->dt;
@@ -353,8 +369,9 @@ HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const Mec
         if (r.type == 1) { double c[3]; cross3(r.p2, fb, c); for (int i = 0; i < 3; i++) { F[i] += fw[i]; tau[i] += c[i]; } }
         else for (int i = 0; i < 3; i++) tau[i] += fb[i];
     }
-    int c = r.childl;
-    if (c >= 0) {     // child joint: this body is the parent
+    const int nch = TREE ? M->nchild[t] : (r.childl >= 0 ? 1 : 0);
+    for (int ci = 0; ci < nch; ci++) {     // child joints: this body is the parent
+        const int c = TREE ? M->child[t][ci] : r.childl;
         double uc = L[Y.UJ + c];
         if (uc != 0.0) {
             double f[3] = {M->axis[c][0] * uc, M->axis[c][1] * uc, M->axis[c][2] * uc};
@@ -674,6 +691,165 @@ HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned en
             tv[c] = d[c] + cd[c];
         }
         double o[6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { o[c] = tv[c] * dtm; o[3 + c] = Di[3 * c] * tv[3] + Di[3 * c + 1] * tv[4] + Di[3 * c + 2] * tv[5]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { L[Y.DS + 6 * b + c] = o[c]; L[Y.CD + 6 * b + c] = cd[c]; }
+    }
+}
+
+// ================================================================== general trees (MechDev::tree)
+// F3 for a body with any number of child joints: C_b = Gk_b(own joint)' lambda_b + sum_children Gk_a(child)' lambda_child
+HD void ph_force_map_tree(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    for (int b = t; b < nb; b += G) {
+        double acc[6];
+        {
+            double gb[30], lb[5];
+#pragma unroll
+            for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lb[i] = L[Y.LAM + 5 * b + i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[c] = gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4];
+        }
+        for (int ci = 0; ci < M->nchild[b]; ci++) {
+            const int ch = M->child[b][ci];
+            double ga[30], lc[5];
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * ch + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = L[Y.LAM + 5 * ch + i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[c] += ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { L[Y.C + 6 * b + c] = acc[c]; L[Y.CD + 6 * b + c] = 0.0; }
+    }
+}
+
+// S2 for trees.  Same task shape as ph_schur_s (two 6-vectors against two 5x6 blocks):
+//   part 0 (joint j, row):  row of S_jj and r_j, parent from the table
+//   part 1 (joint j with a parent joint p, row):  rows of S_jp and S_pj
+//   part 2 (sibling pair (i, j), row):  row of S_ij = W_a[i] Gk_a[j]'  and of  S_ji = W_a[j] Gk_a[i]'
+HD void ph_schur_s_tree(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    const int ntask = 5 * (2 * nb + M->npairs);
+    for (int e = t; e < ntask; e += G) {
+        const int part = (e >= 10 * nb) ? 2 : ((e >= 5 * nb) ? 1 : 0);
+        const int e5 = e - part * 5 * nb;
+        const int idx = e5 / 5, row = e5 - 5 * idx;
+        int ov1, ov2, om1, om2, od1 = Y.D, od2 = Y.D, oo1, oo2;
+        double use2 = 1.0;
+        if (part == 2) {
+            const int i = M->pair_i[idx], j = M->pair_j[idx];
+            ov1 = Y.GVA + BLK * i + 6 * row; om1 = Y.GKA + BLK * j; oo1 = Y.SS + 25 * (2 * idx) + 5 * row;
+            ov2 = Y.GVA + BLK * j + 6 * row; om2 = Y.GKA + BLK * i; oo2 = Y.SS + 25 * (2 * idx + 1) + 5 * row;
+        } else {
+            const int j = idx, pp = M->parent[j];
+            const bool has_p = pp >= 0;
+            if (part && !has_p) continue;
+            const int p = has_p ? pp : j;
+            ov1 = (part ? Y.GVA + BLK * j : Y.GVB + BLK * j) + 6 * row;
+            ov2 = (part ? Y.GVB + BLK * p : Y.GVA + BLK * j) + 6 * row;
+            om1 = part ? Y.GKB + BLK * p : Y.GKB + BLK * j;
+            om2 = Y.GKA + BLK * j;
+            od1 = Y.D + 6 * j; od2 = Y.D + 6 * p;
+            use2 = (part || has_p) ? 1.0 : 0.0;
+            oo1 = (part ? Y.SJP : Y.SJJ) + 25 * j + 5 * row;
+            oo2 = Y.SPJ + 25 * j + 5 * row;
+        }
+        double v1[6], v2[6], m1[30], m2[30], d1[6], d2[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { v1[i] = L[ov1 + i]; v2[i] = L[ov2 + i]; d1[i] = L[od1 + i]; d2[i] = L[od2 + i]; }
+#pragma unroll
+        for (int i = 0; i < 30; i++) { m1[i] = L[om1 + i]; m2[i] = L[om2 + i]; }
+        double o1[5], o2[5];
+#pragma unroll
+        for (int col = 0; col < 5; col++) { o1[col] = dot6(v1, m1 + 6 * col); o2[col] = use2 * dot6(v2, m2 + 6 * col); }
+        if (part == 0) {
+            const double g0 = L[Y.G + 5 * idx + row];
+            const double rr = g0 - dot6(v1, d1) - use2 * dot6(v2, d2);
+#pragma unroll
+            for (int col = 0; col < 5; col++) L[oo1 + col] = o1[col] + o2[col];
+            L[Y.R + 5 * idx + row] = rr;
+        } else {
+#pragma unroll
+            for (int col = 0; col < 5; col++) { L[oo1 + col] = o1[col]; L[oo2 + col] = o2[col]; }
+        }
+    }
+}
+
+// S3 for trees: eliminate link l (links are taken in reverse order, so its whole subtree is already folded into S_ll and r_l).
+// Lane (g = t >> 3, c = t & 7): group g < nn owns neighbour x_g; lanes c < 5 solve column c of Z_{l,x_g} = S_ll^-1 S_{l,x_g}
+// and subtract S_{x',l} z from column c of S_{x',x_g} for every neighbour x'; lane (0, 5) does the same with y = S_ll^-1 r_l
+// on the right-hand sides.  Z overwrites S_{l,x_g}, y overwrites r_l.  A root with nothing left above it only computes y.
+HD void ph_tree_elim(int t, int l, const Lay& Y, double* L, const MechDev* M) {
+    const int g = t >> 3, c = t & 7, nn = M->el_nn[l];
+    const bool isy = (g == 0 && c == 5);
+    if (!(isy || (g < nn && c < 5))) return;
+    double lu[25], zy[5];
+    const int orhs = isy ? Y.R + 5 * l : M->el_lx[l][g] + c, srhs = isy ? 1 : 5;
+#pragma unroll
+    for (int r = 0; r < 5; r++) zy[r] = L[orhs + srhs * r];
+    lu5(L, Y.SJJ + 25 * l, lu);
+    lu5_solve(lu, zy);
+    for (int gp = 0; gp < nn; gp++) {
+        const int oxl = M->el_xl[l][gp];
+        const int otgt = isy ? Y.R + 5 * M->el_x[l][gp] : M->el_t[l][gp][g] + c;
+        double sxl[25], tg[5];
+#pragma unroll
+        for (int i = 0; i < 25; i++) sxl[i] = L[oxl + i];
+#pragma unroll
+        for (int r = 0; r < 5; r++) tg[r] = L[otgt + srhs * r];
+#pragma unroll
+        for (int r = 0; r < 5; r++) tg[r] -= sxl[5 * r] * zy[0] + sxl[5 * r + 1] * zy[1] + sxl[5 * r + 2] * zy[2] + sxl[5 * r + 3] * zy[3] + sxl[5 * r + 4] * zy[4];
+#pragma unroll
+        for (int r = 0; r < 5; r++) L[otgt + srhs * r] = tg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) L[orhs + srhs * r] = zy[r];
+}
+// back substitution for link l (links in forward order: every neighbour above l is already solved): dl_l = y_l - sum_g Z_{l,x_g} dl_{x_g}
+HD void ph_tree_back(int t, int l, const Lay& Y, double* L, const MechDev* M) {
+    if (t >= 5) return;
+    double acc = L[Y.R + 5 * l + t];
+    for (int g = 0; g < M->el_nn[l]; g++) {
+        const int oz = M->el_lx[l][g] + 5 * t, od = Y.DL + 5 * M->el_x[l][g];
+        acc -= L[oz] * L[od] + L[oz + 1] * L[od + 1] + L[oz + 2] * L[od + 2] + L[oz + 3] * L[od + 3] + L[oz + 4] * L[od + 4];
+    }
+    L[Y.DL + 5 * l + t] = acc;
+}
+
+// S4 for trees: ds_b = D_b^-1 (d_b + Gk_b(own joint)' dl_b + sum_children Gk_a(child)' dl_child)
+HD void ph_body_solve_tree(int t, int G, int nb, const Lay& Y, double* L, const MechDev* M) {
+    for (int b = t; b < nb; b += G) {
+        double d[6], Di[9], cd[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) d[i] = L[Y.D + 6 * b + i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Di[i] = L[Y.DINV + 9 * b + i];
+        const double dtm = L[Y.DTM + b];
+        {
+            double gb[30], lb[5];
+#pragma unroll
+            for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lb[i] = L[Y.DL + 5 * b + i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) cd[c] = gb[c] * lb[0] + gb[6 + c] * lb[1] + gb[12 + c] * lb[2] + gb[18 + c] * lb[3] + gb[24 + c] * lb[4];
+        }
+        for (int ci = 0; ci < M->nchild[b]; ci++) {
+            const int ch = M->child[b][ci];
+            double ga[30], lc[5];
+#pragma unroll
+            for (int i = 0; i < 30; i++) ga[i] = L[Y.GKA + BLK * ch + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) lc[i] = L[Y.DL + 5 * ch + i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) cd[c] += ga[c] * lc[0] + ga[6 + c] * lc[1] + ga[12 + c] * lc[2] + ga[18 + c] * lc[3] + ga[24 + c] * lc[4];
+        }
+        double tv[6], o[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) tv[c] = d[c] + cd[c];
 #pragma unroll
         for (int c = 0; c < 3; c++) { o[c] = tv[c] * dtm; o[3 + c] = Di[3 * c] * tv[3] + Di[3 * c + 1] * tv[4] + Di[3 * c + 2] * tv[5]; }
 #pragma unroll

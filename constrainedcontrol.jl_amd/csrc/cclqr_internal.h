@@ -24,9 +24,9 @@ struct RolloutArgs {
     int* status;          // [n_inst] or null
 };
 
-int rollout_lanes_per_instance(int nb);
-size_t rollout_lds_bytes(int nb);
-hipError_t launch_rollout(const RolloutArgs& a, int nb, hipStream_t stream);
+int rollout_lanes_per_instance(int nb, int tree);
+size_t rollout_lds_bytes(int nb, int tree, int npairs);
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream);
 
 struct LinArgs {
     const MechDev* M;
@@ -37,8 +37,8 @@ struct LinArgs {
     double *A, *Bu, *Bl, *G; // [nk][...] internal link order
     int* status;             // [nk]
 };
-size_t linearize_lds_bytes(int nb);
-hipError_t launch_linearize(const LinArgs& a, int nb, hipStream_t stream);
+size_t linearize_lds_bytes(int nb, int tree, int npairs);
+hipError_t launch_linearize(const LinArgs& a, int nb, int tree, int npairs, hipStream_t stream);
 
 struct RicArgs {
     int nprob, mx, mu, ml, N;

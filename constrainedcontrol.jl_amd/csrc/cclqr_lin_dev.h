@@ -170,8 +170,7 @@ HD void ph_lin_rows_A(int t, int nb, const Lay& Y, int JB, const double* L, cons
         make_N(w2n, sqrt(4.0 / (dt * dt) - (w2n[0] * w2n[0] + w2n[1] * w2n[1] + w2n[2] * w2n[2])), dt, N);
     }
     const double* own = L + JB + LJB * t;
-    const int a = r.parent, c = r.childl;
-    const double* ch = (c >= 0) ? L + JB + LJB * c : nullptr;
+    const int a = r.parent, nch = M->nchild[t];
     const int rb = 12 * M->perm[t];
     double* A = O.A;
     const int ld = O.mx;
@@ -181,7 +180,8 @@ HD void ph_lin_rows_A(int t, int nb, const Lay& Y, int JB, const double* L, cons
         double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         // x columns: dx+ = I (+ via FR[x_b] from the child joint)
         double frx[9];
-        for (int i = 0; i < 9; i++) frx[i] = ch ? ch[J_PRXA + i] : 0.0;
+        for (int i = 0; i < 9; i++) frx[i] = 0.0;
+        for (int ci = 0; ci < nch; ci++) { const double* ch = L + JB + LJB * M->child[t][ci]; for (int i = 0; i < 9; i++) frx[i] += ch[J_PRXA + i]; }
         body_cols(A, ld, rb, cb, nullptr, frx, Dinv, N, dtm, dt);
         for (int i = 0; i < 3; i++) A[(size_t)(rb + i) * ld + cb + i] += 1.0;
         // v columns: dv+ = I, dx+ = dt I
@@ -189,7 +189,8 @@ HD void ph_lin_rows_A(int t, int nb, const Lay& Y, int JB, const double* L, cons
         put3(A, ld, rb, cb + 3, dtI); put3(A, ld, rb + 3, cb + 3, I3); put3(A, ld, rb + 6, cb + 3, Z9); put3(A, ld, rb + 9, cb + 3, Z9);
         // qtilde columns: FT from the child joint (PTQ), FR from own joint (RQB) and child joint (PRQA); plus the kinematic term Eqq
         double ftq[9], frq[9];
-        for (int i = 0; i < 9; i++) { ftq[i] = ch ? ch[J_PTQ + i] : 0.0; frq[i] = own[J_RQB + i] + (ch ? ch[J_PRQA + i] : 0.0); }
+        for (int i = 0; i < 9; i++) { ftq[i] = 0.0; frq[i] = own[J_RQB + i]; }
+        for (int ci = 0; ci < nch; ci++) { const double* ch = L + JB + LJB * M->child[t][ci]; for (int i = 0; i < 9; i++) { ftq[i] += ch[J_PTQ + i]; frq[i] += ch[J_PRQA + i]; } }
         body_cols(A, ld, rb, cb + 6, ftq, frq, Dinv, N, dtm, dt);
         const double* w2 = L + Y.S + 6 * t + 3;
         double sq2 = sqrt(4.0 / (dt * dt) - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
@@ -214,7 +215,9 @@ HD void ph_lin_rows_A(int t, int nb, const Lay& Y, int JB, const double* L, cons
         const int ca = 12 * M->perm[a];
         body_cols(A, ld, rb, ca + 6, own + J_TQA, own + J_RQA, Dinv, N, dtm, dt);
     }
-    if (c >= 0) {   // child columns: through the child joint (this body is its parent)
+    for (int ci = 0; ci < nch; ci++) {   // child columns: through each child joint (this body is its parent)
+        const int c = M->child[t][ci];
+        const double* ch = L + JB + LJB * c;
         const int cc = 12 * M->perm[c];
         double nfrx[9];
         for (int i = 0; i < 9; i++) nfrx[i] = -ch[J_PRXA + i];
@@ -248,11 +251,10 @@ HD void ph_lin_rows_B(int t, int nb, const Lay& Y, const double* L, const LaneRe
         make_N(w2n, sqrt(4.0 / (dt * dt) - (w2n[0] * w2n[0] + w2n[1] * w2n[1] + w2n[2] * w2n[2])), dt, N);
     }
     const int rb = 12 * M->perm[t];
-    const int c = r.childl;
+    const int nch = M->nchild[t];
     // the joint of link l is the caller's joint jperm(l): constraint rows keep the caller's joint numbering
-    for (int side = 0; side < 2; side++) {
-        int j = side ? c : t;
-        if (j < 0) continue;
+    for (int side = 0; side <= nch; side++) {   // own joint (this body is the child), then every child joint (this body is the parent)
+        const int j = side ? M->child[t][side - 1] : t;
         const double* Gk = L + (side ? Y.GKA : Y.GKB) + BLK * j;
         for (int row = 0; row < 5; row++)
             body_col1(O.Bl, O.ml, rb, 5 * M->jperm[j] + row, Gk + 6 * row, Gk + 6 * row + 3, Dinv, N, dtm, dt, false);
@@ -270,7 +272,8 @@ HD void ph_lin_rows_B(int t, int nb, const Lay& Y, const double* L, const LaneRe
             if (r.type == 1) { double cr[3]; cross3(r.p2, yb, cr); for (int q = 0; q < 3; q++) { ft[q] = Raa[q]; fr[q] = 2.0 * cr[q]; } }
             else for (int q = 0; q < 3; q++) fr[q] = 2.0 * yb[q];
             hit = true;
-        } else if (j == c && c >= 0) {   // this body is the parent of the controlled joint
+        } else if (j >= 0 && j < nb && M->parent[j] == t) {   // this body is the parent of the controlled joint
+            const int c = j;
             double Rb[9], Raa[3];
             rotmat(L + Y.Z + 13 * t + 3, Rb);
             const double* ax = M->axis[c];

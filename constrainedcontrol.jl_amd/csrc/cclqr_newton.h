@@ -80,7 +80,7 @@ __device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double
 // valid=false groups only keep the wave's control flow uniform.  Returns iterations used; *converged reports success.
 // After a successful return DINV/NB/GV* hold the values at the solution only if the last accepted trial was a full step
 // (callers that need them -- the linearisation -- re-evaluate).
-template <int G>
+template <int G, bool TREE = false>
 __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt, bool valid,
                                             bool* converged PROF_ARG) {
     double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
@@ -92,6 +92,25 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
     for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
         if (!__any(!done)) break;
         PCOUNT(PF_NEWTON_ITERS);
+        if (TREE) {
+            // general tree: sibling-coupled Schur complement, table-driven elimination leaves -> roots, back substitution roots -> leaves
+            if (!done) ph_schur_s_tree(t, G, nb, Y, L, M);
+            __syncthreads();
+            STAMP(PF_SCHUR_S);
+            for (int l = nb - 1; l >= 0; l--) {
+                if (!done) ph_tree_elim(t, l, Y, L, M);
+                __syncthreads();
+            }
+            STAMP(PF_TRI_FWD);
+            for (int l = 0; l < nb; l++) {
+                if (!done) ph_tree_back(t, l, Y, L, M);
+                __syncthreads();
+            }
+            STAMP(PF_TRI_BWD);
+            if (!done) ph_body_solve_tree(t, G, nb, Y, L, M);
+            __syncthreads();
+            STAMP(PF_BODY_SOLVE);
+        } else {
         // Schur complement on the multipliers
         if (!done) ph_schur_s(t, G, nb, Y, L, smask);
         __syncthreads();
@@ -119,6 +138,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         if (!done) ph_body_solve(t, G, nb, Y, L, emask);
         __syncthreads();
         STAMP(PF_BODY_SOLVE);
+        }
         // line search: halve while ||f|| grows.  The first (full-step) trial also evaluates the Jacobians, speculating that it
         // is accepted; later trials evaluate the residual only.
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;

@@ -41,23 +41,38 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
         if (a >= 0) nchild[a]++;
         if (d->type[j] != CCLQR_REVOLUTE && d->type[j] != CCLQR_PRISMATIC) { err = "unknown joint type"; return CCLQR_EINVAL; }
     }
-    for (int b = 0; b < nb; b++)
-        if (nchild[b] > 1) { err = "a body with more than one child joint (branching tree) is not supported yet"; return CCLQR_EUNSUPPORTED; }
-    // link order: chain by chain (every body has at most one child joint, so the mechanism is a forest of chains), root to leaf
+    bool tree = false;
+    int npairs_total = 0;
+    for (int b = 0; b < nb; b++) {
+        if (nchild[b] > CCLQR_MAXK) { err = "a body with more than 4 child joints is not supported"; return CCLQR_EUNSUPPORTED; }
+        if (nchild[b] > 1) { tree = true; npairs_total += nchild[b] * (nchild[b] - 1) / 2; }
+    }
+    if (npairs_total > CCLQR_MAXP) { err = "too many sibling joint pairs"; return CCLQR_EUNSUPPORTED; }
+    // link order: depth first from the origin, children in the caller's joint order; the first child of a body continues its
+    // chain (link l+1), further children start new chains.  A forest of chains (no body with two child joints) therefore keeps
+    // the chain-contiguous numbering the two-front sweep relies on.
     std::vector<int> bfs, cstart, clen;
-    for (int j = 0; j < nb; j++)
-        if (d->parent[j] == -1) {
-            cstart.push_back((int)bfs.size());
-            int b = d->child[j];
-            while (b >= 0) {
-                bfs.push_back(b);
-                int nxt = -1;
-                for (int k = 0; k < nb; k++) if (d->parent[k] == b) nxt = d->child[k];
-                b = nxt;
-                if ((int)bfs.size() > nb) break;
+    {
+        std::vector<int> stack;
+        for (int j = nb - 1; j >= 0; j--)
+            if (d->parent[j] == -1) stack.push_back(d->child[j]);
+        int prev = -2;
+        while (!stack.empty()) {
+            int b = stack.back();
+            stack.pop_back();
+            if ((int)bfs.size() >= nb) { bfs.push_back(b); break; }
+            const int par = d->parent[pj[b]];
+            if (!(prev >= 0 && par == prev)) {   // does not continue the previous link: a new chain starts here
+                if (!cstart.empty()) clen.push_back((int)bfs.size() - cstart.back());
+                cstart.push_back((int)bfs.size());
             }
-            clen.push_back((int)bfs.size() - cstart.back());
+            bfs.push_back(b);
+            prev = b;
+            for (int k = nb - 1; k >= 0; k--)
+                if (d->parent[k] == b) stack.push_back(d->child[k]);
         }
+        if (!cstart.empty()) clen.push_back((int)bfs.size() - cstart.back());
+    }
     if ((int)bfs.size() != nb) { err = "mechanism is not a tree rooted at the origin"; return CCLQR_EINVAL; }
 
     memset(&m->host, 0, sizeof(MechDev));
@@ -92,7 +107,13 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
             for (int i = 0; i < 3; i++) H.sel[l][r][i] = (nrows == 3) ? (i == q ? 1.0 : 0.0) : V12[3 * q + i];
         }
     }
-    for (int l = 0; l < nb; l++) if (H.parent[l] >= 0) H.childl[H.parent[l]] = l;
+    for (int l = 0; l < nb; l++)
+        if (H.parent[l] >= 0) {
+            const int a = H.parent[l];
+            if (H.nchild[a] == 0) H.childl[a] = l;
+            H.child[a][H.nchild[a]++] = l;
+        }
+    H.tree = tree ? 1 : 0;
     H.nchains = (int)cstart.size();
     H.start_mask = 0; H.end_mask = 0;
     for (int c = 0; c < H.nchains; c++) {
@@ -100,8 +121,43 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
         H.start_mask |= 1u << cstart[c];
         H.end_mask |= 1u << (cstart[c] + clen[c] - 1);
     }
-    for (int l = 0; l < nb; l++)
-        if (H.parent[l] != (((H.start_mask >> l) & 1u) ? -1 : l - 1)) { err = "internal: link order is not chain-contiguous"; return CCLQR_EINVAL; }
+    for (int l = 0; l < nb; l++) {
+        if (H.parent[l] >= l) { err = "internal: a link precedes its parent"; return CCLQR_EINVAL; }
+        if (!tree && H.parent[l] != (((H.start_mask >> l) & 1u) ? -1 : l - 1)) { err = "internal: link order is not chain-contiguous"; return CCLQR_EINVAL; }
+    }
+    if (tree) {
+        // sibling pairs and the elimination program (links in reverse order; when l goes, what is left around its parent body
+        // is the parent's own joint and the siblings with a smaller index)
+        const Lay Y = make_layout(nb, 2 * npairs_total);
+        auto pair_of = [&](int i, int j) { for (int q = 0; q < H.npairs; q++) if (H.pair_i[q] == i && H.pair_j[q] == j) return q; return -1; };
+        for (int a = 0; a < nb; a++)
+            for (int x = 0; x < H.nchild[a]; x++)
+                for (int y = x + 1; y < H.nchild[a]; y++) { H.pair_i[H.npairs] = H.child[a][x]; H.pair_j[H.npairs] = H.child[a][y]; H.npairs++; }
+        // offset of the block S_{x', x} among two neighbours of an eliminated link (both hang off the same body, or one is its joint)
+        auto block = [&](int xr, int xc) {
+            if (xr == xc) return Y.SJJ + 25 * xr;
+            if (H.parent[xc] == xr) return Y.SPJ + 25 * xc;       // S_{parent, child}
+            if (H.parent[xr] == xc) return Y.SJP + 25 * xr;       // S_{child, parent}
+            const int q = xr < xc ? pair_of(xr, xc) : pair_of(xc, xr);
+            return Y.SS + 25 * (2 * q + (xr < xc ? 0 : 1));        // siblings: S_ij (i < j) then S_ji
+        };
+        for (int l = 0; l < nb; l++) {
+            int nn = 0;
+            const int a = H.parent[l];
+            if (a >= 0) {
+                H.el_x[l][nn++] = a;
+                for (int x = 0; x < H.nchild[a]; x++)
+                    if (H.child[a][x] < l) H.el_x[l][nn++] = H.child[a][x];
+            }
+            if (nn > CCLQR_MAXK) { err = "internal: too many neighbours in the elimination"; return CCLQR_EINVAL; }
+            H.el_nn[l] = nn;
+            for (int g = 0; g < nn; g++) {
+                H.el_lx[l][g] = block(l, H.el_x[l][g]);
+                H.el_xl[l][g] = block(H.el_x[l][g], l);
+                for (int gp = 0; gp < nn; gp++) H.el_t[l][gp][g] = block(H.el_x[l][gp], H.el_x[l][g]);
+            }
+        }
+    }
     return CCLQR_OK;
 }
 

@@ -9,6 +9,7 @@
 
 namespace cclqr {
 
+template <bool TREE>
 __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     extern __shared__ double lds[];
     constexpr int G = 64;
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     const MechDev* M = a.M;
     const int nb = M->nb, nz = 13 * nb, mx = 12 * nb, ml = 5 * nb, mu = a.mu;
     const double dt = M->dt;
-    const Lay Y = make_layout(nb);
+    const Lay Y = make_layout(nb, TREE ? 2 * M->npairs : 0);
     const int JB = Y.total;
     double* L = lds;
     LinOut O;
@@ -37,17 +38,18 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     if (t == 0)
         for (int i = 0; i < mu; i++) L[Y.UJ + a.cj[i]] += a.Fd ? a.Fd[(size_t)knot * mu + i] : 0.0;
     __syncthreads();
-    ph_forces(t, nb, Y, L, r, M);
+    ph_forces<TREE>(t, nb, Y, L, r, M);
     ph_knot_jac(t, nb, Y, L, r);
     __syncthreads();
-    ph_force_map(t, G, nb, Y, L, M->end_mask);
+    if (TREE) ph_force_map_tree(t, G, nb, Y, L, M);
+    else ph_force_map(t, G, nb, Y, L, M->end_mask);
     __syncthreads();
     bool done = false;
 #ifdef CCLQR_PROFILE
     Prof prof;
     prof.start();
 #endif
-    int its = newton_solve<G>(t, nb, Y, L, r, M, dt, true, &done PROF_PASS);
+    int its = newton_solve<G, TREE>(t, nb, Y, L, r, M, dt, true, &done PROF_PASS);
     __syncthreads();
     // D_R^-1 and the next pose at the converged solution (the last line-search trial may have been residual-only)
     ph_body_eval<true>(t, nb, Y, L, r, dt, Y.S, 0.0);
@@ -59,14 +61,16 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     if (t == 0 && a.status) a.status[knot] = done ? its : -its;
 }
 
-size_t linearize_lds_bytes(int nb) { return (size_t)(make_layout(nb).total + LJB * nb) * sizeof(double); }
+size_t linearize_lds_bytes(int nb, int tree, int npairs) { return (size_t)(make_layout(nb, tree ? 2 * npairs : 0).total + LJB * nb) * sizeof(double); }
 
-hipError_t launch_linearize(const LinArgs& a, int nb, hipStream_t stream) {
+hipError_t launch_linearize(const LinArgs& a, int nb, int tree, int npairs, hipStream_t stream) {
     if (a.nk <= 0) return hipSuccess;
-    const size_t lds = linearize_lds_bytes(nb);
-    hipError_t e = hipFuncSetAttribute((const void*)linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = linearize_lds_bytes(nb, tree, npairs);
+    const void* fn = tree ? (const void*)linearize_kernel<true> : (const void*)linearize_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(linearize_kernel, dim3(a.nk), dim3(64), lds, stream, a);
+    if (tree) hipLaunchKernelGGL(linearize_kernel<true>, dim3(a.nk), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL(linearize_kernel<false>, dim3(a.nk), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 
 namespace cclqr {
 
-template <int G>
+template <int G, bool TREE>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const CtrlDev* C = a.C;
     const int nb = M->nb;
     const double dt = M->dt;
-    const Lay Y = make_layout(nb);
+    const Lay Y = make_layout(nb, TREE ? 2 * M->npairs : 0);
     double* L = lds + grp * Y.total;
     const int nz = 13 * nb;
 
@@ -77,17 +77,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
         STAMP(PF_CONTROL);
         // ---------------- per-step invariants
-        ph_forces(t, nb, Y, L, r, M);
+        ph_forces<TREE>(t, nb, Y, L, r, M);
         ph_knot_jac(t, nb, Y, L, r);
         __syncthreads();
-        ph_force_map(t, G, nb, Y, L, M->end_mask);
+        if (TREE) ph_force_map_tree(t, G, nb, Y, L, M);
+        else ph_force_map(t, G, nb, Y, L, M->end_mask);
         __syncthreads();
         STAMP(PF_FORCES);
         PCOUNT(PF_STEPS);
 
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool done = false;
-        int its = newton_solve<G>(t, nb, Y, L, r, M, dt, valid && !dead, &done PROF_PASS);
+        int its = newton_solve<G, TREE>(t, nb, Y, L, r, M, dt, valid && !dead, &done PROF_PASS);
         if (valid && !dead) {
             if (!done) bad = true;
             if (its > worst) worst = its;
@@ -115,38 +116,34 @@ extern "C" int cclqr_prof_read(unsigned long long* out, int reset) {
 }
 #endif
 
-int rollout_lanes_per_instance(int nb) { return nb <= 4 ? 16 : (nb <= 8 ? 32 : 64); }
+// lanes per instance: one lane per link, and a tree needs 8 lanes per neighbour group of its elimination (up to CCLQR_MAXK groups)
+int rollout_lanes_per_instance(int nb, int tree) { return tree ? (nb <= 8 ? 32 : 64) : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64)); }
 
-size_t rollout_lds_bytes(int nb) {
-    int G = rollout_lanes_per_instance(nb);
-    return (size_t)(64 / G) * make_layout(nb).total * sizeof(double);
+size_t rollout_lds_bytes(int nb, int tree, int npairs) {
+    int G = rollout_lanes_per_instance(nb, tree);
+    return (size_t)(64 / G) * make_layout(nb, tree ? 2 * npairs : 0).total * sizeof(double);
 }
 
-hipError_t launch_rollout(const RolloutArgs& a, int nb, hipStream_t stream) {
-    const int G = rollout_lanes_per_instance(nb);
+template <int G, bool TREE>
+static hipError_t launch_one(const RolloutArgs& a, unsigned grid, size_t lds, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<G, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rollout_kernel<G, TREE>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream) {
+    const int G = rollout_lanes_per_instance(nb, tree);
     const int per_wg = 64 / G;
-    const size_t lds = rollout_lds_bytes(nb);
+    const size_t lds = rollout_lds_bytes(nb, tree, npairs);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
-    hipError_t e;
+    if (tree) return G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream);
     switch (G) {
-        case 16:
-            e = hipFuncSetAttribute((const void*)rollout_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(rollout_kernel<16>, dim3(grid), dim3(64), lds, stream, a);
-            break;
-        case 32:
-            e = hipFuncSetAttribute((const void*)rollout_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(rollout_kernel<32>, dim3(grid), dim3(64), lds, stream, a);
-            break;
-        default:
-            e = hipFuncSetAttribute((const void*)rollout_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(rollout_kernel<64>, dim3(grid), dim3(64), lds, stream, a);
-            break;
+        case 16: return launch_one<16, false>(a, grid, lds, stream);
+        case 32: return launch_one<32, false>(a, grid, lds, stream);
+        default: return launch_one<64, false>(a, grid, lds, stream);
     }
-    return hipGetLastError();
 }
 
 }  // namespace cclqr

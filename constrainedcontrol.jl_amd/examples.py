@@ -2,7 +2,7 @@
 Every number below is read from the cited script; nothing else of the scripts is reproduced."""
 import numpy as np
 
-from .mechanism import (Box, EqualityConstraint, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, setPosition)
+from .mechanism import (Box, EqualityConstraint, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, setJointPosition, setPosition)
 
 EX = np.array([1.0, 0.0, 0.0])
 EY = np.array([0.0, 1.0, 0.0])
@@ -166,3 +166,42 @@ def prismatic_slider():
     mech = Mechanism(origin, [link1], [joint], g=0.0)
     setPosition(origin, link1, Δx=[1.0, 0.0, 0.0])
     return dict(mech=mech, bodies=[link1], joints=[joint], Q=np.ones(1), R=np.ones(1), horizon=10.0)
+
+
+def dual_cartpole(φ1=0.1, φ2=-0.15, y0=0.2):
+    """Not one of the reference's scripts: the cart of lqr_cartpole.jl carrying TWO poles (lengths 1 and 0.6) on the same cart body --
+    the smallest mechanism whose body/joint tree branches (two child joints on one body)."""
+    origin = Origin()
+    cart = Box(0.1, 0.5, 0.1, 0.5)
+    pole1 = Box(0.1, 0.1, 1.0, 1.0)
+    pole2 = Box(0.1, 0.1, 0.6, 0.6)
+    j0 = EqualityConstraint(Prismatic(origin, cart, EY))
+    j1 = EqualityConstraint(Revolute(cart, pole1, EX, p1=np.array([0.0, 0.15, 0.0]), p2=np.array([0.0, 0.0, -0.5])))
+    j2 = EqualityConstraint(Revolute(cart, pole2, EX, p1=np.array([0.0, -0.15, 0.0]), p2=np.array([0.0, 0.0, -0.3])))
+    mech = Mechanism(origin, [cart, pole1, pole2], [j0, j1, j2], g=-9.81)
+    setJointPosition(mech, j0, y0)
+    setJointPosition(mech, j1, φ1)
+    setJointPosition(mech, j2, φ2)
+    return dict(mech=mech, bodies=[cart, pole1, pole2], joints=[j0, j1, j2], Q=[np.eye(12) for _ in range(3)], R=[np.ones((1, 1))], ctrl=[j0],
+                horizon=10.0, tend=10.0)
+
+
+def tree_mechanism(parents, seed=0, g=-9.81, prismatic=()):
+    """A random tree of 1-DoF joints for tests: body i hangs off body parents[i] (-1 = origin; parents[i] < i) through a revolute
+    (or, for i in `prismatic`, a prismatic) joint with random axis and anchor points; placed at random joint coordinates."""
+    rng = np.random.default_rng(seed)
+    origin = Origin()
+    bodies, joints = [], []
+    for i, a in enumerate(parents):
+        dims = rng.uniform(0.1, 0.6, 3)
+        b = Box(dims[0], dims[1], dims[2], float(rng.uniform(0.3, 1.5)))
+        bodies.append(b)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        par = origin if a < 0 else bodies[a]
+        kw = dict(p1=rng.uniform(-0.3, 0.3, 3), p2=rng.uniform(-0.3, 0.3, 3))
+        joints.append(EqualityConstraint((Prismatic if i in prismatic else Revolute)(par, b, axis, **kw)))
+    mech = Mechanism(origin, bodies, joints, g=g)
+    for e in joints:                                    # bodies are listed parents-first, so this places root to leaf
+        setJointPosition(mech, e, rng.uniform(-0.6, 0.6))
+    return dict(mech=mech, bodies=bodies, joints=joints)

@@ -24,6 +24,12 @@ static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRe
     int its = 0;
     int s_cur = Y.S, s_try = Y.ST, l_cur = Y.LAM, l_try = Y.LT;
     for (int iter = 1; iter <= 100 && !done; iter++) {
+        if (M->tree) {
+            for (int t = 0; t < G; t++) ph_schur_s_tree(t, G, nb, Y, L, M);
+            for (int l = nb - 1; l >= 0; l--) for (int t = 0; t < G; t++) ph_tree_elim(t, l, Y, L, M);
+            for (int l = 0; l < nb; l++) for (int t = 0; t < G; t++) ph_tree_back(t, l, Y, L, M);
+            for (int t = 0; t < G; t++) ph_body_solve_tree(t, G, nb, Y, L, M);
+        } else {
         for (int t = 0; t < G; t++) ph_schur_s(t, G, nb, Y, L, M->start_mask);
         for (int c = 0; c < M->nchains; c++) {
             const TriPlan P = tri_plan(M->chain_start[c], M->chain_len[c]);
@@ -38,6 +44,7 @@ static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRe
             for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ph_tri_back(t, j, P, Y, L);
         }
         for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M->end_mask);
+        }
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;
         bool jac_ok = true;
         for (int ls = 0; ls <= 10; ls++) {
@@ -76,8 +83,8 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
     const CtrlDev* C = &T.H;
     const int nb = M->nb, nz = 13 * nb;
     const double dt = M->dt;
-    const int G = G_override > 0 ? G_override : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64));
-    const Lay Y = make_layout(nb);
+    const int G = G_override > 0 ? G_override : (M->tree ? (nb <= 8 ? 32 : 64) : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64)));
+    const Lay Y = make_layout(nb, M->tree ? 2 * M->npairs : 0);
     std::vector<double> lds(Y.total);
     std::vector<LaneRegs> R(G);
     for (int64_t inst = 0; inst < n_inst; inst++) {
@@ -108,8 +115,8 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     L[Y.UJ + C->cj[i]] += u;
                 }
             if (C->has_pid) for (int t = 0; t < G; t++) ph_pid(t, nb, Y, L, R[t], C, dt, k == 1);
-            for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
-            for (int t = 0; t < G; t++) ph_force_map(t, G, nb, Y, L, M->end_mask);
+            for (int t = 0; t < G; t++) { if (M->tree) ph_forces<true>(t, nb, Y, L, R[t], M); else ph_forces<false>(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+            for (int t = 0; t < G; t++) { if (M->tree) ph_force_map_tree(t, G, nb, Y, L, M); else ph_force_map(t, G, nb, Y, L, M->end_mask); }
             bool done = false;
             int its = emu_newton(G, nb, Y, L, R, M, dt, &done);
             if (!done) bad = true;
@@ -133,7 +140,7 @@ extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu
     const MechDev* M = &m.host;
     const int nb = M->nb, nz = 13 * nb, mx = 12 * nb, ml = 5 * nb, G = 64;
     const double dt = M->dt;
-    const Lay Y = make_layout(nb);
+    const Lay Y = make_layout(nb, M->tree ? 2 * M->npairs : 0);
     const int JB = Y.total;
     std::vector<double> lds(Y.total + LJB * nb, 0.0);
     double* L = lds.data();
@@ -149,8 +156,8 @@ extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu
     for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t < nb ? t : 0);
     for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = zd[M->perm[l] * 13 + c]; }
     for (int i = 0; i < mu; i++) L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0;
-    for (int t = 0; t < G; t++) { ph_forces(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
-            for (int t = 0; t < G; t++) ph_force_map(t, G, nb, Y, L, M->end_mask);
+    for (int t = 0; t < G; t++) { if (M->tree) ph_forces<true>(t, nb, Y, L, R[t], M); else ph_forces<false>(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+    for (int t = 0; t < G; t++) { if (M->tree) ph_force_map_tree(t, G, nb, Y, L, M); else ph_force_map(t, G, nb, Y, L, M->end_mask); }
     bool done = false;
     emu_newton(G, nb, Y, L, R, M, dt, &done);
     if (!done) return -3;

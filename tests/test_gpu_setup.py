@@ -205,9 +205,9 @@ def test_error_codes(cclqr):
     capi = cclqr._capi
     ex = cclqr.examples.cartpole_n(2)
     t = ex["mech"].tables()
-    bad = cclqr.MechTables(t.nb, t.ne, t.dt, t.g, t.mass, t.inertia, [-1, 0, 0], t.child, t.type, t.p1, t.p2, t.axis, t.qoff)
+    big = cclqr.examples.tree_mechanism([-1, 0, 0, 0, 0, 0])["mech"].tables()
     with pytest.raises(capi.CclqrError) as e:
-        capi.MechHandle(bad)   # body 0 with two child joints: branching tree
+        capi.MechHandle(big)   # five child joints on one body
     assert e.value.code == capi.EUNSUPPORTED
     mech = capi.MechHandle(t)
     with pytest.raises(capi.CclqrError) as e:
