@@ -287,3 +287,54 @@ def test_philox_known_answers(orc):
     assert abs(x.mean()) < 0.03 and abs(x.std() - 1) < 0.03
     # streams of different instances / seeds are distinct
     assert orc.philox_normal(0xC0FFEE, 0, 1) != orc.philox_normal(0xC0FFEE, 1, 1) != orc.philox_normal(0xC0FFED, 1, 1)
+
+
+def _energy(t, z):
+    E = 0.0
+    for b in range(t.nb):
+        J = np.asarray(t.inertia[b]).reshape(3, 3)
+        E += 0.5 * t.mass[b] * z[b, 7:10] @ z[b, 7:10] + 0.5 * z[b, 10:13] @ J @ z[b, 10:13] - t.mass[b] * t.g * z[b, 2]
+    return E
+
+
+def test_integrator_physics_independent_of_the_reference(cclqr, orc):
+    """Physics pins of the integrator restatement (the dependency's source is not available, so these do not rely on it):
+    small-oscillation period of the physical pendulum, first-order energy behaviour without drift, momentum about the joint axis."""
+    free = lambda nb: orc.ctrl_desc(nb, [], K=None, N=0)
+    # 1. period of a rod (length 1, m = 1) pivoted at its end: T = 2 pi sqrt(I / (m g l)); first-order scheme, dt = 0.01
+    ex = cclqr.examples.pendulum(θ0=0.01)
+    t = ex["mech"].tables()
+    _, traj, st = orc.rollout(t, free(1), ex["mech"].state()[None], 2000, record=True)
+    th = np.array([orc.minimal_coordinates(t, traj[0, k])[0] for k in range(2000)])
+    idx = np.where(np.sign(th[:-1]) * np.sign(th[1:]) < 0)[0]
+    tc = np.array([(k + th[k] / (th[k] - th[k + 1])) * t.dt for k in idx])
+    I = (0.1 ** 2 + 1.0 ** 2) / 12.0 + 0.25
+    assert abs(2 * np.mean(np.diff(tc)) / (2 * np.pi * np.sqrt(I / (9.81 * 0.5))) - 1) < 2e-4
+    # 2. double pendulum, large swing, 10 s: the energy error oscillates, halves with the step and does not drift
+    osc = []
+    for dt in (0.01, 0.005):
+        ex = cclqr.examples.double_pendulum(1.0, -0.5)
+        ex["mech"].Δt = dt
+        t = ex["mech"].tables()
+        n = int(round(10 / dt))
+        _, traj, st = orc.rollout(t, free(2), ex["mech"].state()[None], n, record=True)
+        assert (st > 0).all()
+        E = np.array([_energy(t, traj[0, k]) for k in range(n)])
+        osc.append(E.max() - E.min())
+        assert abs(np.mean(E[-n // 5:]) - np.mean(E[:n // 5])) < 0.5 * osc[-1]
+    assert 1.8 < osc[0] / osc[1] < 2.2 and osc[0] < 0.02 * 12.3
+    # 3. no gravity, both links spinning rigidly about the joint axis: angular momentum about that axis stays put
+    ex = cclqr.examples.double_pendulum(0.3, 0.8)
+    ex["mech"].g = 0.0
+    t = ex["mech"].tables()
+    z = ex["mech"].state()
+    for b in range(2):
+        z[b, 10:13] = [1.0, 0, 0]
+        z[b, 7:10] = np.cross([1.0, 0, 0], z[b, 0:3])
+    _, traj, st = orc.rollout(t, free(2), z[None], 1000, record=True)
+    L = []
+    for k in range(1, 1000):
+        zz = traj[0, k]
+        L.append(sum(t.mass[b] * np.cross(zz[b, 0:3], zz[b, 7:10])[0] + cclqr.vrotate(np.asarray(t.inertia[b]).reshape(3, 3) @ zz[b, 10:13], zz[b, 3:7])[0]
+                     for b in range(2)))
+    assert (max(L) - min(L)) / abs(L[0]) < 2e-5
