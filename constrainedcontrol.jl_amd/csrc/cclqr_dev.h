@@ -354,7 +354,7 @@ HD double ph_gain_partial(int t, int G, int nb, const Lay& Y, const double* L, c
 
 // F1: joint inputs -> force/torque on the owned body, per-step invariants, solution guess (SURVEY 8a-bis 'Joint input')
 template <bool TREE = false>
-HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M) {
+HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, bool owner = true) {
     if (t >= nb) return;
     const double dt = M->dt;
     const double* z = L + Y.Z + 13 * t;
@@ -389,9 +389,9 @@ HD void ph_forces(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const Mec
     for (int i = 0; i < 3; i++) {
         r.cT[i] = r.m * (-v1[i] / dt + (i == 2 ? -M->g : 0.0)) - F[i];
         r.cR[i] = -(sq1 * Jw1[i] - c1[i]) - 2.0 * tau[i];
-        L[Y.S + 6 * t + i] = v1[i]; L[Y.S + 6 * t + 3 + i] = w1[i];
+        if (owner) { L[Y.S + 6 * t + i] = v1[i]; L[Y.S + 6 * t + 3 + i] = w1[i]; }
     }
-    L[Y.DTM + t] = dt / r.m;
+    if (owner) L[Y.DTM + t] = dt / r.m;
 }
 
 // F2: constraint Jacobians at the current knot (force mapping G_k)
@@ -873,6 +873,50 @@ HD double ph_trial(int t, int G, int nb, const Lay& Y, double* L, double alpha, 
     }
     return acc;
 }
+// ---- line-search levels evaluated side by side.  After the full step has been rejected, the halvings alpha = 2^-j are tried
+// NL at a time: lane group lg = t / nb evaluates level j0 + lg for link tl = t - lg nb.  A level's trial point, next pose and
+// residual live in the (by then dead) Schur blocks: level slot q uses the 25 nb doubles at SJJ + 25 nb q  (SJJ, SJP, SPJ are
+// consecutive):  ST (6 nb) | LT (5 nb) | XQ (7 nb) | D / G (6 nb).  Accepting the FIRST level in order that does not increase
+// ||f|| (or level LINE_MAXIT) is the same decision sequence as halving one level at a time.
+#define LEVEL_SLOTS 3
+// lane groups that evaluate levels side by side: as many whole copies of the mechanism as fit the G lanes of an instance
+HD int newton_level_groups(int G, int nb) { int n = G / nb; return n > LEVEL_SLOTS ? LEVEL_SLOTS : (n < 1 ? 1 : n); }
+HD Lay level_layout(const Lay& Y, int nb, int slot) {
+    Lay V = Y;
+    const int base = Y.SJJ + 25 * nb * slot;
+    V.ST = base; V.LT = base + 6 * nb; V.XQ = base + 11 * nb; V.D = base + 18 * nb; V.G = base + 18 * nb;
+    return V;
+}
+HD void ph_trial_level(int tl, int nb, const Lay& Y, const Lay& V, double* L, double alpha, int s_cur, int l_cur) {
+    if (tl >= nb) return;
+    double sv[6], dv[6], lv[5], ev[5];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sv[i] = L[s_cur + 6 * tl + i]; dv[i] = L[Y.DS + 6 * tl + i]; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) { lv[i] = L[l_cur + 5 * tl + i]; ev[i] = L[Y.DL + 5 * tl + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) L[V.ST + 6 * tl + i] = sv[i] - alpha * dv[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) L[V.LT + 5 * tl + i] = lv[i] - alpha * ev[i];
+}
+// the accepted level's trial point and next pose become the regular trial buffers
+HD void ph_level_commit(int t, int nb, const Lay& Y, const Lay& V, double* L, int s_try, int l_try) {
+    if (t >= nb) return;
+    double a[6], b[5], c[7];
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = L[V.ST + 6 * t + i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) b[i] = L[V.LT + 5 * t + i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) c[i] = L[V.XQ + 7 * t + i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) L[s_try + 6 * t + i] = a[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) L[l_try + 5 * t + i] = b[i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) L[Y.XQ + 7 * t + i] = c[i];
+}
+
 // accept: the trial buffers become the current ones (the caller swaps offsets); C follows lambda:  C -= alpha CD
 HD void ph_accept(int t, int G, int nb, const Lay& Y, double* L, double alpha) {
     for (int b = t; b < nb; b += G) {

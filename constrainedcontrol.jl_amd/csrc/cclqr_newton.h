@@ -89,6 +89,9 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
     const unsigned smask = M->start_mask, emask = M->end_mask;
     const int nchains = M->nchains;
     int s_cur = Y.S, s_try = Y.ST, l_cur = Y.LAM, l_try = Y.LT;   // accepted / trial buffers swap roles on every acceptance
+    // lane groups of the level-parallel line search: group lg works on link tl (the caller has loaded link tl's constants and
+    // per-step invariants into r for every lane with lg < NL)
+    const int NL = newton_level_groups(G, nb), lg = t / nb, tl = t - lg * nb;
     for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
         if (!__any(!done)) break;
         PCOUNT(PF_NEWTON_ITERS);
@@ -143,20 +146,48 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         // is accepted; later trials evaluate the residual only.
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;
         bool ls_done = done, jac_ok = true;
-        for (int ls = 0; ls <= LINE_MAXIT; ls++) {
-            if (!__any(!ls_done)) break;
+        {   // full step (ls = 0), with the Jacobians
             double pd = ls_done ? 0.0 : ph_trial(t, G, nb, Y, L, alpha, s_cur, s_try, l_cur, l_try);
-            double nd2 = group_sum<G>(pd);
-            if (ls == 0) nd = sqrt(nd2);
+            nd = sqrt(group_sum<G>(pd));
             __syncthreads();
             STAMP(PF_TRIAL);
-            double nf = (ls == 0) ? eval_point<G, true>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS)
-                                  : eval_point<G, false>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS);
+            double nf = eval_point<G, true>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS);
             if (!ls_done) {
                 normf1 = nf;
-                if (ls > 0) jac_ok = false;
-                if (normf1 > normf0 && ls < LINE_MAXIT) alpha *= 0.5; else ls_done = true;
+                if (!(normf1 > normf0)) ls_done = true;
             }
+            __syncthreads();
+        }
+        // halvings, NL levels per pass (see level_layout): lane group lg tests alpha = 2^-(lv + lg)
+        for (int lv = 1; lv <= LINE_MAXIT; lv += NL) {
+            if (!__any(!ls_done)) break;
+            const int mylv = lv + lg;
+            const bool lane_on = !ls_done && lg < NL && mylv <= LINE_MAXIT;
+            const double a_l = ldexp(1.0, -mylv);
+            const Lay V = level_layout(Y, nb, lg < NL ? lg : 0);
+            if (lane_on) ph_trial_level(tl, nb, Y, V, L, a_l, s_cur, l_cur);
+            __syncthreads();
+            STAMP(PF_TRIAL);
+            double part = lane_on ? ph_body_eval<false>(tl, nb, V, L, r, dt, V.ST, a_l) : 0.0;
+            __syncthreads();
+            STAMP(PF_EVAL_BODY);
+            part += lane_on ? ph_joint_eval<false>(tl, nb, V, L, r, dt) : 0.0;
+            __syncthreads();
+            STAMP(PF_EVAL_JOINT);
+            double nfq[LEVEL_SLOTS];
+#pragma unroll
+            for (int q = 0; q < LEVEL_SLOTS; q++) nfq[q] = (q < NL) ? sqrt(group_sum<G>(lg == q ? part : 0.0)) : 0.0;
+            STAMP(PF_EVAL_MAP);
+            PCOUNT(PF_EVALS);
+            int chosen = -1;
+            if (!ls_done) {
+#pragma unroll
+                for (int q = 0; q < LEVEL_SLOTS; q++)
+                    if (chosen < 0 && q < NL && lv + q <= LINE_MAXIT && (!(nfq[q] > normf0) || lv + q == LINE_MAXIT)) { chosen = q; normf1 = nfq[q]; alpha = ldexp(1.0, -(lv + q)); }
+                if (chosen < 0 && lv + NL > LINE_MAXIT) chosen = -2;   // cannot happen: level LINE_MAXIT always accepts
+                if (chosen >= 0) { ls_done = true; jac_ok = false; }
+            }
+            if (chosen >= 0) ph_level_commit(t, nb, Y, level_layout(Y, nb, chosen), L, s_try, l_try);
             __syncthreads();
         }
         bool need_jac = false;

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     for (int e = t; e < ml * mx; e += G) O.G[e] = 0.0;
 
     LaneRegs r;
-    lane_load_consts(r, M, t < nb ? t : 0);
+    const int NL = newton_level_groups(G, nb), lg = t / nb, tl = t - lg * nb;   // lane groups of the level-parallel line search
+    lane_load_consts(r, M, lg < NL ? tl : 0);
     for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = a.zd[(size_t)knot * nz + M->perm[l] * 13 + c]; }
     for (int e = t; e < 5 * nb; e += G) L[Y.LAM + e] = 0.0;
     for (int e = t; e < nb; e += G) L[Y.UJ + e] = 0.0;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinArgs a) {
     if (t == 0)
         for (int i = 0; i < mu; i++) L[Y.UJ + a.cj[i]] += a.Fd ? a.Fd[(size_t)knot * mu + i] : 0.0;
     __syncthreads();
-    ph_forces<TREE>(t, nb, Y, L, r, M);
+    if (lg < NL) ph_forces<TREE>(tl, nb, Y, L, r, M, lg == 0);
     ph_knot_jac(t, nb, Y, L, r);
     __syncthreads();
     if (TREE) ph_force_map_tree(t, G, nb, Y, L, M);

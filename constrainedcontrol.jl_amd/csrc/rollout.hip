@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const int nz = 13 * nb;
 
     LaneRegs r;
-    lane_load_consts(r, M, t < nb ? t : 0);
+    const int NL = newton_level_groups(G, nb), lg = t / nb, tl = t - lg * nb;   // lane groups of the level-parallel line search
+    lane_load_consts(r, M, lg < NL ? tl : 0);
 #ifdef CCLQR_PROFILE
     Prof prof;
     prof.start();
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
         STAMP(PF_CONTROL);
         // ---------------- per-step invariants
-        ph_forces<TREE>(t, nb, Y, L, r, M);
+        if (lg < NL) ph_forces<TREE>(tl, nb, Y, L, r, M, lg == 0);
         ph_knot_jac(t, nb, Y, L, r);
         __syncthreads();
         if (TREE) ph_force_map_tree(t, G, nb, Y, L, M);

@@ -46,14 +46,35 @@ static int emu_newton(int G, int nb, const Lay& Y, double* L, std::vector<LaneRe
         for (int t = 0; t < G; t++) ph_body_solve(t, G, nb, Y, L, M->end_mask);
         }
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;
-        bool jac_ok = true;
-        for (int ls = 0; ls <= 10; ls++) {
+        bool jac_ok = true, ls_done = false;
+        {
             double pd = 0.0;
             for (int t = 0; t < G; t++) pd += ph_trial(t, G, nb, Y, L, alpha, s_cur, s_try, l_cur, l_try);
-            if (ls == 0) nd = sqrt(pd);
-            normf1 = (ls == 0) ? eval_point<true>(G, nb, Y, L, R, M, dt, s_try, alpha) : eval_point<false>(G, nb, Y, L, R, M, dt, s_try, alpha);
-            if (ls > 0) jac_ok = false;
-            if (normf1 > normf0 && ls < 10) alpha *= 0.5; else break;
+            nd = sqrt(pd);
+            normf1 = eval_point<true>(G, nb, Y, L, R, M, dt, s_try, alpha);
+            if (!(normf1 > normf0)) ls_done = true;
+        }
+        // serial twin of the level-parallel halvings: lane group lg = t / nb evaluates level lv + lg in its own slot of the Schur blocks
+        const int NL = newton_level_groups(G, nb);
+        for (int lv = 1; lv <= 10 && !ls_done; lv += NL) {
+            double part[LEVEL_SLOTS] = {0, 0, 0};
+            for (int ph = 0; ph < 3; ph++)
+                for (int t = 0; t < G; t++) {
+                    const int lg = t / nb, tl = t - lg * nb;
+                    if (!(lg < NL && lv + lg <= 10)) continue;
+                    const double a_l = ldexp(1.0, -(lv + lg));
+                    const Lay V = level_layout(Y, nb, lg);
+                    if (ph == 0) ph_trial_level(tl, nb, Y, V, L, a_l, s_cur, l_cur);
+                    if (ph == 1) part[lg] += ph_body_eval<false>(tl, nb, V, L, R[t], dt, V.ST, a_l);
+                    if (ph == 2) part[lg] += ph_joint_eval<false>(tl, nb, V, L, R[t], dt);
+                }
+            int chosen = -1;
+            for (int q = 0; q < NL; q++)
+                if (chosen < 0 && lv + q <= 10 && (!(sqrt(part[q]) > normf0) || lv + q == 10)) { chosen = q; normf1 = sqrt(part[q]); alpha = ldexp(1.0, -(lv + q)); }
+            if (chosen >= 0) {
+                ls_done = true; jac_ok = false;
+                for (int t = 0; t < G; t++) ph_level_commit(t, nb, Y, level_layout(Y, nb, chosen), L, s_try, l_try);
+            }
         }
         for (int t = 0; t < G; t++) ph_accept(t, G, nb, Y, L, alpha);
         { int q = s_cur; s_cur = s_try; s_try = q; q = l_cur; l_cur = l_try; l_try = q; }
@@ -90,7 +111,8 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
     for (int64_t inst = 0; inst < n_inst; inst++) {
         double* L = lds.data();
         for (int e = 0; e < Y.total; e++) L[e] = 0.0;
-        for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t < nb ? t : 0);
+        const int NLg = newton_level_groups(G, nb);
+        for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t / nb < NLg ? t % nb : 0);
         for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = z0[inst * nz + M->perm[l] * 13 + c]; }
         int worst = 0; bool bad = false;
         for (int kk = 0; kk < steps; kk++) {
@@ -115,7 +137,11 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
                     L[Y.UJ + C->cj[i]] += u;
                 }
             if (C->has_pid) for (int t = 0; t < G; t++) ph_pid(t, nb, Y, L, R[t], C, dt, k == 1);
-            for (int t = 0; t < G; t++) { if (M->tree) ph_forces<true>(t, nb, Y, L, R[t], M); else ph_forces<false>(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+            for (int t = 0; t < G; t++) {
+                const int lg = t / nb, tl = t - lg * nb;
+                if (lg < NLg) { if (M->tree) ph_forces<true>(tl, nb, Y, L, R[t], M, lg == 0); else ph_forces<false>(tl, nb, Y, L, R[t], M, lg == 0); }
+                ph_knot_jac(t, nb, Y, L, R[t]);
+            }
             for (int t = 0; t < G; t++) { if (M->tree) ph_force_map_tree(t, G, nb, Y, L, M); else ph_force_map(t, G, nb, Y, L, M->end_mask); }
             bool done = false;
             int its = emu_newton(G, nb, Y, L, R, M, dt, &done);
@@ -153,10 +179,15 @@ extern "C" int emu_linearize(const cclqr_mech_desc* md, const double* zd, int mu
     for (int e = 0; e < mx * mu; e++) Bu[e] = 0;
     for (int e = 0; e < mx * ml; e++) Bl[e] = 0;
     for (int e = 0; e < ml * mx; e++) Gm[e] = 0;
-    for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t < nb ? t : 0);
+    const int NLg = newton_level_groups(G, nb);
+    for (int t = 0; t < G; t++) lane_load_consts(R[t], M, t / nb < NLg ? t % nb : 0);
     for (int e = 0; e < nz; e++) { int l = e / 13, c = e - 13 * l; L[Y.Z + e] = zd[M->perm[l] * 13 + c]; }
     for (int i = 0; i < mu; i++) L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0;
-    for (int t = 0; t < G; t++) { if (M->tree) ph_forces<true>(t, nb, Y, L, R[t], M); else ph_forces<false>(t, nb, Y, L, R[t], M); ph_knot_jac(t, nb, Y, L, R[t]); }
+    for (int t = 0; t < G; t++) {
+        const int lg = t / nb, tl = t - lg * nb;
+        if (lg < NLg) { if (M->tree) ph_forces<true>(tl, nb, Y, L, R[t], M, lg == 0); else ph_forces<false>(tl, nb, Y, L, R[t], M, lg == 0); }
+        ph_knot_jac(t, nb, Y, L, R[t]);
+    }
     for (int t = 0; t < G; t++) { if (M->tree) ph_force_map_tree(t, G, nb, Y, L, M); else ph_force_map(t, G, nb, Y, L, M->end_mask); }
     bool done = false;
     emu_newton(G, nb, Y, L, R, M, dt, &done);
