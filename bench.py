@@ -155,7 +155,7 @@ def main():
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,
                    "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "rollout_kernel<%d>" % lanes, "kernel_ms": kern_ms,
+                     "traffic": traffic, "kernel": "rollout_kernel<%d, false>" % lanes, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_instance_step": bs},
         "newton": {"max_iters_mean": float(status.mean()), "max_iters_max": int(status.max()), "failed_instances": n_bad},
         "setup": {"lqr_construct_s": setup_s, "riccati_kbreak": int(lqr.kbreak)},
