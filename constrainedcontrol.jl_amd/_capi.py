@@ -15,7 +15,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path"]
+           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
 class CclqrError(RuntimeError):
@@ -190,6 +190,11 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
 def riccati_path(path):
     """0 auto, 1 persistent workgroup per problem, 2 tiled over the device"""
     check(lib().cclqr_riccati_path(C.c_int32(int(path))))
+
+
+def set_pid_state(ptr):
+    """device address of a [n_inst][nb][2] fp64 buffer carrying the PID integrators across rollout_dev launches (0: none)"""
+    check(lib().cclqr_set_pid_state(C.c_void_p(int(ptr)) if ptr else None))
 
 
 def set_instance_offset(first_instance):

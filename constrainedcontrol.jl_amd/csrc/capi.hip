@@ -95,6 +95,10 @@ extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
 static thread_local int64_t g_inst0 = 0;
 extern "C" int cclqr_set_instance_offset(int64_t first_instance) { g_inst0 = first_instance; return CCLQR_OK; }
 
+// device buffer that carries the PID integrators between the following device-pointer launches of this thread (nullptr: none)
+static thread_local double* g_pid_state = nullptr;
+extern "C" int cclqr_set_pid_state(double* pid_state_dev) { g_pid_state = pid_state_dev; return CCLQR_OK; }
+
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
     if (lanes) *lanes = rollout_lanes_per_instance(m->nb, m->host.tree);
@@ -112,7 +116,7 @@ extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64
     if (rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = noise;
-    a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = g_inst0;
+    a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = g_inst0; a.pid_state = g_pid_state;
     HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, (hipStream_t)stream));
     return CCLQR_OK;
 }

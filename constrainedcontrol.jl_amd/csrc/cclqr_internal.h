@@ -18,6 +18,7 @@ struct RolloutArgs {
     double* lam;          // [n_inst][5 nb] internal order, or null
     const double* noise;  // [n_inst][noise_stride] or null
     int64_t noise_stride;
+    double* pid_state;    // [n_inst][nb][2] integrated / last PID errors carried between launches (opaque link order), or nullptr
     int64_t inst0;        // global index of instance 0 of this launch (Philox stream = global instance index, so shards reproduce the whole batch)
     double* traj;         // [n_inst][steps][nb][13] or null
     double* zT;           // [n_inst][nb][13]

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     LaneRegs r;
     const int NL = newton_level_groups(G, nb), lg = t / nb, tl = t - lg * nb;   // lane groups of the level-parallel line search
     lane_load_consts(r, M, lg < NL ? tl : 0);
+    if (a.pid_state && a.k0 > 1 && valid && t < nb) { r.pid_int = a.pid_state[(inst * nb + t) * 2]; r.pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
 #ifdef CCLQR_PROFILE
     Prof prof;
     prof.start();
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.zT[inst * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
         if (a.lam) for (int e = t; e < 5 * nb; e += G) a.lam[inst * 5 * nb + e] = L[Y.LAM + e];
         if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
+        if (a.pid_state && t < nb) { a.pid_state[(inst * nb + t) * 2] = r.pid_int; a.pid_state[(inst * nb + t) * 2 + 1] = r.pid_last; }
     }
 #ifdef CCLQR_PROFILE
     prof.stamp(PF_IO);

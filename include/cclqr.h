@@ -61,7 +61,7 @@ typedef struct {
     const double *fric;        /* [ne] viscous joint friction of examples/trackingLQR_triple_cartpole.jl:98-101, or NULL */
     double noise_scale;        /* cart noise amplitude, same file :98 (`randn()*2`); 0 = none */
     /* PID{T,N} (src/control/pid.jl:3-40) on 1-DoF joints in minimal coordinates; control_pid! (pid.jl:69-88) runs every step.
-     * The integrated / last errors live for one launch (start a rollout with k0 = 1). npid = 0: none. */
+     * The integrated / last errors live for one launch unless cclqr_set_pid_state provides a buffer. npid = 0: none. */
     int32_t npid;
     const int32_t *pid_joint;  /* [npid] joint indices (eqcids) */
     const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid]  P, I, D, goals (pid.jl:4-9) */
@@ -127,6 +127,11 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
 /* Global index of instance 0 of the following rollout launches of this thread (default 0).  Only matters for noise_philox: the
  * noise stream of an instance is keyed by its GLOBAL index, so rank r of a sharded batch sets its shard's first index here. */
 int cclqr_set_instance_offset(int64_t first_instance);
+
+/* PID integrators across launches: a DEVICE buffer [n_inst][nb][2] (integrated error, last error per joint, opaque order) used by the
+ * following cclqr_rollout_dev launches of this thread -- read when k0 > 1, always written.  NULL (default): the integrated / last
+ * errors of pid.jl:10-11 live for one launch. */
+int cclqr_set_pid_state(double *pid_state_dev);
 
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py) */
 int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);

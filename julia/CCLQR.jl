@@ -162,6 +162,9 @@ riccati_path!(path::Integer) = check(ccall((:cclqr_riccati_path, lib), Cint, (In
 "Global index of instance 1 of the following simulate_batch! calls (Philox noise streams are keyed by global instance index)."
 instance_offset!(first::Integer) = check(ccall((:cclqr_set_instance_offset, lib), Cint, (Int64,), first))
 
+"Device buffer (n_inst x Nb x 2 Float64) that carries the PID integrators between device-pointer launches; C_NULL = none."
+pid_state!(ptr::Ptr{Float64}) = check(ccall((:cclqr_set_pid_state, lib), Cint, (Ptr{Float64},), ptr))
+
 "Storage{T}(steps, Nb) view of instance n of a batched trajectory: storage.x[i][k] etc. (lqr_tracking.jl:32-35)."
 function storage_fields(traj::Array{Float64,4}, n::Integer)
     nb, steps = size(traj, 2), size(traj, 3)

@@ -126,3 +126,38 @@ def test_chained_device_launches_equal_one_launch(cclqr, orc):
     octrl = orc.ctrl_desc(t.nb, [0], K=K, N=150, zd=zd)
     zo, _, _ = orc.rollout(t, octrl, z0, 100)
     assert np.abs(one.cpu().numpy() - zo).max() < TOL
+
+
+def test_pid_state_carried_across_launches(cclqr, orc):
+    """PID (pid.jl:69-88) with step-per-launch use: with cclqr_set_pid_state the integrated / last errors survive between launches,
+    so 30 + 70 steps in two launches equal 100 steps in one (and equal the oracle)"""
+    import torch
+    capi = cclqr._capi
+    ex = cclqr.examples.double_pendulum(0.2, -0.1)
+    t = ex["mech"].tables()
+    pid = dict(joint=[0, 1], P=ex["P"], I=ex["I"], D=ex["D"], goal=ex["goals"])
+    z0 = np.stack([cclqr.examples.double_pendulum(a, b)["mech"].state() for a, b in ((0.2, -0.1), (-0.5, 0.3), (0.0, 0.0))])
+    n = len(z0)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [], K=None, N=0, pid=pid)
+    dev = torch.device("cuda", 0)
+    z0_d = torch.from_numpy(z0).to(dev)
+    one, a, b = torch.empty_like(z0_d), torch.empty_like(z0_d), torch.empty_like(z0_d)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    capi.rollout_dev(mech, ctrl, n, 100, 1, z0_d.data_ptr(), 0, 0, 0, 0, one.data_ptr(), st.data_ptr())
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+    pstate = torch.zeros((n, t.nb, 2), dtype=torch.float64, device=dev)
+    try:
+        capi.set_pid_state(pstate.data_ptr())
+        capi.rollout_dev(mech, ctrl, n, 30, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr())
+        capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr())
+    finally:
+        capi.set_pid_state(0)
+    torch.cuda.synchronize()
+    assert torch.equal(b, one)
+    zo, _, _ = orc.rollout(t, orc.ctrl_desc(2, [], K=None, N=0, pid=pid), z0, 100)
+    assert np.abs(one.cpu().numpy() - zo).max() < TOL
+    # without the buffer the integrators restart: a different trajectory
+    capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    assert not torch.equal(b, one)
