@@ -44,7 +44,7 @@ struct MechDev {
     // ---- general trees (tree != 0: some body carries several child joints; links are numbered depth-first, first child = l+1).
     // The Schur complement on the multipliers then couples the joints around a body pairwise (siblings), and the solve is the
     // table-driven elimination below instead of the chains' two-front sweep.
-    int tree;
+    int tree;        // 0: forest of chains; otherwise 8 x (largest neighbour count in the elimination) = lanes one elimination step needs
     int nchild[CCLQR_MAXL], child[CCLQR_MAXL][CCLQR_MAXK];   // child links of body l
     int npairs, pair_i[CCLQR_MAXP], pair_j[CCLQR_MAXP];      // sibling pairs i < j: LDS blocks SS[2p] = S_ij, SS[2p+1] = S_ji
     // elimination program, links in reverse order: when l is eliminated its remaining neighbours are x_0 .. x_{nn-1}

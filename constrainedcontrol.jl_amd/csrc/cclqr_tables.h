@@ -151,6 +151,7 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
             }
             if (nn > CCLQR_MAXK) { err = "internal: too many neighbours in the elimination"; return CCLQR_EINVAL; }
             H.el_nn[l] = nn;
+            if (8 * nn > H.tree) H.tree = 8 * nn;
             for (int g = 0; g < nn; g++) {
                 H.el_lx[l][g] = block(l, H.el_x[l][g]);
                 H.el_xl[l][g] = block(H.el_x[l][g], l);

@@ -120,7 +120,10 @@ extern "C" int cclqr_prof_read(unsigned long long* out, int reset) {
 #endif
 
 // lanes per instance: one lane per link, and a tree needs 8 lanes per neighbour group of its elimination (up to CCLQR_MAXK groups)
-int rollout_lanes_per_instance(int nb, int tree) { return tree ? (nb <= 8 ? 32 : 64) : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64)); }
+int rollout_lanes_per_instance(int nb, int tree) {
+    const int g = nb <= 4 ? 16 : (nb <= 8 ? 32 : 64);
+    return tree > g ? (tree <= 16 ? 16 : (tree <= 32 ? 32 : 64)) : g;   // tree = lanes an elimination step needs (0 for chains)
+}
 
 size_t rollout_lds_bytes(int nb, int tree, int npairs) {
     int G = rollout_lanes_per_instance(nb, tree);
@@ -141,7 +144,7 @@ hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hi
     const size_t lds = rollout_lds_bytes(nb, tree, npairs);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
-    if (tree) return G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream);
+    if (tree) return G == 16 ? launch_one<16, true>(a, grid, lds, stream) : (G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream));
     switch (G) {
         case 16: return launch_one<16, false>(a, grid, lds, stream);
         case 32: return launch_one<32, false>(a, grid, lds, stream);

@@ -104,7 +104,7 @@ extern "C" int emu_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd,
     const CtrlDev* C = &T.H;
     const int nb = M->nb, nz = 13 * nb;
     const double dt = M->dt;
-    const int G = G_override > 0 ? G_override : (M->tree ? (nb <= 8 ? 32 : 64) : (nb <= 4 ? 16 : (nb <= 8 ? 32 : 64)));
+    const int G = G_override > 0 ? G_override : [&] { const int g = nb <= 4 ? 16 : (nb <= 8 ? 32 : 64); return M->tree > g ? (M->tree <= 16 ? 16 : (M->tree <= 32 ? 32 : 64)) : g; }();
     const Lay Y = make_layout(nb, M->tree ? 2 * M->npairs : 0);
     std::vector<double> lds(Y.total);
     std::vector<LaneRegs> R(G);
