@@ -129,6 +129,9 @@ def main():
     status = st_d.cpu().numpy()
     n_bad = int((status <= 0).sum())
 
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()     # every rank leaves the job cleanly before rank 0 formats the line
     if rank != 0:
         return
     total_units = float(n_inst) * world * T * args.steps
