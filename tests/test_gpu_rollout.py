@@ -161,3 +161,58 @@ def test_pid_state_carried_across_launches(cclqr, orc):
     capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr())
     torch.cuda.synchronize()
     assert not torch.equal(b, one)
+
+
+def test_step_per_launch_chain_captured_in_a_hip_graph(cclqr, orc):
+    """configs[4] asks for a hipGraph-captured step: 20 single-step launches of cclqr_rollout_dev (state and multipliers round-trip
+    HBM between them) captured once on a stream into a graph and replayed == one 20-step launch, bit for bit"""
+    import torch
+    capi = cclqr._capi
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N = 40
+    rng = np.random.default_rng(2)
+    z00 = ex["mech"].state()
+    zd = np.tile(z00, (N, 1, 1))
+    K = rng.normal(size=(N - 1, 1, 48)) * 0.3
+    n = 256
+    z0 = np.tile(z00, (n, 1, 1))
+    z0[:, 0, 1] += rng.uniform(-0.1, 0.1, n)
+    z0[:, 1:, 1] += (z0[:, 0, 1] - z00[0, 1])[:, None]          # shift the whole mechanism with the cart: still consistent
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=N, zd=zd, fric=ex["fric"])
+    dev = torch.device("cuda", 0)
+    z0_d = torch.from_numpy(z0).to(dev)
+    ref = torch.empty_like(z0_d)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, ref.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    za, zb = z0_d.clone(), torch.empty_like(z0_d)
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        capi.rollout_dev(mech, ctrl, n, 1, 1, za.data_ptr(), lam.data_ptr(), 0, 0, 0, zb.data_ptr(), st.data_ptr(), side.cuda_stream)   # warm (loads the code object)
+        side.synchronize()
+        za.copy_(z0_d)
+        lam.zero_()
+        side.synchronize()
+        graph.capture_begin()
+        src, dst = za, zb
+        for k in range(1, 21):
+            capi.rollout_dev(mech, ctrl, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
+            src, dst = dst, src
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(src, ref)
+    # replay on fresh inputs through the same captured buffers
+    za.copy_(z0_d)
+    lam.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(src, ref)
+    zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=N, zd=zd, fric=ex["fric"]), z0[:16], 20)
+    assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
