@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import scipy.linalg as sl
 
-from test_tree import TREES, build
+from test_tree import TREES, build, _random_parents
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -72,3 +72,37 @@ def test_dual_cartpole_lqr_pipeline(cclqr, orc):
         assert abs(th[0]) < 0.05 and abs(th[1]) < 0.02 and abs(th[2]) < 0.02
     zo, _, sto = orc.rollout(t, orc.ctrl_desc(3, [0], K=lqr.K, N=lqr.N, zd=lqr.zd), z0[:8], 800)
     assert np.abs(st.zT[:8] - zo).max() < 1e-8
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_topologies_gpu_vs_oracle(cclqr, orc, seed):
+    """random forests (up to 4 child joints per body, several roots, mixed joint types): batched rollout + linearisation on the GPU"""
+    capi = cclqr._capi
+    rng = np.random.default_rng(2000 + seed)
+    nb = int(rng.integers(2, 15))
+    parents = _random_parents(rng, nb)
+    prism = tuple(int(i) for i in range(nb) if rng.uniform() < 0.2)
+    ex = cclqr.examples.tree_mechanism(parents, seed=seed, prismatic=prism, g=-9.81 if seed % 3 else 0.0)
+    mech = ex["mech"]
+    t = mech.tables()
+    z0 = []
+    for n in range(7):
+        for e in ex["joints"]:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.5, 0.5))
+        z0.append(mech.state())
+    z0 = np.stack(z0)
+    steps = 25
+    cj = sorted(set(int(j) for j in rng.integers(0, t.ne, 2)))
+    K = rng.normal(size=(steps + 3, len(cj), 12 * t.nb)) * 0.05
+    Fd = rng.normal(size=(1, len(cj))) * 0.3
+    kw = dict(K=K, N=steps + 4, zd=z0[0], Fd=Fd, fric=rng.uniform(0, 0.05, t.ne))
+    zo, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, cj, **kw), z0, steps, record=True)
+    h = capi.MechHandle(t)
+    zT, traj, st = capi.rollout(h, capi.CtrlHandle(h, cj, **kw), z0, steps, record=True)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < TOL
+    A, Bu, Bl, G = capi.linearize(h, z0[:2], cj, np.tile(Fd, (2, 1)))
+    for k in range(2):
+        Ao, Buo, Blo, Go = orc.linearize(t, z0[k], cj, Fd[0])
+        for X, Xo in ((A[k], Ao), (Bu[k], Buo), (Bl[k], Blo), (G[k], Go)):
+            assert np.abs(X - Xo).max() < 1e-8 * max(1.0, np.abs(Xo).max())

@@ -124,3 +124,48 @@ def test_dual_cartpole_lqr_balances_both_poles(cclqr, orc, emu):
     assert abs(th[0]) < 0.05 and abs(th[1]) < 0.02 and abs(th[2]) < 0.02
     zT, traj, st = emu_rollout(emu, orc, t, oc, z0, 600)
     assert (st > 0).all() and np.abs(traj - traj_o).max() < 1e-8
+
+
+def _random_parents(rng, nb, max_children=4):
+    """random forest: each body picks a parent among the earlier bodies (or the origin) that still has room"""
+    parents, count = [], {}
+    for i in range(nb):
+        cands = [-1] + [a for a in range(i) if count.get(a, 0) < max_children]
+        a = int(rng.choice(cands)) if rng.uniform() > 0.15 else -1
+        parents.append(a)
+        if a >= 0:
+            count[a] = count.get(a, 0) + 1
+    return parents
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_topologies_emulator_vs_oracle(cclqr, orc, emu, seed):
+    """random forests of 2..12 bodies (up to 4 child joints per body, several roots, revolute / prismatic joints with random axes and
+    anchors, bodies listed in an order unrelated to the kernels' link order): rollout and linearisation of the kernel phases == oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    nb = int(rng.integers(2, 13))
+    parents = _random_parents(rng, nb)
+    prism = tuple(int(i) for i in range(nb) if rng.uniform() < 0.2)
+    ex = cclqr.examples.tree_mechanism(parents, seed=seed, prismatic=prism, g=-9.81 if seed % 3 else 0.0)
+    t = ex["mech"].tables()
+    z0 = ex["mech"].state()[None]
+    assert np.abs(orc.constraints(t, z0[0])).max() < 1e-12
+    steps = 12
+    cj = sorted(set(int(j) for j in rng.integers(0, t.ne, 2)))
+    K = rng.normal(size=(steps + 3, len(cj), 12 * t.nb)) * 0.05
+    Fd = rng.normal(size=(1, len(cj))) * 0.3
+    oc = orc.ctrl_desc(t.nb, cj, K=K, N=steps + 4, zd=z0[0], Fd=Fd, fric=rng.uniform(0, 0.05, t.ne))
+    zo, traj_o, st_o = orc.rollout(t, oc, z0, steps, record=True)
+    zT, traj, st = emu_rollout(emu, orc, t, oc, z0, steps)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-9 and np.abs(zT - zo).max() < 1e-9
+    m = orc.mech_desc(t)
+    cja = np.array(cj, dtype=np.int32)
+    mx, ml, mu = 12 * t.nb, 5 * t.ne, len(cj)
+    A, Bu, Bl, G = np.zeros((mx, mx)), np.zeros((mx, mu)), np.zeros((mx, ml)), np.zeros((ml, mx))
+    rc = emu.emu_linearize(C.byref(m.desc), z0[0].ctypes.data_as(dp), mu, cja.ctypes.data_as(C.POINTER(C.c_int32)), Fd[0].ctypes.data_as(dp),
+                           A.ctypes.data_as(dp), Bu.ctypes.data_as(dp), Bl.ctypes.data_as(dp), G.ctypes.data_as(dp))
+    assert rc == 0
+    Ao, Buo, Blo, Go = orc.linearize(t, z0[0], cj, Fd[0])
+    for X, Xo in ((A, Ao), (Bu, Buo), (Bl, Blo), (G, Go)):
+        assert np.abs(X - Xo).max() < 1e-8 * max(1.0, np.abs(Xo).max())
