@@ -35,8 +35,9 @@ def emu():
     d = os.path.join(ROOT, "tests", "emu")
     so = os.path.join(d, "libemu.so")
     src = os.path.join(d, "emu_rollout.cpp")
-    hdr = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc", "cclqr_dev.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    csrc = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, h) for h in ("cclqr_dev.h", "cclqr_lin_dev.h", "cclqr_tables.h", "cclqr_internal.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared",
                                "-o", so, src])
     return C.CDLL(so)
