@@ -106,6 +106,8 @@ def main():
             return pkg.dist.gather_to_root(zT_d, n_inst * world, rank, world)   # RCCL fan-in of the final states
         return zT_d
 
+    if world > 1:   # open the RCCL peer connections the gather uses, whatever --warmup says (communicator set-up is not a step)
+        pkg.dist.gather_to_root(torch.zeros((1, 1), dtype=torch.float64, device=dev), world, rank, world)
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
