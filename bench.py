@@ -131,6 +131,7 @@ def main():
     status = st_d.cpu().numpy()
     n_bad = int((status <= 0).sum())
 
+    backend_name = dist.get_backend() if world > 1 else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()     # every rank leaves the job cleanly before rank 0 formats the line
@@ -154,7 +155,7 @@ def main():
         "metric": "LQR sim steps/sec (whole node) on N-link cartpole batch", "value": value, "unit": "instance-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "rehearsal_shared_gpu": bool(args.rehearse_shared_gpu),
+        "rehearsal_shared_gpu": bool(args.rehearse_shared_gpu), "collective_backend": backend_name,
         "config": {"workload": "lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, "
                                "y0~U(-0.5,0.5) phi_i~U(-0.2,0.2)" % (n_links, nb, T * t.dt),
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,

@@ -2,6 +2,7 @@
 contiguous block with no data-path collective; the only exchange is the gather of results to rank 0 (RCCL over xGMI on
 GPUs, gloo on CPU for tests).  One process per GPU, torch.distributed for the plumbing."""
 import os
+import sys
 
 import numpy as np
 
@@ -31,7 +32,19 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            try:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+                probe = torch.zeros(1, device=torch.device("cuda", local))
+                dist.all_reduce(probe)           # RCCL creates its communicator lazily: fail here, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:               # the instances do not need the collective; the final-state gather can run on host buffers
+                sys.stderr.write("cclqr.dist: RCCL unavailable (%s); gathering through gloo on host buffers\n" % (e,))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
