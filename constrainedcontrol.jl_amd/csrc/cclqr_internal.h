@@ -53,9 +53,8 @@ struct RicArgs {
     int* stop;               // [nprob] scratch flags of the tiled path
     int lds_cols;            // right-hand-side columns staged in LDS per batch (set by launch_riccati)
 };
-size_t ric_work_doubles(int mx, int mu, int ml);
 size_t ric_total_work_doubles(const RicArgs& a);
-void set_riccati_path(int p);   // 0 auto, 1 one persistent workgroup per problem, 2 tiled (three launches per backward step)
+void set_riccati_path(int p);   // 0 auto / 1: LDS-resident workgroup per problem whenever it fits; 2: tiled (three launches per backward step)
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream);
 
 }  // namespace cclqr

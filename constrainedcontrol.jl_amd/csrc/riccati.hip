@@ -1,8 +1,8 @@
 // riccati.hip -- constrained discrete Riccati backward recursion, dlqr(A,Bu,Bλ,G,Q,R,N) of src/control/lqr.jl:141-184 and its
 // time-varying twin dlqr(mechanism, ...) of src/control/lqr_tracking.jl:73-122 (A,Bu,Bλ,G indexed by knot).
 //
-// One workgroup (8 wavefronts) per independent problem, persistent over k = N-1 ... 1: the sweep is sequential in k, so all
-// parallelism inside a problem is in the dense algebra of one step.  The mx x mx products (P [A' | D], Abar' (P Abar)) run on the
+// Two launch shapes (RESIDENT: one workgroup per problem with P in LDS; TILED: every step tiled over the device), see below.
+// The sweep is sequential in k, so all parallelism inside a problem is in the dense algebra of one step.  The mx x mx products (P [A' | D], Abar' (P Abar)) run on the
 // fp64 matrix cores (v_mfma_f64_16x16x4_f64, 16x16 tiles per wavefront); the linear solves are in-kernel LUs with partial
 // pivoting (Julia's `\` on a square matrix) followed by one-column-per-thread substitution.
 // Statement-by-statement correspondence with lqr.jl is marked with the line numbers.
@@ -166,32 +166,16 @@ __device__ void wg_lu_solve(int n, MP LU, int lda, const int* piv, double* B, in
     __syncthreads();
 }
 
-// Workspace of one problem.  The recursion runs in its PROJECTED form: with E = (G Bλ)^-1 G Bu and F = (G Bλ)^-1 G A,
+// The recursion runs in its PROJECTED form: with E = (G Bλ)^-1 G Bu and F = (G Bλ)^-1 G A,
 //   D  = Bu - Bλ E            (lqr.jl:151, the reference's D)
 //   A' = A  - Bλ F            (dynamics projected onto the constraint manifold)
 // the second block row of M Kk = b (lqr.jl:154-160) gives Kλ = F - E Ku, and substituting it into the first block row leaves
 //   (R + D' P D) Ku = D' P A' ,   Abar = A - Bu Ku - Bλ Kλ = A' - D Ku        (lqr.jl:160,169)
 // i.e. the same Kk and Abar as the reference's (mu+ml)-square solve, at the cost of a mu-square one; E, F, D, A' do not depend on P,
 // so a time-invariant problem computes them once.  Only Ku is stored by the reference (lqr.jl:162-164), Kλ is never formed.
-struct RicWork {
-    double *GBl, *X, *AD, *W, *TS, *S, *Ku, *Abar, *P, *Pn, *KRK;
-    int* piv;
-};
-__host__ __device__ inline size_t ric_carve(int mx, int mu, int ml, double* base, RicWork* w) {
-    const size_t na = (size_t)mx + mu;
-    size_t o = 0;
-    auto take = [&](size_t n) { double* p = base ? base + o : nullptr; o += (n + 1) & ~(size_t)1; return p; };
-    double *GBl = take((size_t)ml * ml), *X = take((size_t)ml * na), *AD = take((size_t)mx * na), *W = take((size_t)mx * na),
-           *TS = take((size_t)mu * na), *S = take((size_t)mu * mu), *Ku = take((size_t)mu * mx), *Abar = take((size_t)mx * mx),
-           *P = take((size_t)mx * mx), *Pn = take((size_t)mx * mx), *KRK = take((size_t)mu * mx), *piv = take((size_t)ml + mu + 16);
-    if (w) { w->GBl = GBl; w->X = X; w->AD = AD; w->W = W; w->TS = TS; w->S = S; w->Ku = Ku; w->Abar = Abar; w->P = P; w->Pn = Pn;
-             w->KRK = KRK; w->piv = (int*)piv; }
-    return o;
-}
-size_t ric_work_doubles(int mx, int mu, int ml) { return ric_carve(mx, mu, ml, nullptr, nullptr); }
 
 #ifdef CCLQR_PROFILE
-enum { RP_PRE, RP_PA, RP_GAIN, RP_UPD, RP_PP, RP_NORM, RP_STEPS, RP_N };
+enum { RP_PA, RP_GAIN, RP_UPD, RP_PP, RP_NORM, RP_STEPS, RP_N };
 static __device__ unsigned long long g_rprof[RP_N];
 #define RSTAMP(c) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t1_ = __builtin_readcyclecounter(); g_rprof[c] += t1_ - rt0; rt0 = t1_; } } while (0)
 #else
@@ -199,124 +183,6 @@ static __device__ unsigned long long g_rprof[RP_N];
 #endif
 
 #define RIC_LDS_M 96   // G Bλ (ml x ml) is kept in LDS for its pivoted LU when ml <= 96 (72 KB)
-
-template <bool LDSM>
-__global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
-    extern __shared__ double lds_M[];
-    typedef typename std::conditional<LDSM, lds_double*, double*>::type MP;
-#ifdef CCLQR_PROFILE
-    unsigned long long rt0 = __builtin_readcyclecounter();
-#endif
-    __shared__ double red_v[RIC_WAVES];
-    __shared__ int sing;
-    const int prob = blockIdx.x, tid = threadIdx.x;
-    const int mx = a.mx, mu = a.mu, ml = a.ml, N = a.N, na = mx + mu;
-    RicWork w;
-    ric_carve(mx, mu, ml, a.work + (size_t)prob * ric_carve(mx, mu, ml, nullptr, nullptr), &w);
-    MP GBl = LDSM ? (MP)lds_M : (MP)w.GBl;
-    MP Xs = LDSM ? (MP)lds_M + (size_t)ml * ml : (MP) nullptr;
-    const int CB = LDSM ? a.lds_cols : 0;
-    const size_t nlin = a.time_varying ? (size_t)(N - 1) : 1;
-    const double* Ab = a.A + (size_t)prob * nlin * mx * mx;
-    const double* Bub = a.Bu + (size_t)prob * nlin * mx * mu;
-    const double* Blb = a.Bl + (size_t)prob * nlin * mx * ml;
-    const double* Gb = a.G + (size_t)prob * nlin * ml * mx;
-    double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
-    if (tid == 0) sing = 0;
-    for (int e = tid; e < mx * mx; e += RIC_THREADS) w.P[e] = a.Q[e];   // Pk = Q                                  lqr.jl:147
-    __syncthreads();
-    double* P = w.P;
-    double* Pn = w.Pn;
-    const int tr = tid >> 5, tc = tid & 31;   // 16 x 32 thread grid for the elementwise passes (no per-element index division)
-    int k = 0, status = 0;
-    for (k = N - 1; k >= 1; k--) {                                       // for outer k=N-1:-1:1                    lqr.jl:150
-        const size_t li = a.time_varying ? (size_t)(k - 1) : 0;
-        const double *A = Ab + li * mx * mx, *Bu = Bub + li * mx * mu, *Bl = Blb + li * mx * ml, *G = Gb + li * ml * mx;
-        if (a.time_varying || k == N - 1) {
-            // AD = [A' | D] = [A | Bu] - Bλ (G Bλ)^-1 G [A | Bu]                                                    lqr.jl:151,154-155,158
-            for (int i = tr; i < mx; i += RIC_THREADS / 32) {
-                for (int j = tc; j < mx; j += 32) w.AD[(size_t)i * na + j] = A[(size_t)i * mx + j];
-                for (int j = tc; j < mu; j += 32) w.AD[(size_t)i * na + mx + j] = Bu[(size_t)i * mu + j];
-            }
-            __syncthreads();
-            if (ml > 0) {
-                wg_gemm<false>(ml, ml, mx, 1.0, G, mx, Bl, ml, 0.0, w.GBl, ml);          // M22 = G*Bλ                  lqr.jl:155
-                wg_gemm<false>(ml, na, mx, 1.0, G, mx, w.AD, na, 0.0, w.X, na);          // [G*A | G*Bu]               lqr.jl:158,154
-                if (LDSM) { for (int e = tid; e < ml * ml; e += RIC_THREADS) GBl[e] = w.GBl[e]; __syncthreads(); }
-                wg_lu<MP>(ml, GBl, ml, w.piv, &sing);
-                if (!sing) {
-                    wg_lu_solve<MP>(ml, GBl, ml, w.piv, w.X, na, na, Xs, CB);            // X = [F | E]
-                    wg_gemm<false>(mx, na, ml, -1.0, Bl, ml, w.X, na, 1.0, w.AD, na);
-                }
-            }
-        }
-        if (sing) { status = CCLQR_ESINGULAR_; break; }
-        RSTAMP(RP_PRE);
-        // W = Pk [A' | D]   (Pk symmetric)
-        wg_gemm<true>(mx, na, mx, 1.0, P, mx, w.AD, na, 0.0, w.W, na);
-        RSTAMP(RP_PA);
-        // TS = D' W = [D' Pk A' | D' Pk D] ;  S = R + D' Pk D ;  Ku = S \ (D' Pk A')                               lqr.jl:152-160
-        wg_gemm<true>(mu, na, mx, 1.0, w.AD + mx, na, w.W, na, 0.0, w.TS, na);
-        for (int e = tid; e < mu * mu; e += RIC_THREADS) w.S[e] = a.R[e] + w.TS[(size_t)(e / mu) * na + mx + e % mu];
-        for (int e = tid; e < mu * mx; e += RIC_THREADS) w.Ku[e] = w.TS[(size_t)(e / mx) * na + e % mx];
-        __syncthreads();
-        wg_lu<double*>(mu, w.S, mu, w.piv + ml + 4, &sing);
-        if (sing) { status = CCLQR_ESINGULAR_; break; }
-        wg_lu_solve<double*>(mu, w.S, mu, w.piv + ml + 4, w.Ku, mx, mx, nullptr, 0);
-        const double* Ku = w.Ku;
-        for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k - 1) * mu * mx + e] = Ku[e];   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
-        // KRK = R Kuk (mu x mx)
-        for (int e = tid; e < mu * mx; e += RIC_THREADS) {
-            int i = e / mx, c = e % mx; double s = 0.0;
-            for (int q = 0; q < mu; q++) s += a.R[i * mu + q] * Ku[(size_t)q * mx + c];
-            w.KRK[e] = s;
-        }
-        RSTAMP(RP_GAIN);
-        // Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) ;  W <- Pk Abar = Pk A' - (Pk D) Kuk ;  Pn = Q
-        for (int i = tr; i < mx; i += RIC_THREADS / 32) {
-            const double* ADi = w.AD + (size_t)i * na;
-            double* Wi = w.W + (size_t)i * na;
-            for (int j = tc; j < mx; j += 32) {
-                double ab = ADi[j], pw = Wi[j];
-                for (int q = 0; q < mu; q++) { const double kq = Ku[(size_t)q * mx + j]; ab -= ADi[mx + q] * kq; pw -= Wi[mx + q] * kq; }
-                w.Abar[(size_t)i * mx + j] = ab;
-                Wi[j] = pw;
-                Pn[(size_t)i * mx + j] = a.Q[(size_t)i * mx + j];
-            }
-        }
-        __syncthreads();
-        RSTAMP(RP_UPD);
-        // Pkp1 = Q + Kuk'*R*Kuk + Abar'*Pk*Abar                                                                     lqr.jl:170
-        wg_gemm<true>(mx, mx, mu, 1.0, Ku, mx, w.KRK, mx, 1.0, Pn, mx);
-        wg_gemm<true>(mx, mx, mx, 1.0, w.Abar, mx, w.W, na, 1.0, Pn, mx);
-        RSTAMP(RP_PP);
-        // if norm(Pk-Pkp1) < 1e-5  break                                                                            lqr.jl:172-174
-        double acc = 0.0;
-        for (int e = tid; e < mx * mx; e += RIC_THREADS) { double d = P[e] - Pn[e]; acc += d * d; }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if ((tid & 63) == 0) red_v[tid >> 6] = acc;
-        __syncthreads();
-        double tot = 0.0;
-        for (int q = 0; q < RIC_WAVES; q++) tot += red_v[q];
-        __syncthreads();
-        RSTAMP(RP_NORM);
-#ifdef CCLQR_PROFILE
-        if (tid == 0 && blockIdx.x == 0) g_rprof[RP_STEPS] += 1;
-#endif
-        if (sqrt(tot) < a.tol) break;
-        double* tmp = P; P = Pn; Pn = tmp;                                                               // Pk = Pkp1  lqr.jl:176
-    }
-    if (status == 0) {
-        if (k < 1 && N - 1 >= 1) k = 1;   // Julia: after a completed loop the outer k holds its last value
-        if (N - 1 < 1) k = 0;
-        __syncthreads();
-        for (int k2 = k - 1; k2 >= 1; k2--) {                                                    // Ku[k2] = Ku[k2+1]  lqr.jl:179-181
-            for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
-            __syncthreads();
-        }
-    }
-    if (tid == 0) { a.kbreak[prob] = k; a.status[prob] = status; }
-}
 
 // =====================================================================================================================
 // TILED path: one backward step = three launches over a grid of 32x32 tiles (x problems), so a single large problem uses
@@ -330,7 +196,6 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_kernel(RicArgs a) {
 // summed per tile and then over tiles in index order, so results do not depend on scheduling.  A problem that has met the
 // break criterion (lqr.jl:172) raises its `stop` flag and its later launches return at once.
 #define TILE_THREADS 256
-#define RIC_TILED_MIN_MX 48
 struct RicGrid {
     int nprob, mx, mu, ml, N, nlin, na, tm, tn;
     double tol;
@@ -608,6 +473,200 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_pn_kernel(RicGrid a, int k) 
     if (tid == 0) a.part[((size_t)(k & 1) * a.nprob + prob) * (a.tm * a.tm) + blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
+// =====================================================================================================================
+// RESIDENT path (problems whose P and W = P [A'|D] fit one CU's LDS, mx up to ~96): one 512-thread workgroup per problem
+// runs the whole sweep with P and W resident in LDS; A' | D (constant, or per knot) and Abar stream through L2.  Per step:
+//   W = Pk [A' | D]                       16x16 MFMA tiles, A operand from LDS, B operand from global
+//   S = R + D'W_D ; Ku = S \ D'W_A'       mu x mu pivoted LU in LDS                                   lqr.jl:152-164
+//   W_A' -= W_D Ku (= Pk Abar) ; Abar = A' - D Ku -> global scratch                                   lqr.jl:169
+//   Pkp1 = Q + Ku'RKu + Abar' (Pk Abar)   tiles again, written over Pk in LDS while |Pk - Pkp1|^2 is summed   lqr.jl:170-176
+// No flags, no launches per step: this is the shape for many small problems (config 4 with a setpoint per instance).
+// 16x16 tile of sum_k a(k) b(k) by one wavefront, eight k-groups (16 operand loads) per pass.  Measured alternatives that were
+// slower under the 256-register budget of a 512-thread workgroup: all of a tile's operands in one pass, strips of tiles sharing the
+// global operand's fragments, two register buffers with the next pass prefetched (spills in every case).
+template <class FA, class FB>
+__device__ inline v4d wave_tile16(int K, FA la, FB lb) {
+    const int lk = (threadIdx.x & 63) >> 4;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const int ngroups = (K + 3) >> 2;
+    constexpr int CH = 8;
+    for (int g0 = 0; g0 < ngroups; g0 += CH) {
+        double av[CH], bv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int k = 4 * (g0 + u) + lk;
+            const bool kok = k < K;
+            av[u] = kok ? la(k) : 0.0;
+            bv[u] = kok ? lb(k) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+size_t ric_resident_lds_bytes(int mx, int mu) {
+    const size_t na = (size_t)mx + mu;
+    return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2) * sizeof(double) + (mu + 2) * sizeof(int);
+}
+
+__global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a) {
+    extern __shared__ double rl[];
+#ifdef CCLQR_PROFILE
+    unsigned long long rt0 = __builtin_readcyclecounter();
+#endif
+    __shared__ int sing;
+    const int prob = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int mx = a.mx, mu = a.mu, na = a.na, N = a.N;
+    if (a.stop[prob]) return;            // G Bλ was singular in the projection (status already set)
+    lds_double* P = (lds_double*)rl;
+    lds_double* W = P + (size_t)mx * mx;
+    lds_double* Dl = W + (size_t)mx * na;
+    lds_double* Ku = Dl + (size_t)mx * mu;
+    lds_double* KRK = Ku + (size_t)mu * mx;
+    lds_double* TS = KRK + (size_t)mu * mx;
+    lds_double* S = TS + (size_t)mu * na;
+    lds_double* Rl = S + (size_t)mu * mu;
+    lds_double* red = Rl + (size_t)mu * mu;
+    int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2));
+    double* Abar = a.Abar + (size_t)prob * mx * mx;
+    double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
+    if (tid == 0) sing = 0;
+    for (int e = tid; e < mx * mx; e += RIC_THREADS) P[e] = a.Q[e];       // Pk = Q                                  lqr.jl:147
+    for (int e = tid; e < mu * mu; e += RIC_THREADS) Rl[e] = a.R[e];
+    __syncthreads();
+    const int t16m = (mx + 15) >> 4, t16n = (na + 15) >> 4;
+    int k = 0, status = 0;
+    for (k = N - 1; k >= 1; k--) {                                        // for outer k=N-1:-1:1                    lqr.jl:150
+        const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
+        for (int e = tid; e < mx * mu; e += RIC_THREADS) Dl[e] = AD[(size_t)(e / mu) * na + mx + e % mu];
+        // W = Pk [A' | D]   (Pk symmetric)
+        for (int tile = wave; tile < t16m * t16n; tile += RIC_WAVES) {
+            const int i0 = (tile / t16n) << 4, j0 = (tile % t16n) << 4;
+            const bool iok = i0 + li < mx, jok = j0 + li < na;
+            const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? P[kk * mx + i0 + li] : 0.0; },
+                                        [&](int kk) { return jok ? AD[(size_t)kk * na + j0 + li] : 0.0; });
+            if (jok) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < mx) W[row * na + j0 + li] = acc[r]; }
+            }
+        }
+        __syncthreads();
+        RSTAMP(RP_PA);
+        // TS = D' W = [D' Pk A' | D' Pk D] ; S = R + D' Pk D
+        for (int e = tid; e < mu * na; e += RIC_THREADS) {
+            const int q = e / na, j = e - q * na;
+            double sacc = 0.0;
+            for (int i = 0; i < mx; i++) sacc += Dl[i * mu + q] * W[i * na + j];
+            TS[e] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];
+        __syncthreads();
+        if (wave == 0) {                                     // LU with partial pivoting (mu <= 32) by ONE wavefront: LDS is in order per
+            for (int c = 0; c < mu; c++) {                   // wavefront, so fences replace the workgroup barriers
+                int bi = c;
+                {
+                    double best = -1.0;
+                    for (int r = c; r < mu; r++) { double v = fabs(S[r * mu + c]); if (v > best) { best = v; bi = r; } }   // every lane: same scan
+                    if (!(best > 0.0)) { if (lane == 0) sing = 1; break; }
+                }
+                if (lane == 0) piv[c] = bi;
+                if (bi != c && lane < mu) { double t = S[c * mu + lane]; S[c * mu + lane] = S[bi * mu + lane]; S[bi * mu + lane] = t; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const double pinv = 1.0 / S[c * mu + c];
+                if (lane > c && lane < mu) S[lane * mu + c] *= pinv;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int w = mu - c - 1;
+                for (int e = lane; e < w * w; e += 64) {
+                    const int r = c + 1 + e / w, j = c + 1 + e % w;
+                    S[r * mu + j] -= S[r * mu + c] * S[c * mu + j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        __syncthreads();
+        if (sing) { status = CCLQR_ESINGULAR_; break; }
+        for (int j = tid; j < mx; j += RIC_THREADS) {         // Ku = S \ (D' Pk A'), one column per thread
+            for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[c * na + j]; TS[c * na + j] = TS[p * na + j]; TS[p * na + j] = t; } }
+            for (int i = 1; i < mu; i++) { double sacc = TS[i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[r * na + j]; TS[i * na + j] = sacc; }
+            for (int i = mu - 1; i >= 0; i--) {
+                double sacc = TS[i * na + j];
+                for (int r = i + 1; r < mu; r++) sacc -= S[i * mu + r] * TS[r * na + j];
+                TS[i * na + j] = sacc / S[i * mu + i];
+            }
+            for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(size_t)(k - 1) * mu * mx + (size_t)q * mx + j] = v; }   // lqr.jl:162-164
+            for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += Rl[q * mu + r] * TS[r * na + j]; KRK[q * mx + j] = sacc; }
+        }
+        __syncthreads();
+        RSTAMP(RP_GAIN);
+        // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) -> global scratch
+        for (int i = tid >> 5; i < mx; i += RIC_THREADS / 32) {
+            for (int j0 = tid & 31; j0 < mx; j0 += 128) {          // four columns of a row per pass: their A' loads are in flight together
+                double ab[4], pw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 32 * u;
+                    ab[u] = j < mx ? AD[(size_t)i * na + j] : 0.0;
+                    pw[u] = j < mx ? W[i * na + j] : 0.0;
+                }
+                for (int q = 0; q < mu; q++) {
+                    const double dq = Dl[i * mu + q], wq = W[i * na + mx + q];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; const double kq = j < mx ? Ku[q * mx + j] : 0.0; ab[u] -= dq * kq; pw[u] -= wq * kq; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; if (j < mx) { Abar[(size_t)i * mx + j] = ab[u]; W[i * na + j] = pw[u]; } }
+            }
+        }
+        __syncthreads();
+        RSTAMP(RP_UPD);
+        // Pkp1 = Q + Kuk'*R*Kuk + Abar'*(Pk*Abar), over Pk; |Pk - Pkp1|^2 on the way                                lqr.jl:170-176
+        double nacc = 0.0;
+        for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
+            const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
+            const bool iok = i0 + li < mx, jok = j0 + li < mx;
+            const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? Abar[(size_t)kk * mx + i0 + li] : 0.0; },
+                                        [&](int kk) { return jok ? W[kk * na + j0 + li] : 0.0; });
+            if (jok) {
+                const int j = j0 + li;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = i0 + lk + 4 * r;
+                    if (i < mx) {
+                        double v = a.Q[(size_t)i * mx + j] + acc[r];
+                        for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j];
+                        const double d = P[i * mx + j] - v;
+                        nacc += d * d;
+                        P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
+                    }
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_xor(nacc, o, 64);
+        if (lane == 0) red[wave] = nacc;
+        __syncthreads();
+        double tot = 0.0;
+        for (int q = 0; q < RIC_WAVES; q++) tot += red[q];
+        __syncthreads();
+        RSTAMP(RP_PP);
+#ifdef CCLQR_PROFILE
+        if (tid == 0 && blockIdx.x == 0) g_rprof[RP_STEPS] += 1;
+#endif
+        if (sqrt(tot) < a.tol) break;                                     // if norm(Pk-Pkp1) < 1e-5  break          lqr.jl:172-174
+    }
+    if (status == 0) {
+        if (k < 1 && N - 1 >= 1) k = 1;   // Julia: after a completed loop the outer k holds its last value
+        if (N - 1 < 1) k = 0;
+        __syncthreads();
+        for (int k2 = k - 1; k2 >= 1; k2--) {                             // Ku[k2] = Ku[k2+1]                       lqr.jl:179-181
+            for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { a.kbreak[prob] = k; a.status[prob] = status; }
+}
+
 // Ku[k2] = Ku[k2+1] below the break index (lqr.jl:179-181) and the loop variable's final value
 __global__ void ric_backfill_kernel(RicGrid a) {
     const int prob = blockIdx.x, tid = threadIdx.x;
@@ -639,13 +698,26 @@ size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_
     return (size_t)nprob * (nlin * mx * na + mx * na + 3 * (size_t)mx * mx + 2 * (size_t)mu * mx + 2 * tm * tm + tm * mu * na + nlin * sc + nlin * (ml + 2) + 8) + 64;
 }
 
-static hipError_t launch_riccati_tiled(const RicArgs& a, double* work, int* stop, hipStream_t stream) {
+static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024; }
+// resident (one workgroup per problem, P and W in LDS) whenever it fits; otherwise the tiled three-launch step
+static bool ric_use_tiled(const RicArgs& a) {
+    if (!ric_resident_fits(a)) return true;
+    if (g_ric_path != 0) return g_ric_path == 2;
+    // measured crossover: a single 84..96-state problem is faster spread over the device (41 vs 59 us per step), small problems
+    // and large batches are faster resident (mx 48: 14 vs 20 us; 1024 x mx 84: 0.54 vs 0.74 ms per step)
+    return a.mx >= 64 && a.nprob < 128;
+}
+
+size_t ric_total_work_doubles(const RicArgs& a) { return ric_grid_work_doubles(a.nprob, a.mx, a.mu, a.ml, a.N, a.time_varying); }
+
+hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
+    if (a.nprob <= 0) return hipSuccess;
     RicGrid g;
     g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
     g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol;
-    g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = stop;
+    g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = a.stop;
     const size_t np = a.nprob, nlin = g.nlin, mx = a.mx, na = g.na, mu = a.mu, ml = a.ml;
-    double* o = work;
+    double* o = a.work;
     g.AD = o; o += np * nlin * mx * na;
     g.W = o; o += np * mx * na;
     g.Abar = o; o += np * mx * mx;
@@ -655,18 +727,19 @@ static hipError_t launch_riccati_tiled(const RicArgs& a, double* work, int* stop
     g.part = o; o += 2 * np * g.tm * g.tm;
     g.TSp = o; o += np * g.tm * mu * na;
     g.scratch = o;
-    hipError_t e = hipMemsetAsync(stop, 0, np * sizeof(int), stream);
+    hipError_t e = hipMemsetAsync(a.stop, 0, np * sizeof(int), stream);
     if (e == hipSuccess) e = hipMemsetAsync(a.status, 0, np * sizeof(int), stream);
     if (e == hipSuccess) e = hipMemsetAsync(a.kbreak, 0, np * sizeof(int), stream);
     if (e != hipSuccess) return e;
+    // [A' | D] of every knot of every problem, in parallel
     size_t lds = 0; int cols = 0;
     if (ml <= RIC_LDS_M && ml > 0) {
-        const size_t budget = 150 * 1024;
+        const size_t budget = 150 * 1024;                 // of the 160 KB per CU; the rest is static LDS
         size_t c = (budget - ml * ml * sizeof(double)) / (ml * sizeof(double));
         if (c > RIC_THREADS) c = RIC_THREADS;
         if (c > na) c = na;
         cols = (int)c;
-        lds = (ml * ml + ml * c) * sizeof(double);
+        lds = (ml * ml + ml * c) * sizeof(double);        // G Bλ for the pivoted LU + one batch of right-hand-side columns
     }
     if (lds > 0) {
         e = hipFuncSetAttribute((const void*)ric_project_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -674,6 +747,13 @@ static hipError_t launch_riccati_tiled(const RicArgs& a, double* work, int* stop
         hipLaunchKernelGGL(ric_project_kernel<true>, dim3(g.nlin, a.nprob), dim3(RIC_THREADS), lds, stream, g, cols);
     } else {
         hipLaunchKernelGGL(ric_project_kernel<false>, dim3(g.nlin, a.nprob), dim3(RIC_THREADS), 0, stream, g, 0);
+    }
+    if (!ric_use_tiled(a)) {
+        const size_t rl = ric_resident_lds_bytes(a.mx, a.mu);
+        e = hipFuncSetAttribute((const void*)riccati_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(riccati_resident_kernel, dim3(a.nprob), dim3(RIC_THREADS), rl, stream, g);
+        return hipGetLastError();
     }
     const size_t lds_gain = (mu * na + mu * mu + 2 * RU * mu) * sizeof(double) + (mu + 2) * sizeof(int), lds_pn = 2 * mu * 32 * sizeof(double);
     if (lds_gain > 48 * 1024) {
@@ -686,42 +766,6 @@ static hipError_t launch_riccati_tiled(const RicArgs& a, double* work, int* stop
         hipLaunchKernelGGL(ric_pn_kernel, dim3(g.tm * g.tm, a.nprob), dim3(TILE_THREADS), lds_pn, stream, g, k);
     }
     hipLaunchKernelGGL(ric_backfill_kernel, dim3(a.nprob), dim3(TILE_THREADS), 0, stream, g);
-    return hipGetLastError();
-}
-
-static bool ric_use_tiled(const RicArgs& a) {
-    if (g_ric_path == 1) return false;
-    if (g_ric_path == 2) return true;
-    return a.mx >= RIC_TILED_MIN_MX;     // small problems are launch-latency bound: keep them in one persistent workgroup
-}
-
-size_t ric_total_work_doubles(const RicArgs& a) {
-    return ric_use_tiled(a) ? ric_grid_work_doubles(a.nprob, a.mx, a.mu, a.ml, a.N, a.time_varying)
-                            : (size_t)a.nprob * ric_work_doubles(a.mx, a.mu, a.ml);
-}
-
-hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
-    if (a.nprob <= 0) return hipSuccess;
-    if (ric_use_tiled(a)) return launch_riccati_tiled(a, a.work, a.stop, stream);
-    const int m = a.ml, na = a.mx + a.mu;
-    RicArgs a2 = a;
-    size_t lds = 0;
-    a2.lds_cols = 0;
-    if (m <= RIC_LDS_M && m > 0) {
-        const size_t budget = 150 * 1024;                 // of the 160 KB per CU; the rest is static LDS
-        size_t cols = (budget - (size_t)m * m * sizeof(double)) / ((size_t)m * sizeof(double));
-        if (cols > RIC_THREADS) cols = RIC_THREADS;
-        if (cols > (size_t)na) cols = na;
-        a2.lds_cols = (int)cols;
-        lds = ((size_t)m * m + (size_t)m * cols) * sizeof(double);   // G Bλ for the pivoted LU + one batch of right-hand-side columns
-    }
-    if (lds > 0) {
-        hipError_t e = hipFuncSetAttribute((const void*)riccati_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(riccati_kernel<true>, dim3(a.nprob), dim3(RIC_THREADS), lds, stream, a2);
-    } else {
-        hipLaunchKernelGGL(riccati_kernel<false>, dim3(a.nprob), dim3(RIC_THREADS), 0, stream, a2);
-    }
     return hipGetLastError();
 }
 

@@ -100,8 +100,9 @@ int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t m
 int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
                   const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
 
-/* Tuning knob for the two dlqr entry points (lqr.jl:141, lqr_tracking.jl:73): 0 = choose by problem size (default), 1 = one
- * persistent workgroup per problem, 2 = every backward step tiled over the whole device.  Same results either way. */
+/* Tuning knob for the two dlqr entry points (lqr.jl:141, lqr_tracking.jl:73): 0 = choose by problem size and count (default), 1 = one
+ * LDS-resident workgroup per problem whenever the problem fits (mx up to ~96), 2 = every backward step tiled over the whole device.
+ * Same results either way. */
 int cclqr_riccati_path(int32_t path);
 
 /* dlqr(mechanism, xd, vd, qd, ωd, Fτd, eqcids, Q, R, N) -- lqr_tracking.jl:73-122: re-linearises at every knot (:88).

@@ -74,7 +74,7 @@ def test_riccati_matches_oracle(cclqr, orc, n_links, N):
 
 @pytest.mark.parametrize("path", [1, 2])
 def test_riccati_both_paths(cclqr, orc, path):
-    """the persistent-workgroup and the tiled implementation of dlqr (cclqr_riccati_path) against the oracle: time-invariant with an
+    """the LDS-resident and the tiled implementation of dlqr (cclqr_riccati_path) against the oracle: time-invariant with an
     early break, batched, time-varying (lqr_tracking.jl:73-122), multi-input (mu = 3), and a singular G*Bλ"""
     capi = cclqr._capi
     capi.riccati_path(path)

@@ -24,7 +24,7 @@ def case(name, A, Bu, Bl, G, Q, R, N, tol=1e-5):
     capi.riccati_path(0)
     steps = (N - np.maximum(res[1][2], 1)).max() + 1
     d = np.abs(res[1][1] - res[2][1]).max() / max(1.0, np.abs(res[1][1]).max())
-    print("%-34s steps %4d: persistent %.4fs (%.1f us/step)  tiled %.4fs (%.1f us/step)  speedup %.2fx  |dK|rel %.1e kb %s" % (
+    print("%-34s steps %4d: resident %.4fs (%.1f us/step)  tiled %.4fs (%.1f us/step)  speedup %.2fx  |dK|rel %.1e kb %s" % (
         name, steps, res[1][0], 1e6 * res[1][0] / steps, res[2][0], 1e6 * res[2][0] / steps, res[1][0] / res[2][0], d,
         "same" if np.array_equal(res[1][2], res[2][2]) else "DIFFER"))
 
