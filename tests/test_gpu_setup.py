@@ -314,3 +314,30 @@ def test_pid_double_pendulum(cclqr, orc):
     for i in range(3):
         th = orc.minimal_coordinates(t, st.zT[i])
         assert abs(th[0] - np.pi / 2) < 0.05 and abs(th[1] + np.pi / 4) < 0.05
+
+
+def test_plain_c_program_through_the_abi(cclqr, orc, tmp_path):
+    """examples/c_abi_cartpole.c (plain C, no Python in the process): lqr_cartpole.jl through mech_create -> linearize -> riccati ->
+    ctrl_create -> rollout; its printed gains and final states against the oracle"""
+    import subprocess
+    from test_host import _build_c_example
+    exe = _build_c_example(tmp_path)
+    n = 5
+    out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    kb, kmax = int(lines[0].split()[1]), float(lines[0].split()[3])
+    zT = np.array([[float(v) for v in ln.split()[5:]] for ln in lines[1:]]).reshape(n, 2, 13)
+    st = [int(ln.split()[3]) for ln in lines[1:]]
+    ex = cclqr.examples.cartpole_n(1)
+    t = ex["mech"].tables()
+    zd = upright_setpoint(1)
+    A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
+    Ko, kbo = orc.riccati(A, Bu, Bl, G, np.eye(24) * t.dt, np.eye(1) * t.dt, 1000)
+    assert kb == kbo and abs(kmax - np.abs(Ko).max()) < 1e-7 * np.abs(Ko).max()
+    y0 = np.array([-0.4 + 0.8 * i / (n - 1) for i in range(n)])
+    phi = np.array([[0.05 + 0.25 * i / (n - 1)] for i in range(n)])
+    z0 = cclqr.examples.cartpole_states(1, y0, phi)
+    zo, _, sto = orc.rollout(t, orc.ctrl_desc(2, [0], K=Ko, N=1000, zd=zd), z0, 1000)
+    assert all(s > 0 for s in st) and (sto > 0).all()
+    assert np.abs(zT - zo).max() < 1e-8

@@ -182,3 +182,20 @@ def test_minimal_to_maximal_kinematics(cclqr, orc):
     for i in range(4):
         assert np.allclose((xp[i] - xm[i]) / (2 * h), vd[i], atol=1e-8)
     assert np.allclose(ωd[1], [θd[1], 0, 0]) and np.allclose(ωd[3], [θd[1] + θd[2] + θd[3], 0, 0])
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_cartpole")
+    libdir = os.path.join(ROOT, "constrainedcontrol.jl_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_cartpole.c"),
+                           "-o", exe, "-L", libdir, "-lcclqr", "-lm", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_example_compiles_and_links_against_the_abi(cclqr, tmp_path):
+    """examples/c_abi_cartpole.c uses include/cclqr.h from plain C (no Python, no torch): it must compile warning-free and link"""
+    import __graft_entry__ as graft
+    if not os.path.exists(cclqr._capi.LIB_PATH):
+        graft.build()
+    assert os.path.exists(_build_c_example(tmp_path))
