@@ -51,7 +51,6 @@ struct RicArgs {
     int* status;             // [nprob]
     double* work;            // ric_total_work_doubles(args) doubles
     int* stop;               // [nprob] scratch flags of the tiled path
-    int lds_cols;            // right-hand-side columns staged in LDS per batch (set by launch_riccati)
 };
 size_t ric_total_work_doubles(const RicArgs& a);
 void set_riccati_path(int p);   // 0 auto / 1: LDS-resident workgroup per problem whenever it fits; 2: tiled (three launches per backward step)
