@@ -193,6 +193,11 @@ HD void lane_load_consts(LaneRegs& r, const MechDev* M, int l) {
 // translational  R(qa)'(xb + R(qb) p2 - xa) - p1 ; rotational vec(qa^-1 qb qoff^-1); rows picked by sel/rotmask.
 // Ba/Bb (5x6 row major, row stride 6): [dg/dx * sx_side , (dg/dphi) * Nside]  where N = 3x3 (nullptr = identity).
 // JAC = false evaluates g only (rejected line-search trials need no Jacobian).
+// Row kinds of the two joint types (Revolute = 3 translational + 2 rotational rows, Prismatic = 2 + 3): rows 0,1 are always
+// translational, rows 3,4 always rotational, only row 2 depends on the joint -- so in the unrolled row loops four of the five
+// rows fold to one kind at compile time (no selects, and only that kind's Jacobian products are formed).
+HD bool row_is_rotational(int rotmask, int row) { return row >= 3 ? true : (row <= 1 ? false : ((rotmask >> 2) & 1) != 0); }
+
 template <bool JAC>
 HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const double* xb, const double* qb, bool has_a,
                    double sxa, double sxb, const double* Na_, const double* Nb_, double* g, double* Ba, double* Bb) {
@@ -219,7 +224,7 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
     if (!JAC) {
 #pragma unroll
         for (int row = 0; row < 5; row++) {
-            bool rot = (r.rotmask >> row) & 1;
+            const bool rot = (r.rotmask >> row) & 1;
             double s0 = r.sel[row][0], s1 = r.sel[row][1], s2 = r.sel[row][2];
             g[row] = rot ? (s0 * e[1] + s1 * e[2] + s2 * e[3]) : (s0 * gT[0] + s1 * gT[1] + s2 * gT[2]);
         }
@@ -250,7 +255,7 @@ HD void joint_eval(const LaneRegs& r, const double* xa, const double* qa, const 
     double PRa[9] = {-e[0], -e[3], e[2], e[3], -e[0], -e[1], -e[2], e[1], -e[0]};
 #pragma unroll
     for (int row = 0; row < 5; row++) {
-        bool rot = (r.rotmask >> row) & 1;
+        const bool rot = row_is_rotational(r.rotmask, row);
         double s0 = r.sel[row][0], s1 = r.sel[row][1], s2 = r.sel[row][2];
         double vT = s0 * gT[0] + s1 * gT[1] + s2 * gT[2];
         double vR = s0 * e[1] + s1 * e[2] + s2 * e[3];

@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """a GPU test that does not come back within three minutes is a hang, not a slow test: fail it instead of blocking the session"""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(180, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def cclqr():
     return graft.load_package()

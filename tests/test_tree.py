@@ -13,6 +13,7 @@ dp = C.POINTER(C.c_double)
 
 TREES = {
     "dual_cartpole": None,
+    "small4": [-1, 0, 0, 1],                   # four bodies, two joints on body 0: the 16-lane tree kernel like the dual cartpole
     "y": [-1, 0, 1, 2, 1, 4],                  # chain 0-1-2-3 with a branch 1-4-5
     "three_children": [-1, 0, 0, 0, 2, 2],     # three joints on body 0, two on body 2
     "four_children": [-1, 0, 0, 0, 0, -1, 5, 5],
