@@ -199,3 +199,28 @@ def test_c_example_compiles_and_links_against_the_abi(cclqr, tmp_path):
     if not os.path.exists(cclqr._capi.LIB_PATH):
         graft.build()
     assert os.path.exists(_build_c_example(tmp_path))
+
+
+def test_rollout_kernel_resources(tmp_path):
+    """every instantiation of the rollout kernel cross-compiles for gfx950 within one wavefront's register file (512 VGPR + AGPR per
+    lane), and the headline instantiation (64 lanes per instance, chains) does not touch scratch memory"""
+    import subprocess
+    asm = str(tmp_path / "rollout.s")
+    src = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc", "rollout.hip")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=fast", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                           "-o", asm, src], stderr=subprocess.DEVNULL)
+    txt = open(asm).read()
+    kernels = {}
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "rollout_kernel" not in name:
+            continue
+        kernels[name] = dict(agpr=int(blk.split()[0]), vgpr=int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)),
+                             scratch=int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)),
+                             lds=int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    assert len(kernels) == 6, sorted(kernels)          # G in {16, 32, 64} x {chains, trees}
+    for name, k in kernels.items():
+        assert k["vgpr"] <= 512 and k["lds"] == 0, (name, k)      # all LDS is dynamic (one instance layout per lane group)
+        assert k["scratch"] <= 64, (name, k)
+    headline = [k for n, k in kernels.items() if "ILi64ELb0" in n][0]
+    assert headline["scratch"] == 0
