@@ -1,0 +1,439 @@
+// cclqr_chain.h -- register-resident phases of the chain rollout kernel (rollout_chain.hip).
+//
+// Execution model: one mechanism instance per group of G lanes (G = 16 / 32) of ONE wavefront, lane t < nb
+// owns link t (= body t and the joint that hangs it off its parent) and keeps EVERYTHING that belongs to the link in its
+// own registers: constants, state, multipliers, the sparse constraint Jacobians at knot k (G_k) and k+1 (W = G_v D^-1), the
+// Newton iterate.  Links of a chain are numbered root to leaf, so the parent link is lane t-1 and the child link lane t+1:
+// neighbour vectors move by whole-wave DPP shifts (wave_shr:1 / wave_shl:1).  LDS holds what is gathered across lanes (the
+// 5x5 Schur blocks of the block-tridiagonal solve, G_k of every joint) plus a few private per-lane slots that relieve the
+// register file: 150 doubles per link, 20.4 KB for the 17-body chain instead of 40.8 KB (make_chain_layout).
+//
+// Sparse form of a joint's 5x6 Jacobian pair (parent side Ba, child side Bb):  row r = sel_r' [X | Phi] with
+//   translational row:  Bb = [ xt_r * sxb , pb_r ]   Ba = [ -xt_r * sxa , pa_r ]     xt_r = (Ra sel_r)'
+//   rotational row:     Bb = [ 0          , pb_r ]   Ba = [ 0           , pa_r ]
+// so a 3x3 (XT: rows 3, 4 are always rotational) and two 5x3 arrays (PB, PA) plus two scalars replace two 5x6 blocks, and a
+// product with a Jacobian costs 6 to 9 instead of 12 multiply-adds per entry.
+//
+// Every function is __host__ __device__ so that tests/emu_chain can run the identical arithmetic lane by lane on the CPU
+// (test infrastructure only; the product never executes these on the host).  Neighbour inputs are explicit arguments:
+// the kernel fills them by DPP, the emulator by reading the neighbour lane's struct.
+#pragma once
+#include "cclqr_dev.h"
+
+namespace cclqr {
+
+// ---- constants of the owned link.  The five constraint rows are (Revolute) e0 e1 e2 | V1 V2 or (Prismatic) V1 V2 | e0 e1 e2
+// (translational | rotational part; V1, V2 span the plane normal to the joint axis -- cclqr_tables.h), so the row selectors
+// are rebuilt from V12 and the joint type instead of being kept as fifteen registers.
+struct LinkC {
+    double m, J[9], p1[3], p2[3], V12[6], qoc[4], axis[3];
+    double dtm;        // dt / m
+    double sxb, sxa;   // dt^2 / m of the own body / of the parent body (0 when the parent is the origin)
+    double fric;       // viscous friction of the own joint
+    int type;          // 0 revolute, 1 prismatic
+    bool has_a, has_c, on;   // parent is a link (not the origin) / a child link exists / lane owns a link
+};
+
+HD void link_load_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
+    const bool on = t < nb;
+    const int l = on ? t : 0;
+    c.on = on;
+    c.m = M->m[l];
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.J[i] = M->J[l][i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c.p1[i] = M->p1[l][i]; c.p2[i] = M->p2[l][i]; c.axis[i] = M->axis[l][i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.qoc[i] = M->qoc[l][i];
+    c.type = M->type[l];
+    const int vrow = c.type == 0 ? 3 : 0;     // where V1, V2 sit among the rows
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c.V12[i] = M->sel[l][vrow][i]; c.V12[3 + i] = M->sel[l][vrow + 1][i]; }
+    const int pa = M->parent[l];
+    c.has_a = on && pa >= 0;
+    c.has_c = on && M->childl[l] >= 0;
+    c.dtm = dt / c.m;
+    c.sxb = dt * c.dtm;
+    c.sxa = c.has_a ? dt * dt / M->m[pa >= 0 ? pa : 0] : 0.0;
+    c.fric = 0.0;
+}
+// selector of constraint row `row` (compile-time row index)
+HD void row_sel(const LinkC& c, int row, double* s) {
+    const bool rev = c.type == 0;
+    const int e = rev ? row : row - 2;          // unit vector index when the row is a unit row
+    const bool unit = rev ? row < 3 : row >= 2;
+    const int v = rev ? row - 3 : row;          // 0 / 1: V1 / V2 when it is not
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = unit ? (i == e ? 1.0 : 0.0) : c.V12[3 * (v & 1) + i];
+}
+
+// ---- joint: g and the sparse Jacobians.  Same formulas as joint_eval (cclqr_dev.h), outputs in sparse form:
+// XT[3][3] (rows 0..2; rows 3, 4 are always rotational and have no x part; row 2 is zero for a prismatic joint),
+// PB[5][3], PA[5][3].  Na / Nb: 3x3 applied to the rotational columns of the parent / child side (nullptr = identity).
+template <bool JAC>
+HD void joint_eval_sparse(const LinkC& c, const double* xa, const double* qa, const double* xb, const double* qb,
+                          const double* Na, const double* Nb, double* g, double (*XT)[3], double (*PB)[3], double (*PA)[3]) {
+    double Ra[9], Rb[9], rp[3], w[3], RaTw[3], gT[3];
+    rotmat(qa, Ra); rotmat(qb, Rb);
+    mv3(Rb, c.p2, rp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i] = xb[i] + rp[i] - xa[i];
+    mtv3(Ra, w, RaTw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) gT[i] = RaTw[i] - c.p1[i];
+    double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
+    qmul(qac, qb, rel);
+    qmul(rel, c.qoc, e);
+    const bool rot2 = c.type != 0;     // row 2 is rotational for a prismatic joint
+    if (!JAC) {
+#pragma unroll
+        for (int row = 0; row < 5; row++) {
+            double s[3];
+            row_sel(c, row, s);
+            const double vT = s[0] * gT[0] + s[1] * gT[1] + s[2] * gT[2], vR = s[0] * e[1] + s[1] * e[2] + s[2] * e[3];
+            g[row] = row < 2 ? vT : (row > 2 ? vR : (rot2 ? vR : vT));
+        }
+        return;
+    }
+    double RaTRb[9], PTb[9], PRb[9];
+    mtm3(Ra, Rb, RaTRb);
+    {
+        const double* p = c.p2;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double a = RaTRb[i * 3], b = RaTRb[i * 3 + 1], cc = RaTRb[i * 3 + 2];
+            PTb[i * 3 + 0] = -2.0 * (b * p[2] - cc * p[1]);
+            PTb[i * 3 + 1] = -2.0 * (cc * p[0] - a * p[2]);
+            PTb[i * 3 + 2] = -2.0 * (a * p[1] - b * p[0]);
+        }
+    }
+    {
+        const double s = rel[0], x = rel[1], y = rel[2], z = rel[3];
+        const double os = c.qoc[0], ox = c.qoc[1], oy = c.qoc[2], oz = c.qoc[3];
+        const double Lr[3][4] = {{x, s, -z, y}, {y, z, s, -x}, {z, -y, x, s}};
+        const double Rc[4][3] = {{-ox, -oy, -oz}, {os, oz, -oy}, {-oz, os, ox}, {oy, -ox, os}};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) PRb[i * 3 + j] = Lr[i][0] * Rc[0][j] + Lr[i][1] * Rc[1][j] + Lr[i][2] * Rc[2][j] + Lr[i][3] * Rc[3][j];
+    }
+    const double PTa[9] = {0, -2 * RaTw[2], 2 * RaTw[1], 2 * RaTw[2], 0, -2 * RaTw[0], -2 * RaTw[1], 2 * RaTw[0], 0};
+    const double PRa[9] = {-e[0], -e[3], e[2], e[3], -e[0], -e[1], -e[2], e[1], -e[0]};
+#pragma unroll
+    for (int row = 0; row < 5; row++) {
+        double s[3];
+        row_sel(c, row, s);
+        const double s0 = s[0], s1 = s[1], s2 = s[2];
+        double pb3[3], pa3[3];
+        if (row < 3) {   // translational, or (row 2) either kind
+            const double vT = s0 * gT[0] + s1 * gT[1] + s2 * gT[2];
+            double vR = 0.0;
+            if (row == 2) vR = s0 * e[1] + s1 * e[2] + s2 * e[3];
+            const bool rot = row == 2 && rot2;
+            g[row] = rot ? vR : vT;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double xt = s0 * Ra[k * 3] + s1 * Ra[k * 3 + 1] + s2 * Ra[k * 3 + 2];
+                XT[row][k] = rot ? 0.0 : xt;
+                const double ptb = s0 * PTb[k] + s1 * PTb[3 + k] + s2 * PTb[6 + k];
+                const double pta = s0 * PTa[k] + s1 * PTa[3 + k] + s2 * PTa[6 + k];
+                if (row == 2) {
+                    const double prb = s0 * PRb[k] + s1 * PRb[3 + k] + s2 * PRb[6 + k], pra = s0 * PRa[k] + s1 * PRa[3 + k] + s2 * PRa[6 + k];
+                    pb3[k] = rot ? prb : ptb; pa3[k] = rot ? pra : pta;
+                } else { pb3[k] = ptb; pa3[k] = pta; }
+            }
+        } else {         // rotational
+            g[row] = s0 * e[1] + s1 * e[2] + s2 * e[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pb3[k] = s0 * PRb[k] + s1 * PRb[3 + k] + s2 * PRb[6 + k];
+                pa3[k] = s0 * PRa[k] + s1 * PRa[3 + k] + s2 * PRa[6 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            PB[row][k] = Nb ? (pb3[0] * Nb[k] + pb3[1] * Nb[3 + k] + pb3[2] * Nb[6 + k]) : pb3[k];
+            const double na = Na ? (pa3[0] * Na[k] + pa3[1] * Na[3 + k] + pa3[2] * Na[6 + k]) : pa3[k];
+            PA[row][k] = c.has_a ? na : 0.0;
+        }
+    }
+}
+
+// B' y for the child-side block (own[6]) and the parent-side block (par[6]) of a sparse Jacobian pair with unit x scales
+// (the constraint-force map uses G_k, whose x scales are 1)
+HD void jac_t_apply(const LinkC& c, const double (*XT)[3], const double (*PB)[3], const double (*PA)[3], const double* y, double* own, double* par) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double x = 0.0, pb = 0.0, pa = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) x += XT[r][k] * y[r];
+#pragma unroll
+        for (int r = 0; r < 5; r++) { pb += PB[r][k] * y[r]; pa += PA[r][k] * y[r]; }
+        own[k] = x; own[3 + k] = pb;
+        par[k] = c.has_a ? -x : 0.0; par[3 + k] = pa;
+    }
+}
+
+// ---- control error of the owned body (order x, v, qtilde, w: lqr.jl:92-95; raw vector part, no sign fix: lqr.jl:101-102)
+HD void ck_control_error(const double* z, const double* d, double* dz) {
+    const double qdc[4] = {d[3], -d[4], -d[5], -d[6]};
+    double qe[4];
+    qmul(qdc, z + 3, qe);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dz[i] = z[i] - d[i]; dz[3 + i] = z[7 + i] - d[7 + i]; dz[6 + i] = qe[1 + i]; dz[9 + i] = z[10 + i] - d[10 + i]; }
+}
+// passive joint friction (trackingLQR_triple_cartpole.jl:93-101): -fric * relative joint velocity; za = parent state (13) or the origin's
+HD double ck_friction(const LinkC& c, const double* z, const double* za) {
+    double rel;
+    if (c.type == 0) {
+        rel = c.axis[0] * z[10] + c.axis[1] * z[11] + c.axis[2] * z[12];
+        if (c.has_a) rel -= c.axis[0] * za[10] + c.axis[1] * za[11] + c.axis[2] * za[12];
+    } else {
+        double dv[3], dva[3], Ra[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dv[i] = z[7 + i] - (c.has_a ? za[7 + i] : 0.0);
+        rotmat(za + 3, Ra);
+        mtv3(Ra, dv, dva);
+        rel = c.axis[0] * dva[0] + c.axis[1] * dva[1] + c.axis[2] * dva[2];
+    }
+    return -c.fric * rel;
+}
+// control_pid! for the owned joint (pid.jl:69-88); za = parent state or the origin's
+HD double ck_pid(const LinkC& c, const double* z, const double* za, double P, double I, double D, double goal, double dt, bool first,
+                 double& pid_int, double& pid_last) {
+    double th;
+    if (c.type == 0) {
+        const double qac[4] = {za[3], -za[4], -za[5], -za[6]};
+        double rel[4], e[4];
+        qmul(qac, z + 3, rel);
+        qmul(rel, c.qoc, e);
+        th = 2.0 * atan2(c.axis[0] * e[1] + c.axis[1] * e[2] + c.axis[2] * e[3], e[0]);
+    } else {
+        double Ra[9], Rb[9], rp[3], w[3], gT[3];
+        rotmat(za + 3, Ra); rotmat(z + 3, Rb);
+        mv3(Rb, c.p2, rp);
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] = z[i] + rp[i] - za[i];
+        mtv3(Ra, w, gT);
+        th = c.axis[0] * (gT[0] - c.p1[0]) + c.axis[1] * (gT[1] - c.p1[1]) + c.axis[2] * (gT[2] - c.p1[2]);
+    }
+    const double PI = 3.14159265358979323846;
+    double e = goal - th;
+    if (c.type == 0) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
+    if (first) pid_last = e;
+    pid_int += e * dt;
+    const double de = (e - pid_last) / dt;
+    pid_last = e;
+    return P * e + I * pid_int + D * de;
+}
+
+// ---- joint input u of the own joint -> wrench on the own body (F world, tau body frame) and the reaction on the parent
+// body (Fp world, taup in the parent's frame), SURVEY 8a-bis 'Joint input'.  qa = parent orientation (identity for the origin).
+HD void ck_joint_wrench(const LinkC& c, double u, const double* q, const double* qa, double* F, double* tau, double* Fp, double* taup) {
+    double Ra[9], Rb[9];
+    rotmat(qa, Ra); rotmat(q, Rb);
+    const double f[3] = {c.axis[0] * u, c.axis[1] * u, c.axis[2] * u};
+    double fw[3], fb[3];
+    mv3(Ra, f, fw); mtv3(Rb, fw, fb);
+    if (c.type == 1) {
+        double cb[3], cp[3];
+        cross3(c.p2, fb, cb); cross3(c.p1, f, cp);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { F[i] = fw[i]; tau[i] = cb[i]; Fp[i] = -fw[i]; taup[i] = -cp[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { F[i] = 0.0; tau[i] = fb[i]; Fp[i] = 0.0; taup[i] = -f[i]; }
+    }
+}
+// per-step invariants of the owned body: cT = m(-v/dt + ez g') - F ; cR = -(sq1 I - [w1]x) J w1 - 2 tau
+HD void ck_step_invariants(const LinkC& c, const double* z, const double* F, const double* tau, double dt, double g, double* cT, double* cR) {
+    const double* v1 = z + 7; const double* w1 = z + 10;
+    const double sq1 = sqrt(4.0 / (dt * dt) - (w1[0] * w1[0] + w1[1] * w1[1] + w1[2] * w1[2]));
+    double Jw1[3], c1[3];
+    mv3(c.J, w1, Jw1); cross3(w1, Jw1, c1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        cT[i] = c.m * (-v1[i] / dt + (i == 2 ? -g : 0.0)) - F[i];
+        cR[i] = -(sq1 * Jw1[i] - c1[i]) - 2.0 * tau[i];
+    }
+}
+
+// ---- body at the trial solution s: next pose xq, residual d = dyn(s) - cf, with JAC also D_R^-1 and N D_R^-1; returns |d|^2
+template <bool JAC>
+HD double ck_body_eval(const LinkC& c, const double* z, const double* s, const double* cf, const double* cT, const double* cR, double dt,
+                       double* xq, double* d, double* DINV, double* NB) {
+    const double* w2 = s + 3;
+#pragma unroll
+    for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
+    const double inv_dt = fast_rcp(dt), m_dt = c.m * inv_dt;
+    const double sq2 = sqrt(4.0 * inv_dt * inv_dt - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
+    const double wb[4] = {0.5 * dt * sq2, 0.5 * dt * w2[0], 0.5 * dt * w2[1], 0.5 * dt * w2[2]};
+    qmul(z + 3, wb, xq + 3);
+    double Jw2[3], c2[3];
+    mv3(c.J, w2, Jw2); cross3(w2, Jw2, c2);
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double dT = m_dt * s[i] + cT[i] - cf[i], dR = sq2 * Jw2[i] + c2[i] + cR[i] - cf[3 + i];
+        d[i] = dT; d[3 + i] = dR;
+        acc += dT * dT + dR * dR;
+    }
+    if (!JAC) return acc;
+    const double S[9] = {sq2, -w2[2], w2[1], w2[2], sq2, -w2[0], -w2[1], w2[0], sq2};
+    double SJ[9], Dr[9], N[9];
+    mm3(S, c.J, SJ);
+    const double isq = fast_rcp(sq2);
+    const double Sj[9] = {0, -Jw2[2], Jw2[1], Jw2[2], 0, -Jw2[0], -Jw2[1], Jw2[0], 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Dr[i * 3 + j] = SJ[i * 3 + j] - Sj[i * 3 + j] - Jw2[i] * w2[j] * isq;
+    inv3(Dr, DINV);
+    make_N(w2, sq2, dt, N);
+    mm3(N, DINV, NB);
+    return acc;
+}
+
+// LDS slot of a joint's G_k (39 doubles): rows 0..2 = XT[3] PB[3] PA[3], rows 3, 4 = PB[3] PA[3]
+#define GKSZ 39
+HD int gk_row(int q) { return q < 3 ? 9 * q : 27 + 6 * (q - 3); }
+
+// next pose of the owned body for the solution s = (v+, w+): x+ = x + v+ dt ; q+ = q (dt/2)(sqrt(4/dt^2 - w+'w+), w+)  -- the same
+// expressions as in ck_body_eval, so the recomputed pose equals the one the residual was evaluated at
+HD void ck_next_pose(const double* z, const double* s, double dt, double* xq) {
+    const double* w2 = s + 3;
+#pragma unroll
+    for (int i = 0; i < 3; i++) xq[i] = z[i] + s[i] * dt;
+    const double inv_dt = fast_rcp(dt);
+    const double sq2 = sqrt(4.0 * inv_dt * inv_dt - (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]));
+    const double wb[4] = {0.5 * dt * sq2, 0.5 * dt * w2[0], 0.5 * dt * w2[1], 0.5 * dt * w2[2]};
+    qmul(z + 3, wb, xq + 3);
+}
+
+// ---- Schur complement blocks built by lane j (the owner of link j) straight into LDS, from its own W = G_v D^-1 =
+// (wXT, wPB, wPA; x scales sxb, sxa), which was just evaluated and lives in registers, and the G_k rows of its own, its
+// parent's and its child's joint, read from their LDS slots:
+//   S_jj = W_b[j] Gk_b[j]' + W_a[j] Gk_a[j]'   -> SJJ[j]
+//   S_jp = W_a[j] Gk_b[p]'                      -> SJP[j]      (p = j-1, when has_a)
+//   S_jc = W_b[j] Gk_a[c]'                      -> SPJ[c]      (c = j+1, when has_c: "S_{parent,child}" of the child's slot)
+//   r_j  = g_j - W_b d_b - W_a d_a              -> R[j]        (pd = residual of the parent body, from the parent lane)
+// One column q of the three blocks at a time.
+HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3],
+                      const double (*wPA)[3], const double* g, const double* d, const double* pd) {
+    const double sx = c.sxb + c.sxa;
+    const int jp = c.has_a ? j - 1 : j, jc = c.has_c ? j + 1 : j;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int o = gk_row(q), ob = q < 3 ? 3 : 0;   // offset of PB inside the row
+        double kx[3] = {0, 0, 0}, kpx[3] = {0, 0, 0}, kcx[3] = {0, 0, 0}, kb[3], ka[3], kpb[3], kca[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (q < 3) { kx[i] = L[Y.GKA + GKSZ * j + o + i]; kpx[i] = L[Y.GKA + GKSZ * jp + o + i]; kcx[i] = L[Y.GKA + GKSZ * jc + o + i]; }
+            kb[i] = L[Y.GKA + GKSZ * j + o + ob + i]; ka[i] = L[Y.GKA + GKSZ * j + o + ob + 3 + i];
+            kpb[i] = L[Y.GKA + GKSZ * jp + o + ob + i]; kca[i] = L[Y.GKA + GKSZ * jc + o + ob + 3 + i];
+        }
+        double ojj[5], ojp[5], ojc[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const double bb = wPB[r][0] * kb[0] + wPB[r][1] * kb[1] + wPB[r][2] * kb[2];
+            const double aa = wPA[r][0] * ka[0] + wPA[r][1] * ka[1] + wPA[r][2] * ka[2];
+            const double ajp = wPA[r][0] * kpb[0] + wPA[r][1] * kpb[1] + wPA[r][2] * kpb[2];
+            const double bjc = wPB[r][0] * kca[0] + wPB[r][1] * kca[1] + wPB[r][2] * kca[2];
+            if (r < 3 && q < 3) {
+                const double xx = wXT[r][0] * kx[0] + wXT[r][1] * kx[1] + wXT[r][2] * kx[2];
+                const double xjp = wXT[r][0] * kpx[0] + wXT[r][1] * kpx[1] + wXT[r][2] * kpx[2];
+                const double xjc = wXT[r][0] * kcx[0] + wXT[r][1] * kcx[1] + wXT[r][2] * kcx[2];
+                ojj[r] = sx * xx + bb + aa; ojp[r] = ajp - c.sxa * xjp; ojc[r] = bjc - c.sxb * xjc;
+            } else { ojj[r] = bb + aa; ojp[r] = ajp; ojc[r] = bjc; }
+        }
+        if (store) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) L[Y.SJJ + 25 * j + 5 * r + q] = ojj[r];
+            if (c.has_a) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) L[Y.SJP + 25 * j + 5 * r + q] = ojp[r];
+            }
+            if (c.has_c) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) L[Y.SPJ + 25 * jc + 5 * r + q] = ojc[r];
+            }
+        }
+    }
+    if (store) {
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const double bd = wPB[r][0] * d[3] + wPB[r][1] * d[4] + wPB[r][2] * d[5];
+            const double ad = wPA[r][0] * pd[3] + wPA[r][1] * pd[4] + wPA[r][2] * pd[5];
+            double rr = g[r] - bd - ad;
+            if (r < 3) {
+                const double xd = wXT[r][0] * d[0] + wXT[r][1] * d[1] + wXT[r][2] * d[2];
+                const double xa = wXT[r][0] * pd[0] + wXT[r][1] * pd[1] + wXT[r][2] * pd[2];
+                rr = g[r] - (c.sxb * xd + bd) - (ad - c.sxa * xa);
+            }
+            L[Y.R + 5 * j + r] = rr;
+        }
+    }
+}
+
+// G_k of the owned joint into its LDS slot / B' y against the slot's rows (own[6] child side, par[6] parent side)
+HD void gk_store(int j, const Lay& Y, double* L, const double (*XT)[3], const double (*PB)[3], const double (*PA)[3]) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int o = Y.GKA + GKSZ * j + gk_row(q), ob = q < 3 ? 3 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (q < 3) L[o + i] = XT[q][i];
+            L[o + ob + i] = PB[q][i]; L[o + ob + 3 + i] = PA[q][i];
+        }
+    }
+}
+HD void gk_t_apply(const LinkC& c, int j, const Lay& Y, const double* L, const double* y, double* own, double* par) {
+    double x[3] = {0, 0, 0}, pb[3] = {0, 0, 0}, pa[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int o = Y.GKA + GKSZ * j + gk_row(r), ob = r < 3 ? 3 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (r < 3) x[i] += L[o + i] * y[r];
+            pb[i] += L[o + ob + i] * y[r]; pa[i] += L[o + ob + 3 + i] * y[r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { own[i] = x[i]; own[3 + i] = pb[i]; par[i] = c.has_a ? -x[i] : 0.0; par[3 + i] = pa[i]; }
+}
+
+// ---- body solve: ds = D^-1 (d + cd) with cd = Gk_b(own joint)' dl + Gk_a(child joint)' dl_child (the latter arrives from the child lane)
+HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const double* DINV, double* ds) {
+    double tv[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) tv[k] = d[k] + cd[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ds[k] = tv[k] * c.dtm; ds[3 + k] = DINV[3 * k] * tv[3] + DINV[3 * k + 1] * tv[4] + DINV[3 * k + 2] * tv[5]; }
+}
+
+// LDS image of the chain kernel.  Gathered across lanes by the block-tridiagonal elimination: the Schur blocks, the
+// right-hand side R and the multiplier step DL.  Read by the neighbour lanes: the sparse G_k of every joint (GKA).  Private
+// per-lane slots that only relieve the register file: multipliers LAM, D_R^-1 (DINV), the per-step invariants cT|cR (D),
+// the constraint force C = G_k' lambda at the accepted point and the velocities at the step's start (S, read back only
+// when a step fails).  The state staging area (trajectory rows go to HBM through it so that the stores coalesce) and the
+// control error alias the Schur blocks, which are dead then.  150 doubles per link: 20.4 KB for the 17-body chain, so that
+// four workgroups of two instances fit a CU's 160 KB.
+HD Lay make_chain_layout(int nb) {
+    Lay L;
+    L.ST = L.LT = L.DS = L.XQ = L.NB = L.DTM = L.G = L.GKB = L.GVA = L.GVB = L.UJ = L.CD = L.SS = 0;
+    int o = 0;
+    L.SJJ = o; o += 25 * nb; L.SJP = o; o += 25 * nb; L.SPJ = o; o += 25 * nb;
+    L.R = o; o += 5 * nb; L.DL = o; o += 5 * nb;
+    L.GKA = o; o += GKSZ * nb;
+    L.LAM = o; o += 5 * nb;
+    L.DINV = o; o += 9 * nb;
+    L.D = o; o += 6 * nb;
+    L.C = o; o += 6 * nb;
+    L.S = o; o += 6 * nb;
+    L.Z = L.SJJ;               // 13 nb staging
+    L.DZ = L.SJJ + 13 * nb;    // 12 nb control error
+    L.total = o | 1;
+    return L;
+}
+
+}  // namespace cclqr

@@ -28,6 +28,10 @@ struct RolloutArgs {
 int rollout_lanes_per_instance(int nb, int tree);
 size_t rollout_lds_bytes(int nb, int tree, int npairs);
 hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream);
+// forests of chains (rollout_chain.hip)
+int chain_lanes_per_instance(int nb);
+size_t chain_lds_bytes(int nb);
+hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, hipStream_t stream);
 
 struct LinArgs {
     const MechDev* M;

@@ -121,11 +121,13 @@ extern "C" int cclqr_prof_read(unsigned long long* out, int reset) {
 
 // lanes per instance: one lane per link, and a tree needs 8 lanes per neighbour group of its elimination (up to CCLQR_MAXK groups)
 int rollout_lanes_per_instance(int nb, int tree) {
+    if (!tree) return chain_lanes_per_instance(nb);
     const int g = nb <= 4 ? 16 : (nb <= 8 ? 32 : 64);
     return tree > g ? (tree <= 16 ? 16 : (tree <= 32 ? 32 : 64)) : g;   // tree = lanes an elimination step needs (0 for chains)
 }
 
 size_t rollout_lds_bytes(int nb, int tree, int npairs) {
+    if (!tree) return chain_lds_bytes(nb);
     int G = rollout_lanes_per_instance(nb, tree);
     return (size_t)(64 / G) * make_layout(nb, tree ? 2 * npairs : 0).total * sizeof(double);
 }
@@ -139,17 +141,13 @@ static hipError_t launch_one(const RolloutArgs& a, unsigned grid, size_t lds, hi
 }
 
 hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream) {
+    if (!tree) return launch_rollout_chain(a, nb, stream);   // forests of chains: the register-resident kernel (rollout_chain.hip)
     const int G = rollout_lanes_per_instance(nb, tree);
     const int per_wg = 64 / G;
     const size_t lds = rollout_lds_bytes(nb, tree, npairs);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
-    if (tree) return G == 16 ? launch_one<16, true>(a, grid, lds, stream) : (G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream));
-    switch (G) {
-        case 16: return launch_one<16, false>(a, grid, lds, stream);
-        case 32: return launch_one<32, false>(a, grid, lds, stream);
-        default: return launch_one<64, false>(a, grid, lds, stream);
-    }
+    return G == 16 ? launch_one<16, true>(a, grid, lds, stream) : (G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream));
 }
 
 }  // namespace cclqr

@@ -20,9 +20,13 @@ def emu_rollout(emu, orc, t, ctrl, z0, steps, noise=None, G=0):
     traj = np.zeros((n, steps, t.nb, 13))
     zT = np.zeros_like(z0)
     st = np.zeros(n, dtype=np.int32)
-    rc = emu.emu_rollout(C.byref(m.desc), C.byref(ctrl.desc), C.c_int64(n), C.c_int(steps), C.c_int(1), z0.ctypes.data_as(dp),
-                         None if noise is None else noise.ctypes.data_as(dp), traj.ctypes.data_as(dp), zT.ctypes.data_as(dp),
-                         st.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(G))
+    args = (C.byref(m.desc), C.byref(ctrl.desc), C.c_int64(n), C.c_int(steps), C.c_int(1), z0.ctypes.data_as(dp),
+            None if noise is None else noise.ctypes.data_as(dp), traj.ctypes.data_as(dp), zT.ctypes.data_as(dp),
+            st.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(G))
+    # forests of chains run the register-resident chain kernel (csrc/rollout_chain.hip), branched mechanisms the tree kernel
+    rc = emu.emu_chain_rollout(*args)
+    if rc == -5:
+        rc = emu.emu_rollout(*args)
     assert rc == 0
     return zT, traj, st
 
