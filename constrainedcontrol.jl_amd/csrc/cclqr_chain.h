@@ -414,13 +414,12 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
 // LDS image of the chain kernel.  Gathered across lanes by the block-tridiagonal elimination: the Schur blocks, the
 // right-hand side R and the multiplier step DL.  Read by the neighbour lanes: the sparse G_k of every joint (GKA).  Private
 // per-lane slots that only relieve the register file: multipliers LAM, D_R^-1 (DINV), the per-step invariants cT|cR (D),
-// the constraint force C = G_k' lambda at the accepted point and the velocities at the step's start (S, read back only
-// when a step fails).  The state staging area (trajectory rows go to HBM through it so that the stores coalesce) and the
+// the constraint force C = G_k' lambda at the accepted point.  The state staging area (trajectory rows go to HBM through it so that the stores coalesce) and the
 // control error alias the Schur blocks, which are dead then.  150 doubles per link: 20.4 KB for the 17-body chain, so that
 // four workgroups of two instances fit a CU's 160 KB.
 HD Lay make_chain_layout(int nb) {
     Lay L;
-    L.ST = L.LT = L.DS = L.XQ = L.NB = L.DTM = L.G = L.GKB = L.GVA = L.GVB = L.UJ = L.CD = L.SS = 0;
+    L.S = L.ST = L.LT = L.DS = L.XQ = L.NB = L.DTM = L.G = L.GKB = L.GVA = L.GVB = L.UJ = L.CD = L.SS = 0;
     int o = 0;
     L.SJJ = o; o += 25 * nb; L.SJP = o; o += 25 * nb; L.SPJ = o; o += 25 * nb;
     L.R = o; o += 5 * nb; L.DL = o; o += 5 * nb;
@@ -429,7 +428,6 @@ HD Lay make_chain_layout(int nb) {
     L.DINV = o; o += 9 * nb;
     L.D = o; o += 6 * nb;
     L.C = o; o += 6 * nb;
-    L.S = o; o += 6 * nb;
     L.Z = L.SJJ;               // 13 nb staging
     L.DZ = L.SJJ + 13 * nb;    // 12 nb control error
     L.total = o | 1;

@@ -48,7 +48,7 @@ struct LinkS {
 // (The full-step trial is evaluated with JAC on the speculation that it is accepted; if it is not, the accepted point is
 // evaluated again, which overwrites these rows.)
 template <int G, bool JAC>
-__device__ __forceinline__ double chain_eval(const LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, double dt) {
+__device__ __forceinline__ double chain_eval(const LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, double dt PROF_ARG) {
     double part = 0.0;
     double NB[9], g[5], xq[7];
 #pragma unroll
@@ -63,6 +63,7 @@ __device__ __forceinline__ double chain_eval(const LinkC& c, LinkS& S, int t, co
             for (int k = 0; k < 9; k++) L[Y.DINV + 9 * t + k] = DINV[k];
         }
     }
+    STAMP(PF_EVAL_BODY);
     double pxq[7], pNB[9];
     from_prev<7>(xq, pxq);
     if (JAC) from_prev<9>(NB, pNB);
@@ -76,12 +77,17 @@ __device__ __forceinline__ double chain_eval(const LinkC& c, LinkS& S, int t, co
 #pragma unroll
         for (int i = 0; i < 5; i++) part += g[i] * g[i];
     }
+    STAMP(PF_EVAL_JOINT);
     if (JAC) {
         double pd[6];
         from_prev<6>(S.d, pd);
         ck_schur_rows(c, t, active, Y, L, wXT, wPB, wPA, g, S.d, pd);
+        STAMP(PF_SCHUR_S);
     }
-    return sqrt(group_sum<G>(part));
+    const double nrm = sqrt(group_sum<G>(part));
+    STAMP(PF_EVAL_MAP);
+    PCOUNT(PF_EVALS);
+    return nrm;
 }
 
 template <int G>
@@ -120,6 +126,10 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = a.lam[inst * 5 * nb + 5 * t + i];
     }
 
+#ifdef CCLQR_PROFILE
+    Prof prof;
+    prof.start();
+#endif
     int worst = 0;
     bool bad = false, dead = false;    // dead: a step produced a non-finite residual; the instance is frozen from then on
     for (int kk = 0; kk < a.steps; kk++) {
@@ -138,10 +148,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             }
             __syncthreads();
         }
-        if (on) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) L[Y.S + 6 * t + i] = S.s[i];     // velocities at the step's start (restored if the step fails)
-        }
+        STAMP(PF_IO);
         // ---------------- feedback law (lqr.jl:89-139 / lqr_tracking.jl:46-71)
         const bool gate = (C->N <= 0) || (k < C->N);
         const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         if (C->has_pid) {
             if (on && C->pid_on[t]) uj += ck_pid(c, zf, za, C->pid_P[t], C->pid_I[t], C->pid_D[t], C->pid_goal[t], dt, k == 1, pid_int, pid_last);
         }
+        STAMP(PF_CONTROL);
         // ---------------- joint inputs -> wrenches, per-step invariants, constraint Jacobians at the current knot, force map
         {
             double F[3], tau[3], W6[6], cW6[6];
@@ -217,15 +225,18 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         }
         __syncthreads();
 
+        STAMP(PF_FORCES);
+        PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         const bool go = valid && !dead;
         bool done = !go, failed = false;
         int its = 0;
-        double normf0 = chain_eval<G, true>(c, S, t, Y, L, 0.0, on && !done, dt);
+        double normf0 = chain_eval<G, true>(c, S, t, Y, L, 0.0, on && !done, dt PROF_PASS);
         __syncthreads();
         const int nchains = M->nchains;
         for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
             if (!__any(!done)) break;
+            PCOUNT(PF_NEWTON_ITERS);
             const bool active = on && !done;
             // block-tridiagonal solve along each chain, swept from both ends (cclqr_dev.h S3)
             for (int ci = 0; ci < nchains; ci++) {
@@ -237,12 +248,14 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     if (act) ph_tri_store(t, l, Y, L, zy);
                     __syncthreads();
                 }
+                STAMP(PF_TRI_FWD);
                 if (!done) ph_tri_mid(t, P, Y, L);
                 __syncthreads();
                 for (int j = 0; j < P.steps; j++) {
                     if (!done) ph_tri_back(t, j, P, Y, L);
                     __syncthreads();
                 }
+                STAMP(PF_TRI_BWD);
             }
             double nd;
             {   // multiplier step from LDS, body solve
@@ -266,12 +279,13 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 nd = sqrt(group_sum<G>(pdn));
             }
             __syncthreads();
+            STAMP(PF_BODY_SOLVE);
             // line search: halve while ||f|| grows.  The first (full-step) trial also evaluates the Jacobians, speculating that
             // it is accepted; later trials evaluate the residual only.
             double alpha = 1.0, normf1 = 0.0;
             bool ls_done = done, jac_ok = true;
             {
-                const double nf = chain_eval<G, true>(c, S, t, Y, L, 1.0, active, dt);
+                const double nf = chain_eval<G, true>(c, S, t, Y, L, 1.0, active, dt PROF_PASS);
                 if (!ls_done) {
                     normf1 = nf;
                     if (!(normf1 > normf0)) ls_done = true;
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             for (int lv = 1; lv <= LINE_MAXIT; lv++) {
                 if (!__any(!ls_done)) break;
                 const double a_l = ldexp(1.0, -lv);
-                const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, on && !ls_done, dt);
+                const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, on && !ls_done, dt PROF_PASS);
                 if (!ls_done) {
                     normf1 = nf; alpha = a_l; jac_ok = false;
                     if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
@@ -300,19 +314,18 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 normf0 = normf1;
                 need_jac = !done && !jac_ok;
             }
-            if (__any(need_jac)) chain_eval<G, true>(c, S, t, Y, L, 0.0, on && need_jac, dt);
+            STAMP(PF_ACCEPT);
+            if (__any(need_jac)) chain_eval<G, true>(c, S, t, Y, L, 0.0, on && need_jac, dt PROF_PASS);
             __syncthreads();
         }
         const bool conv = done && !failed;
         if (go) {
             if (!conv) bad = true;
             if (its > worst) worst = its;
-            if (!conv && its < NEWTON_MAXIT) {   // stopped early on a non-finite residual: freeze the instance at the step's start
+            if (!conv && its < NEWTON_MAXIT) {   // stopped early on a non-finite residual: freeze the instance at its last pose, at rest
                 dead = true;
-                if (on) {
 #pragma unroll
-                    for (int i = 0; i < 6; i++) S.s[i] = L[Y.S + 6 * t + i];
-                }
+                for (int i = 0; i < 6; i++) S.s[i] = 0.0;
             } else if (on) {
                 double xq[7];
                 ck_next_pose(S.z, S.s, dt, xq);
@@ -321,6 +334,10 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             }
         }
     }
+#ifdef CCLQR_PROFILE
+    prof.stamp(PF_IO);
+    prof.flush();
+#endif
     // ---------------- final state, multipliers, status
     __syncthreads();
     if (on) {
@@ -342,6 +359,14 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         if (a.pid_state) { a.pid_state[(inst * nb + t) * 2] = pid_int; a.pid_state[(inst * nb + t) * 2 + 1] = pid_last; }
     }
 }
+
+#ifdef CCLQR_PROFILE
+extern "C" int cclqr_prof_read_chain(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PF_N);
+    if (e == hipSuccess && reset) { unsigned long long z[PF_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return e == hipSuccess ? PF_N : -1;
+}
+#endif
 
 // 16 lanes per instance up to 8 links (the two elimination fronts need 14), 32 beyond: with 16 lanes a 9..16-link instance would
 // fill LDS with two wavefronts per CU

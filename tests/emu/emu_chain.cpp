@@ -123,7 +123,6 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                     for (int i = 0; i < 7; i++) dst[i] = I.S[t].z[i];
                     for (int i = 0; i < 6; i++) dst[7 + i] = I.S[t].s[i];
                 }
-            for (int t = 0; t < nb; t++) for (int i = 0; i < 6; i++) L[Y.S + 6 * t + i] = I.S[t].s[i];
             const bool gate = (C->N <= 0) || (k < C->N);
             const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
             const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
@@ -233,7 +232,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                 if (its > worst) worst = its;
                 if (!conv && its < 100) {
                     dead = true;
-                    for (int t = 0; t < nb; t++) for (int i = 0; i < 6; i++) I.S[t].s[i] = L[Y.S + 6 * t + i];
+                    for (int t = 0; t < nb; t++) for (int i = 0; i < 6; i++) I.S[t].s[i] = 0.0;
                 } else
                     for (int t = 0; t < nb; t++) {
                         double xq[7];

@@ -16,10 +16,12 @@ gold = os.path.join(g.ROOT, "tests", "golden", "chain16_hanging_cfg3.npz")
 K = np.tile(np.load(gold)["K_first"][None], (999, 1, 1)) if n_links == 16 else rng.normal(size=(999, 1, 12 * t.nb)) * 0.05
 mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, [0], K=K, N=1000, zd=zd)
 names = ["control", "forces+knotjac", "eval_body", "eval_joint", "eval_map+norm", "schur_w", "schur_s", "tri_fwd", "tri_bwd", "body_solve", "trial", "accept", "io"]
+_nchild = np.bincount(np.asarray(t.parent)[np.asarray(t.parent) >= 0], minlength=t.nb)
+read = capi.lib().cclqr_prof_read if (_nchild > 1).any() else capi.lib().cclqr_prof_read_chain
 buf = (C.c_ulonglong * 16)()
-capi.lib().cclqr_prof_read(buf, 1)
+read(buf, 1)
 t0 = time.time(); zT, _, st = capi.rollout(mh, ctrl, z0, steps); dt = time.time() - t0
-capi.lib().cclqr_prof_read(buf, 1)
+read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 tot = v[:13].sum()
 print("n_links %d inst %d steps %d: %.3fs %.3g inst-steps/s; newton iters/step %.2f evals/step %.2f" % (n_links, ninst, steps, dt, ninst * steps / dt, v[13] / v[15], v[14] / v[15]))
