@@ -15,7 +15,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
+           "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
 class CclqrError(RuntimeError):
@@ -34,7 +34,11 @@ class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
                 ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
                 ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp),
-                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64)]
+                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64), ("n_ctrl", C.c_int32)]
+
+
+class RolloutOpts(C.Structure):
+    _fields_ = [("first_instance", C.c_int64), ("pid_state_dev", C.c_void_p), ("pid_state_len", C.c_int64)]
 
 
 _lib = None
@@ -138,16 +142,18 @@ class MechHandle:
 class CtrlHandle:
     """cclqr_ctrl*: device-resident controller tables"""
 
-    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, pid=None, noise_seed=None):
+    def __init__(self, mech, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, pid=None, noise_seed=None, n_ctrl=0):
+        """n_ctrl > 1: one controller table per instance -- K [n_ctrl][nK][mu][12 nb], zd [n_ctrl][nsp][nb][13], Fd [n_ctrl][nsp][mu]"""
         nb = mech.tables.nb
         cj = i32(ctrl_joint).reshape(-1)
         mu = len(cj)
+        nc = n_ctrl if n_ctrl > 1 else 1
         if zd is None:
-            zd = np.zeros((1, nb, 13))
+            zd = np.zeros((nc, nb, 13))
             zd[:, :, 3] = 1.0
         zd = f64(zd).reshape(-1, nb, 13)
-        nsp = zd.shape[0]
-        Fd = f64(np.zeros((nsp, mu)) if Fd is None else Fd).reshape(nsp, mu)
+        nsp = zd.shape[0] // nc
+        Fd = f64(np.zeros((nc * nsp, mu)) if Fd is None else Fd).reshape(nc * nsp, mu)
         K = None if K is None else f64(K).reshape(-1, mu, 12 * nb)
         fric = None if fric is None else f64(fric).reshape(nb)
         pj = pP = pI = pD = pg = None
@@ -155,9 +161,9 @@ class CtrlHandle:
             pj, pP, pI, pD, pg = i32(pid["joint"]).reshape(-1), f64(pid["P"]).reshape(-1), f64(pid["I"]).reshape(-1), f64(pid["D"]).reshape(-1), f64(pid["goal"]).reshape(-1)
         self._arrs = [cj, K, zd, Fd, fric, pj, pP, pI, pD, pg]
         self.mu, self.N, self.nsp = mu, int(N), nsp
-        self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0], int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale),
+        self.desc = CtrlDesc(mu, _i(cj), 0 if K is None else K.shape[0] // nc, int(N), _d(K), nsp, _d(zd), _d(Fd), _d(fric), float(noise_scale),
                              0 if pj is None else len(pj), _i(pj), _d(pP), _d(pI), _d(pD), _d(pg),
-                             0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed))
+                             0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed), int(n_ctrl))
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
 
@@ -201,11 +207,19 @@ def set_instance_offset(first_instance):
     check(lib().cclqr_set_instance_offset(C.c_int64(int(first_instance))))
 
 
-def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0):
-    """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous"""
+def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0,
+                first_instance=None, pid_state=None):
+    """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
+    first_instance / pid_state given: cclqr_rollout_ex with explicit options (pid_state = device address of [n_inst][nb][2] doubles);
+    neither given: the legacy entry point cclqr_rollout_dev (thread-local setters)"""
     vp = lambda p: C.c_void_p(int(p)) if p else None
-    check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
-                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
+    if first_instance is None and pid_state is None:
+        check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
+                                      vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
+        return
+    o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.nb * 2 if pid_state else 0)
+    check(lib().cclqr_rollout_ex(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
+                                 vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), C.byref(o), vp(stream)))
 
 
 def linearize(mech, zd, ctrl_joint, Fd=None):

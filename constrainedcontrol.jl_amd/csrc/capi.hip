@@ -73,6 +73,8 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     }
     c->host = T.H;
     c->host.K = c->K_dev; c->host.zd = c->zd_dev; c->host.Fd = c->Fd_dev;
+    if (!c->Fd_dev) c->host.Fd_stride = 0;
+    if (!c->K_dev) c->host.K_stride = 0;
     if (e == hipSuccess) e = hipMalloc((void**)&c->dev, sizeof(CtrlDev));
     if (e == hipSuccess) e = hipMemcpy(c->dev, &c->host, sizeof(CtrlDev), hipMemcpyHostToDevice);
     if (e != hipSuccess) { cclqr_ctrl_destroy(c); return fail(CCLQR_EHIP, std::string("controller upload: ") + hipGetErrorString(e)); }
@@ -85,17 +87,16 @@ extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
     if (c->K_dev) (void)hipFree(c->K_dev);
     if (c->zd_dev) (void)hipFree(c->zd_dev);
     if (c->Fd_dev) (void)hipFree(c->Fd_dev);
+    if (c->noise_ws) (void)hipFree(c->noise_ws);
     if (c->dev) (void)hipFree(c->dev);
     delete c;
     return CCLQR_OK;
 }
 
-// global index of the first instance of the next launches on this thread (Philox noise streams are indexed by GLOBAL instance so a
-// sharded batch reproduces the unsharded one); 0 unless the caller shards
+// Deprecated thread-local defaults of cclqr_rollout_opts (kept one round; cclqr_rollout_ex takes them as arguments).
 static thread_local int64_t g_inst0 = 0;
 extern "C" int cclqr_set_instance_offset(int64_t first_instance) { g_inst0 = first_instance; return CCLQR_OK; }
-
-// device buffer that carries the PID integrators between the following device-pointer launches of this thread (nullptr: none)
+// forwarded to cclqr_rollout_dev launches of this thread with a PID controller only (never to the host-pointer cclqr_rollout)
 static thread_local double* g_pid_state = nullptr;
 extern "C" int cclqr_set_pid_state(double* pid_state_dev) { g_pid_state = pid_state_dev; return CCLQR_OK; }
 
@@ -106,19 +107,51 @@ extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32
     return CCLQR_OK;
 }
 
-extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
-                                 double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
-                                 void* stream) {
+extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                                double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
+                                const cclqr_rollout_opts* opts, void* stream) {
     if (m && c && n_inst == 0) return CCLQR_OK;   // empty batch
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
     if (rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    const int64_t first = opts ? opts->first_instance : 0;
+    if (first < 0) return fail(CCLQR_EINVAL, "negative first_instance");
+    if (c->host.n_ctrl > 1 && first + n_inst > c->host.n_ctrl) return fail(CCLQR_EINVAL, "more instances than per-instance controller tables");
+    const CtrlDev& H = c->host;
+    double* pid_state = (opts && H.has_pid) ? opts->pid_state_dev : nullptr;      // never forwarded to a controller without a PID law
+    if (pid_state && opts->pid_state_len != n_inst * (int64_t)m->nb * 2) return fail(CCLQR_EINVAL, "pid_state_len must be n_inst * nb * 2");
+    // counter-based noise: generated for this launch into the handle's workspace, read by the rollout like an injected array
+    const bool use_noise = H.noise_scale != 0.0 && H.mu > 0;
+    if (use_noise && !noise && H.noise_philox && steps > 0) {
+        cclqr_ctrl* cm = const_cast<cclqr_ctrl*>(c);
+        const size_t need = (size_t)n_inst * steps;
+        if (cm->noise_ws_cap < need) {
+            if (cm->noise_ws) HIPCHK(hipFree(cm->noise_ws));
+            cm->noise_ws = nullptr; cm->noise_ws_cap = 0;
+            HIPCHK(hipMalloc((void**)&cm->noise_ws, need * sizeof(double)));
+            cm->noise_ws_cap = need;
+        }
+        HIPCHK(launch_philox_fill(cm->noise_ws, H.noise_key0, first, n_inst, k0, steps, (hipStream_t)stream));
+        noise = cm->noise_ws - (k0 - 1);      // indexed by the absolute step k-1
+        noise_stride = steps;
+    }
+    const int extra = H.has_pid ? 2 : ((H.has_fric || (use_noise && noise)) ? 1 : 0);
     RolloutArgs a;
-    a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = noise;
-    a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = g_inst0; a.pid_state = g_pid_state;
-    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, (hipStream_t)stream));
+    a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
+    a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
+    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, (hipStream_t)stream));
     return CCLQR_OK;
+}
+
+extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                                 double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
+                                 void* stream) {
+    cclqr_rollout_opts o;
+    o.first_instance = g_inst0;
+    o.pid_state_dev = g_pid_state;
+    o.pid_state_len = (m && n_inst > 0) ? n_inst * (int64_t)m->nb * 2 : 0;     // the legacy setter carries no length
+    return cclqr_rollout_ex(m, c, n_inst, steps, k0, z0, lam, noise, noise_stride, traj, zT, status, &o, stream);
 }
 
 extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
@@ -139,7 +172,9 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
     if (e == hipSuccess) {
         // noise is indexed by the absolute step k-1: shift the base so that k0 maps to column 0 of the caller's array
         const double* nbase = dnoise ? dnoise - (k0 - 1) : nullptr;
-        rc = cclqr_rollout_dev(m, c, n_inst, steps, k0, dz0, nullptr, nbase, steps, dtraj, dzT, dst, nullptr);
+        cclqr_rollout_opts o;
+        o.first_instance = g_inst0; o.pid_state_dev = nullptr; o.pid_state_len = 0;
+        rc = cclqr_rollout_ex(m, c, n_inst, steps, k0, dz0, nullptr, nbase, steps, dtraj, dzT, dst, &o, nullptr);
         if (rc == CCLQR_OK) e = hipDeviceSynchronize();
     }
     if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(zT, dzT, n_inst * nz * sizeof(double), hipMemcpyDeviceToHost);

@@ -20,6 +20,13 @@
 #pragma once
 #include "cclqr_dev.h"
 
+// the instruction scheduler must not move code across this point (device code only; the host build of tests/emu ignores it)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE() ((void)0)
+#endif
+
 namespace cclqr {
 
 // ---- constants of the owned link.  The five constraint rows are (Revolute) e0 e1 e2 | V1 V2 or (Prismatic) V1 V2 | e0 e1 e2
@@ -198,6 +205,13 @@ HD double ck_friction(const LinkC& c, const double* z, const double* za) {
     }
     return -c.fric * rel;
 }
+// joint angle of a revolute from the relative quaternion: 2 atan2(axis . e_v, e_s).  Not inlined on the device: atan2's polynomial
+// constants would otherwise sit in ~20 scalar registers for the whole persistent kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) double pid_angle(double sn, double cs) { return 2.0 * atan2(sn, cs); }
+#else
+inline double pid_angle(double sn, double cs) { return 2.0 * atan2(sn, cs); }
+#endif
 // control_pid! for the owned joint (pid.jl:69-88); za = parent state or the origin's
 HD double ck_pid(const LinkC& c, const double* z, const double* za, double P, double I, double D, double goal, double dt, bool first,
                  double& pid_int, double& pid_last) {
@@ -207,7 +221,7 @@ HD double ck_pid(const LinkC& c, const double* z, const double* za, double P, do
         double rel[4], e[4];
         qmul(qac, z + 3, rel);
         qmul(rel, c.qoc, e);
-        th = 2.0 * atan2(c.axis[0] * e[1] + c.axis[1] * e[2] + c.axis[2] * e[3], e[0]);
+        th = pid_angle(c.axis[0] * e[1] + c.axis[1] * e[2] + c.axis[2] * e[3], e[0]);
     } else {
         double Ra[9], Rb[9], rp[3], w[3], gT[3];
         rotmat(za + 3, Ra); rotmat(z + 3, Rb);
@@ -346,18 +360,19 @@ HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L
                 ojj[r] = sx * xx + bb + aa; ojp[r] = ajp - c.sxa * xjp; ojc[r] = bjc - c.sxb * xjc;
             } else { ojj[r] = bb + aa; ojp[r] = ajp; ojc[r] = bjc; }
         }
-        if (store) {
+        if (store) {     // blocks are stored column by column (element (r, q) at 5 q + r): a column is five consecutive doubles
 #pragma unroll
-            for (int r = 0; r < 5; r++) L[Y.SJJ + 25 * j + 5 * r + q] = ojj[r];
+            for (int r = 0; r < 5; r++) L[Y.SJJ + 25 * j + 5 * q + r] = ojj[r];
             if (c.has_a) {
 #pragma unroll
-                for (int r = 0; r < 5; r++) L[Y.SJP + 25 * j + 5 * r + q] = ojp[r];
+                for (int r = 0; r < 5; r++) L[Y.SJP + 25 * j + 5 * q + r] = ojp[r];
             }
             if (c.has_c) {
 #pragma unroll
-                for (int r = 0; r < 5; r++) L[Y.SPJ + 25 * jc + 5 * r + q] = ojc[r];
+                for (int r = 0; r < 5; r++) L[Y.SPJ + 25 * jc + 5 * q + r] = ojc[r];
             }
         }
+        SCHED_FENCE();     // keep the next column's loads behind this column's arithmetic: hoisting all five columns' loads costs ~90 registers
     }
     if (store) {
 #pragma unroll
@@ -409,6 +424,116 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
     for (int k = 0; k < 6; k++) tv[k] = d[k] + cd[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) { ds[k] = tv[k] * c.dtm; ds[3 + k] = DINV[3 * k] * tv[3] + DINV[3 * k + 1] * tv[4] + DINV[3 * k + 2] * tv[5]; }
+}
+
+// ================================================================== block-tridiagonal solve (chain kernel version)
+// Same twisted two-front elimination as cclqr_dev.h S3 (front 0 = lanes 0..5 sweeps from the leaf, front 1 = lanes 8..13 from
+// the root; lane (t & 7) = c < 5 owns column c of Z = S_ll^-1 S_lq and of the update of S_qq, lane 5 owns y = S_ll^-1 r_l and
+// the update of r_q), re-cut for latency, since one wavefront per SIMD has nothing to hide it with:
+//  * blocks are column-major, so every lane's right-hand side, target and result are five consecutive doubles;
+//  * every offset is a per-lane cursor advanced by a constant per step (no index arithmetic in the loop);
+//  * loads are issued in the order of need (S_ll, right-hand side, target, S_ql), so the pivot chain of the factorisation
+//    starts after the first 25 and hides the rest (carrying prefetched blocks across the barrier in registers instead made
+//    the register allocator spill all over the kernel);
+struct TriCur {
+    int oLL, oQL, oRhs, oTgt, oOut;   // LDS offsets at the current step: S_ll, S_ql, this lane's right-hand side (column c of S_lq, or
+                                      // r_l), its target (column c of S_qq, or r_q) and where its solution goes (column c of S_ll, or r_l)
+    int dblk, dvec;                   // per-step increments of the block offsets / of this lane's vector offsets
+    int n;                            // steps of this lane's front (0: the lane takes no part)
+    bool isy;
+};
+HD TriCur tri_cursor(int t, const TriPlan& P, const Lay& Y) {
+    TriCur K;
+    const int front = t >> 3, col = t & 7;
+    const bool in = t < 16 && col < 6;
+    K.n = in ? (front ? P.nB : P.nA) : 0;
+    K.isy = col == 5;
+    const int l = front ? P.cs : P.cs + P.cn - 1, q = front ? l + 1 : l - 1;
+    const int b = front ? q : l;                           // the link whose (SJP, SPJ) pair couples l and q
+    const int cc = col < 5 ? col : 0;
+    K.dblk = front ? 25 : -25;
+    K.dvec = K.isy ? (front ? 5 : -5) : K.dblk;
+    K.oLL = Y.SJJ + 25 * l;
+    K.oQL = (front ? Y.SJP : Y.SPJ) + 25 * b;
+    K.oRhs = K.isy ? Y.R + 5 * l : (front ? Y.SPJ : Y.SJP) + 25 * b + 5 * cc;
+    K.oTgt = K.isy ? Y.R + 5 * q : Y.SJJ + 25 * q + 5 * cc;
+    K.oOut = K.isy ? Y.R + 5 * l : Y.SJJ + 25 * l + 5 * cc;
+    return K;
+}
+// LU (no pivoting; S is SPD-like) of the row-major 5x5 block A in registers, packed as in lu5 (cclqr_dev.h)
+HD void lu5_factor(double* A) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double inv = fast_rcp(A[k * 5 + k]);
+        A[k * 5 + k] = inv;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) {
+            const double f = A[i * 5 + k] * inv;
+            A[i * 5 + k] = f;
+#pragma unroll
+            for (int j = k + 1; j < 5; j++) A[i * 5 + j] -= f * A[k * 5 + j];
+        }
+    }
+}
+// One elimination step of this lane: tg = updated target column, zy = solution column, to be stored by the caller at *otg,
+// *oout AFTER every lane has done its loads (the caller's store sits behind this call in the wavefront's instruction stream).
+// Load order = order of need: S_ll (the LU starts as soon as it has arrived), the right-hand side, the target, and S_ql last
+// (only the final update reads it), so that most of the loads' latency hides under the pivot chain of the factorisation.
+// Returns false (and touches nothing) when the lane has no work in step i.
+HD bool tri_step(TriCur& K, int i, const double* L, double* tg, double* zy, int* otg, int* oout) {
+    if (i >= K.n) return false;
+    double lu[25], sql[25];
+#pragma unroll
+    for (int cI = 0; cI < 5; cI++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) lu[r * 5 + cI] = L[K.oLL + 5 * cI + r];
+#pragma unroll
+    for (int r = 0; r < 5; r++) zy[r] = L[K.oRhs + r];
+#pragma unroll
+    for (int r = 0; r < 5; r++) tg[r] = L[K.oTgt + r];
+#pragma unroll
+    for (int e = 0; e < 25; e++) sql[e] = L[K.oQL + e];
+    lu5_factor(lu);
+    lu5_solve(lu, zy);
+#pragma unroll
+    for (int r = 0; r < 5; r++) tg[r] -= sql[r] * zy[0] + sql[5 + r] * zy[1] + sql[10 + r] * zy[2] + sql[15 + r] * zy[3] + sql[20 + r] * zy[4];
+    *otg = K.oTgt; *oout = K.oOut;
+    K.oLL += K.dblk; K.oQL += K.dblk; K.oRhs += K.dvec; K.oTgt += K.dvec; K.oOut += K.dvec;
+    return true;
+}
+HD void tri_step_store(double* L, int otg, int oout, const double* tg, const double* zy) {
+#pragma unroll
+    for (int r = 0; r < 5; r++) { L[otg + r] = tg[r]; L[oout + r] = zy[r]; }
+}
+// middle link: both sides have been folded in; one lane factorises and solves
+HD void ck_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
+    if (t != 0) return;
+    double A[25], b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) b[i] = L[Y.R + 5 * P.mid + i];
+#pragma unroll
+    for (int cI = 0; cI < 5; cI++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) A[r * 5 + cI] = L[Y.SJJ + 25 * P.mid + 5 * cI + r];
+    lu5_factor(A);
+    lu5_solve(A, b);
+#pragma unroll
+    for (int i = 0; i < 5; i++) L[Y.DL + 5 * P.mid + i] = b[i];
+}
+// back substitution step j: dl_l = y_l - Z_l dl_nbr; front 0 (lanes 0..4, one row each) l = mid+1+j, nbr = l-1; front 1 (lanes
+// 8..12) l = mid-1-j, nbr = l+1.  (A one-lane-per-front sweep with the next link's Z prefetched was measured slower: 6.2 k
+// against 4.7 k cycles per Newton iteration at 17 links.)
+HD void ck_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
+    const int front = t >> 3, row = t & 7;
+    if (t >= 16 || row >= 5) return;
+    if (j >= (front ? P.nB : P.nA)) return;
+    const int l = front ? P.mid - 1 - j : P.mid + 1 + j;
+    const int nbr = front ? l + 1 : l - 1;
+    double z[5], dn[5];
+#pragma unroll
+    for (int cI = 0; cI < 5; cI++) { z[cI] = L[Y.SJJ + 25 * l + 5 * cI + row]; dn[cI] = L[Y.DL + 5 * nbr + cI]; }
+    const double y = L[Y.R + 5 * l + row];
+    L[Y.DL + 5 * l + row] = y - (z[0] * dn[0] + z[1] * dn[1] + z[2] * dn[2] + z[3] * dn[3] + z[4] * dn[4]);
 }
 
 // LDS image of the chain kernel.  Gathered across lanes by the block-tridiagonal elimination: the Schur blocks, the

@@ -70,6 +70,10 @@ struct CtrlDev {
     unsigned noise_key0;
     int has_pid, pid_on[CCLQR_MAXL];
     double pid_P[CCLQR_MAXL], pid_I[CCLQR_MAXL], pid_D[CCLQR_MAXL], pid_goal[CCLQR_MAXL];
+    // per-instance controller tables (n_ctrl > 1): instance with global index n reads K + n K_stride, zd + n zd_stride, Fd + n Fd_stride
+    // (strides in doubles; all 0 when one table is shared, the reference's case)
+    long long K_stride, zd_stride, Fd_stride;
+    int n_ctrl;
 };
 
 // ---- LDS layout of one instance (offsets in doubles) ----

@@ -27,11 +27,13 @@ struct RolloutArgs {
 
 int rollout_lanes_per_instance(int nb, int tree);
 size_t rollout_lds_bytes(int nb, int tree, int npairs);
-hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream);
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, hipStream_t stream);
+hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long long n_inst, int k0, int steps, hipStream_t stream);
 // forests of chains (rollout_chain.hip)
 int chain_lanes_per_instance(int nb);
+int chain_layout_links(int nb);
 size_t chain_lds_bytes(int nb);
-hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, hipStream_t stream);
+hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, hipStream_t stream);
 
 struct LinArgs {
     const MechDev* M;
@@ -76,4 +78,7 @@ struct cclqr_ctrl {
     cclqr::CtrlDev* dev;
     double *K_dev, *zd_dev, *Fd_dev;
     int nb;
+    // workspace of the counter-based noise of one launch (noise_philox), grown on demand and kept with the handle
+    double* noise_ws;
+    size_t noise_ws_cap;
 };

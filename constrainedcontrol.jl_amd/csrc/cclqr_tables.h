@@ -191,15 +191,21 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
         H.pid_on[l] = 1; H.has_pid = 1;
         H.pid_P[l] = d->pid_P[i]; H.pid_I[l] = d->pid_I[i]; H.pid_D[l] = d->pid_D[i]; H.pid_goal[l] = d->pid_goal[i];
     }
-    T.zd.resize((size_t)d->nsp * nb * 13);
-    for (int s = 0; s < d->nsp; s++)
-        for (int l = 0; l < nb; l++) memcpy(&T.zd[((size_t)s * nb + l) * 13], d->zd + ((size_t)s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
+    if (d->n_ctrl < 0) { err = "negative number of controller tables"; return CCLQR_EINVAL; }
+    const size_t nc = d->n_ctrl > 1 ? (size_t)d->n_ctrl : 1;      // controller tables: one shared, or one per instance
+    H.n_ctrl = (int)nc;
+    T.zd.resize(nc * d->nsp * nb * 13);
+    for (size_t s = 0; s < nc * d->nsp; s++)
+        for (int l = 0; l < nb; l++) memcpy(&T.zd[(s * nb + l) * 13], d->zd + (s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
     if (d->K) {
-        T.K.resize((size_t)d->nK * d->mu * mx);
-        for (size_t row = 0; row < (size_t)d->nK * d->mu; row++)
+        T.K.resize(nc * d->nK * d->mu * mx);
+        for (size_t row = 0; row < nc * d->nK * d->mu; row++)
             for (int l = 0; l < nb; l++) memcpy(&T.K[row * mx + 12 * l], d->K + row * mx + 12 * m->host.perm[l], 12 * sizeof(double));
     }
-    if (d->Fd && d->mu > 0) T.Fd.assign(d->Fd, d->Fd + (size_t)d->nsp * d->mu);
+    if (d->Fd && d->mu > 0) T.Fd.assign(d->Fd, d->Fd + nc * d->nsp * d->mu);
+    if (nc > 1) {
+        H.K_stride = (long long)d->nK * d->mu * mx; H.zd_stride = (long long)d->nsp * nb * 13; H.Fd_stride = (long long)d->nsp * d->mu;
+    }
     return CCLQR_OK;
 }
 

@@ -54,16 +54,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         const bool gate = (C->N <= 0) || (k < C->N);
         const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
         const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
-        if (gate && valid) ph_control_error(t, nb, Y, L, r, C, C->zd + (size_t)ksp * nz);
+        const long long ginst = a.inst0 + inst;     // global instance index: selects the controller table when there is one per instance
+        if (gate && valid) ph_control_error(t, nb, Y, L, r, C, C->zd + ginst * C->zd_stride + (size_t)ksp * nz);
         else if (t < nb) L[Y.UJ + t] = 0.0;
         __syncthreads();
         if (gate) {
             for (int i = 0; i < C->mu; i++) {
                 double part = 0.0;
-                if (C->K && valid) part = ph_gain_partial(t, G, nb, Y, L, C->K + ((size_t)kidx * C->mu + i) * 12 * nb);
+                if (C->K && valid) part = ph_gain_partial(t, G, nb, Y, L, C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb);
                 double s = group_sum<G>(part);
                 if (t == 0 && valid) {
-                    double u = (C->Fd ? C->Fd[(size_t)ksp * C->mu + i] : 0.0) - s;
+                    double u = (C->Fd ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
                     if (C->noise_scale != 0.0) {
                         if (a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
                         else if (C->noise_philox) u += C->noise_scale * philox_normal(C->noise_key0, (unsigned long long)(a.inst0 + inst), k);
@@ -140,8 +141,8 @@ static hipError_t launch_one(const RolloutArgs& a, unsigned grid, size_t lds, hi
     return hipGetLastError();
 }
 
-hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, hipStream_t stream) {
-    if (!tree) return launch_rollout_chain(a, nb, stream);   // forests of chains: the register-resident kernel (rollout_chain.hip)
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, hipStream_t stream) {
+    if (!tree) return launch_rollout_chain(a, nb, extra, stream);   // forests of chains: the register-resident kernel (rollout_chain.hip)
     const int G = rollout_lanes_per_instance(nb, tree);
     const int per_wg = 64 / G;
     const size_t lds = rollout_lds_bytes(nb, tree, npairs);

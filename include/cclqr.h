@@ -70,6 +70,11 @@ typedef struct {
      * key = (noise_seed low 32 bits ^ high 32 bits, n)), times noise_scale. */
     int32_t noise_philox;
     uint64_t noise_seed;
+    /* Batched controllers ("Riccati run per instance on distinct setpoints"): n_ctrl > 1 gives every instance its
+     * own table -- K [n_ctrl][nK][mu][12*nb], zd [n_ctrl][nsp][nb][13], Fd [n_ctrl][nsp][mu] -- and instance n of a launch reads table
+     * first_instance + n (cclqr_rollout_opts), which must be < n_ctrl.  0 or 1: one table for all instances = the reference's one
+     * LQR object per simulate! call (lqr.jl:106-111). */
+    int32_t n_ctrl;
 } cclqr_ctrl_desc;
 
 typedef struct cclqr_mech cclqr_mech; /* opaque: device-resident mechanism tables */
@@ -125,13 +130,28 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
                       double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
                       int32_t *status_dev, void *stream);
 
-/* Global index of instance 0 of the following rollout launches of this thread (default 0).  Only matters for noise_philox: the
- * noise stream of an instance is keyed by its GLOBAL index, so rank r of a sharded batch sets its shard's first index here. */
-int cclqr_set_instance_offset(int64_t first_instance);
+/* Per-launch options of cclqr_rollout_ex (all zero = defaults).
+ *   first_instance  global index of instance 0 of this launch: the Philox noise stream (noise_philox) and the per-instance
+ *                   controller table (n_ctrl > 1) of an instance are keyed by its GLOBAL index, so rank r of a sharded batch
+ *                   passes its shard's first index and reproduces the unsharded batch;
+ *   pid_state_dev   DEVICE buffer [n_inst][nb][2] (integrated error, last error per joint, opaque order) that carries the PID
+ *                   integrators of pid.jl:10-11 between launches: read when k0 > 1, always written; only used by controllers with
+ *                   npid > 0.  NULL: they live for one launch;
+ *   pid_state_len   doubles in that buffer (checked against n_inst * nb * 2). */
+typedef struct {
+    int64_t first_instance;
+    double *pid_state_dev;
+    int64_t pid_state_len;
+} cclqr_rollout_opts;
 
-/* PID integrators across launches: a DEVICE buffer [n_inst][nb][2] (integrated error, last error per joint, opaque order) used by the
- * following cclqr_rollout_dev launches of this thread -- read when k0 > 1, always written.  NULL (default): the integrated / last
- * errors of pid.jl:10-11 live for one launch. */
+/* cclqr_rollout_dev with explicit options instead of the thread-local setters below (opts may be NULL). */
+int cclqr_rollout_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0_dev,
+                     double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
+                     int32_t *status_dev, const cclqr_rollout_opts *opts, void *stream);
+
+/* Deprecated (kept one round): thread-local defaults of the two options for cclqr_rollout_dev (and of first_instance for
+ * cclqr_rollout).  The PID buffer set here is only ever handed to a controller with npid > 0. */
+int cclqr_set_instance_offset(int64_t first_instance);
 int cclqr_set_pid_state(double *pid_state_dev);
 
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py) */

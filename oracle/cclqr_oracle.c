@@ -740,13 +740,16 @@ double orc_philox_normal(uint64_t seed, uint64_t instance, int k) {
 
 /* ------------------------------------------------------------------ feedback law */
 /* lqr.jl:89-139 / lqr_tracking.jl:46-71 / trackingLQR_triple_cartpole.jl:76-115 */
-static void control_core(const mech_t *M, const orc_ctrl_desc *c, const double *z, int k, double noise_sample, double *uj) {
+static void control_core(const mech_t *M, const orc_ctrl_desc *c, int64_t inst, const double *z, int k, double noise_sample, double *uj) {
     int nb = M->nb, mx = 12 * nb;
     for (int j = 0; j < M->ne; j++) uj[j] = 0.0;
     int inf = (c->N <= 0);
     if (!inf && !(k < c->N)) return; /* lqr.jl:106: at k >= N no force is written */
     int ksp = (c->nsp > 1) ? (k - 1 < c->nsp ? k - 1 : c->nsp - 1) : 0;
-    const double *zd = c->zd + (size_t)ksp * 13 * nb;
+    const size_t tab = c->n_ctrl > 1 ? (size_t)inst : 0; /* per-instance controller tables */
+    const double *zd = c->zd + (tab * c->nsp + (size_t)ksp) * 13 * nb;
+    const double *Ktab = c->K ? c->K + tab * (size_t)c->nK * c->mu * mx : NULL;
+    const double *Fdtab = c->Fd ? c->Fd + tab * (size_t)c->nsp * c->mu : NULL;
     double dz[12 * MAXB];
     for (int b = 0; b < nb; b++) {
         const double *zb = z + 13 * b, *zdb = zd + 13 * b;
@@ -783,9 +786,9 @@ static void control_core(const mech_t *M, const orc_ctrl_desc *c, const double *
     }
     int kk = inf ? 0 : (k - 1 < c->nK ? k - 1 : c->nK - 1);
     for (int i = 0; i < c->mu; i++) {
-        double u = c->Fd ? c->Fd[(size_t)ksp * c->mu + i] : 0.0;
-        if (c->K) {
-            const double *Kr = c->K + ((size_t)kk * c->mu + i) * mx;
+        double u = Fdtab ? Fdtab[(size_t)ksp * c->mu + i] : 0.0;
+        if (Ktab) {
+            const double *Kr = Ktab + ((size_t)kk * c->mu + i) * mx;
             double s = 0;
             for (int t = 0; t < mx; t++) s += Kr[t] * dz[t];
             u -= s;
@@ -799,7 +802,7 @@ static void control_core(const mech_t *M, const orc_ctrl_desc *c, const double *
 void orc_control(const orc_mech_desc *d, const orc_ctrl_desc *c, const double *z, int k, double noise_sample, double *uj) {
     mech_t M;
     if (mech_build(d, &M)) return;
-    control_core(&M, c, z, k, noise_sample, uj);
+    control_core(&M, c, 0, z, k, noise_sample, uj);
 }
 
 int orc_rollout(const orc_mech_desc *d, const orc_ctrl_desc *c, int64_t n_inst, int32_t steps, const double *z0, double *traj,
@@ -829,7 +832,7 @@ int orc_rollout(const orc_mech_desc *d, const orc_ctrl_desc *c, int64_t n_inst, 
                     if (c->noise) ns = c->noise[(size_t)n * steps + (k - 1)];
                     else if (c->noise_philox) ns = orc_philox_normal(c->noise_seed, (uint64_t)n, k);
                 }
-                control_core(&M, c, z, k, ns, uj);
+                control_core(&M, c, n, z, k, ns, uj);
                 if (c->npid > 0) pid_core(&M, c, z, k, pid_integ, pid_last, uj);
                 int it = step_core(&M, z, lam, uj, W, 0);
                 if (it < 0) { bad = 1; it = -it; }

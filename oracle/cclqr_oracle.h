@@ -68,6 +68,7 @@ typedef struct {
     const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid] */
     int32_t noise_philox;      /* != 0 and noise == NULL: Philox-4x32-10 + Box-Muller stream per instance */
     uint64_t noise_seed;
+    int32_t n_ctrl;            /* > 1: instance n uses table n of K [n_ctrl][nK][mu][12 nb], zd [n_ctrl][nsp][nb][13], Fd [n_ctrl][nsp][mu] */
     /* (fields above = cclqr_ctrl_desc; the injected noise array is oracle-only and therefore last) */
     const double *noise;       /* [n_inst][steps] injected standard-normal samples or NULL */
 } orc_ctrl_desc;

@@ -25,7 +25,7 @@ class CtrlDesc(C.Structure):
     _fields_ = [("mu", C.c_int32), ("ctrl_joint", _ip), ("nK", C.c_int32), ("N", C.c_int32), ("K", _dp),
                 ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
                 ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp),
-                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64), ("noise", _dp)]
+                ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64), ("n_ctrl", C.c_int32), ("noise", _dp)]
 
 
 def build(force=False):
@@ -87,22 +87,24 @@ def mech_desc(t):
     return _Keep(d, arrs)
 
 
-def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None, pid=None, noise_seed=None):
-    """pid = dict(joint=[...], P=[...], I=[...], D=[...], goal=[...]) adds a PID law (pid.jl) on those joints"""
+def ctrl_desc(nb, ctrl_joint, K=None, N=0, zd=None, Fd=None, fric=None, noise_scale=0.0, noise=None, pid=None, noise_seed=None, n_ctrl=0):
+    """pid = dict(joint=[...], P=[...], I=[...], D=[...], goal=[...]) adds a PID law (pid.jl) on those joints;
+    n_ctrl > 1: K [n_ctrl][nK][mu][12 nb], zd [n_ctrl][nsp][nb][13], Fd [n_ctrl][nsp][mu], one table per instance"""
     cj = _i32(ctrl_joint)
     mu = len(cj)
     K = _f64(K)
+    nc = n_ctrl if n_ctrl > 1 else 1
     zd = _f64(zd if zd is not None else _identity_state(nb)).reshape(-1, nb, 13)
     Fd = _f64(Fd if Fd is not None else np.zeros((zd.shape[0], mu))).reshape(zd.shape[0], mu)
-    nK = 0 if K is None else K.reshape(-1, mu, 12 * nb).shape[0]
+    nK = 0 if K is None else K.reshape(-1, mu, 12 * nb).shape[0] // nc
     arrs = dict(cj=cj, K=K, zd=zd, Fd=Fd, fric=_f64(fric), noise=_f64(noise))
     npid = 0
     if pid is not None:
         arrs.update(pj=_i32(pid["joint"]), pP=_f64(pid["P"]), pI=_f64(pid["I"]), pD=_f64(pid["D"]), pg=_f64(pid["goal"]))
         npid = len(arrs["pj"])
-    d = CtrlDesc(mu, _i(cj), nK, int(N), _d(K), zd.shape[0], _d(zd), _d(Fd), _d(arrs["fric"]), float(noise_scale),
+    d = CtrlDesc(mu, _i(cj), nK, int(N), _d(K), zd.shape[0] // nc, _d(zd), _d(Fd), _d(arrs["fric"]), float(noise_scale),
                  npid, _i(arrs.get("pj")), _d(arrs.get("pP")), _d(arrs.get("pI")), _d(arrs.get("pD")), _d(arrs.get("pg")),
-                 0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed), _d(arrs["noise"]))
+                 0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed), int(n_ctrl), _d(arrs["noise"]))
     return _Keep(d, arrs)
 
 

@@ -90,7 +90,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
     I.G = G_override > 0 ? G_override : (nb <= 8 ? 16 : 32);
     if (I.G < nb) return CCLQR_EINVAL;
     I.nb = nb; I.dt = dt;
-    I.Y = make_chain_layout(nb);
+    I.Y = make_chain_layout(nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : 32)));     // = chain_layout_links(nb) of rollout_chain.hip
     I.lds.resize(I.Y.total);          // exact size: an out-of-range offset is an out-of-bounds access for the sanitizer
     I.L = I.lds.data();
     I.c.resize(I.G); I.S.resize(I.G); I.T.resize(I.G);
@@ -183,15 +183,17 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
             for (int iter = 1; iter <= 100 && !done; iter++) {
                 for (int ci = 0; ci < M->nchains; ci++) {
                     const TriPlan P = tri_plan(M->chain_start[ci], M->chain_len[ci]);
+                    std::vector<TriCur> K(G);
+                    for (int t = 0; t < G; t++) K[t] = tri_cursor(t, P, Y);
                     for (int i = 0; i < P.steps; i++) {
-                        double zy[64][5];
-                        int l[64];
+                        double tg[64][5], zy[64][5];
+                        int otg[64], oout[64];
                         bool act[64];
-                        for (int t = 0; t < G; t++) act[t] = ph_tri_elim(t, i, P, Y, L, zy[t], &l[t]);
-                        for (int t = 0; t < G; t++) if (act[t]) ph_tri_store(t, l[t], Y, L, zy[t]);
+                        for (int t = 0; t < G; t++) act[t] = tri_step(K[t], i, L, tg[t], zy[t], &otg[t], &oout[t]);     // every lane's loads come before any lane's stores
+                        for (int t = 0; t < G; t++) if (act[t]) tri_step_store(L, otg[t], oout[t], tg[t], zy[t]);
                     }
-                    for (int t = 0; t < G; t++) ph_tri_mid(t, P, Y, L);
-                    for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ph_tri_back(t, j, P, Y, L);
+                    for (int t = 0; t < G; t++) ck_tri_mid(t, P, Y, L);
+                    for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ck_tri_back(t, j, P, Y, L);
                 }
                 double pdn = 0.0;
                 {

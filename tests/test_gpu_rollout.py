@@ -147,10 +147,27 @@ def test_pid_state_carried_across_launches(cclqr, orc):
     capi.rollout_dev(mech, ctrl, n, 100, 1, z0_d.data_ptr(), 0, 0, 0, 0, one.data_ptr(), st.data_ptr())
     lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
     pstate = torch.zeros((n, t.nb, 2), dtype=torch.float64, device=dev)
+    # explicit options (cclqr_rollout_ex): the buffer is an argument of the launch, its length is checked
+    capi.rollout_dev(mech, ctrl, n, 30, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr(), pid_state=pstate.data_ptr())
+    capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr(), pid_state=pstate.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(b, one)
+    # deprecated thread-local setter: same result
+    lam.zero_(); pstate.zero_()
     try:
         capi.set_pid_state(pstate.data_ptr())
         capi.rollout_dev(mech, ctrl, n, 30, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr())
         capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr())
+        # a controller without a PID law launched while the buffer is still set must not touch it
+        ex2 = cclqr.examples.cartpole_n(1)
+        t2 = ex2["mech"].tables()
+        m2 = capi.MechHandle(t2)
+        c2 = capi.CtrlHandle(m2, [0], K=np.zeros((5, 1, 24)), N=6, zd=None)
+        zc = torch.from_numpy(cclqr.examples.cartpole_states(1, np.linspace(-0.3, 0.3, 40), np.full((40, 1), 0.1))).to(dev)
+        keep = pstate.clone()
+        capi.rollout_dev(m2, c2, 40, 3, 1, zc.data_ptr(), 0, 0, 0, 0, torch.empty_like(zc).data_ptr(), torch.zeros(40, dtype=torch.int32, device=dev).data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(keep, pstate)
     finally:
         capi.set_pid_state(0)
     torch.cuda.synchronize()
@@ -216,3 +233,41 @@ def test_step_per_launch_chain_captured_in_a_hip_graph(cclqr, orc):
     assert torch.equal(src, ref)
     zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=N, zd=zd, fric=ex["fric"]), z0[:16], 20)
     assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
+
+
+def test_per_instance_controller_tables(cclqr, orc):
+    """SURVEY 8d cfg4 / VERDICT r1 item 7: a batch in which every instance has its OWN gains, setpoint and feed-forward
+    (cclqr_ctrl_desc.n_ctrl), chain kernel (triple cartpole) and tree kernel (dual-pole cart); a shard launched with
+    first_instance reads its slice of the tables"""
+    capi = cclqr._capi
+    rng = np.random.default_rng(21)
+    for ex in (cclqr.examples.triple_cartpole(), cclqr.examples.dual_cartpole()):
+        if ex is None:
+            continue
+        t = ex["mech"].tables()
+        n, N = 24, 30
+        z00 = ex["mech"].state()
+        zd = np.tile(z00, (n, 1, 1, 1))                      # [n][nsp = 1][nb][13]
+        zd[:, 0, 0, 1] += rng.uniform(-0.2, 0.2, n)          # every instance regulates the cart to its own position
+        K = rng.normal(size=(n, N - 1, 1, 12 * t.nb)) * 0.3
+        Fd = rng.normal(size=(n, 1, 1)) * 0.5
+        z0 = np.tile(z00, (n, 1, 1))
+        mech = capi.MechHandle(t)
+        ctrl = capi.CtrlHandle(mech, [0], K=K, N=N, zd=zd, Fd=Fd, n_ctrl=n)
+        zT, traj, st = capi.rollout(mech, ctrl, z0, N, record=True)
+        oc = orc.ctrl_desc(t.nb, [0], K=K, N=N, zd=zd, Fd=Fd, n_ctrl=n)
+        zo, trajo, sto = orc.rollout(t, oc, z0, N, record=True)
+        assert (st > 0).all() and (sto > 0).all()
+        assert np.abs(traj - trajo).max() < TOL
+        assert np.abs(traj[0] - traj[1]).max() > 1e-3      # the tables really differ
+        # shard [8, 20): first_instance selects the tables
+        import torch
+        dev = torch.device("cuda", 0)
+        zs = torch.from_numpy(z0[8:20]).to(dev)
+        out = torch.empty_like(zs)
+        sts = torch.zeros(12, dtype=torch.int32, device=dev)
+        capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=8)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), zT[8:20])
+        with pytest.raises(capi.CclqrError):
+            capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=20)
