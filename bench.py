@@ -12,12 +12,16 @@ Workload (config.workload): the mechanism of examples/lqr_cartpole_n_pendulum.jl
 regulated about its HANGING equilibrium: about the upright one the reference's own recursion yields |K| ~ 1e11 and every
 fp64 rollout diverges (DESIGN.md "Workloads"), so upright chains are parity-tested up to N = 8 only.
 
-Multi-GPU: one process per GPU (torchrun), instances sharded with no data-path collective, final states gathered to
-rank 0 over RCCL inside the timed region ("scaling": "weak").
+Multi-GPU: one process per GPU (torchrun), instances sharded with no data-path collective.  Inside the timed region the
+recorded trajectories of all ranks are collected on rank 0 in time chunks (--chunks launches per rollout through the k0
+continuation of cclqr_rollout_dev; chunk c travels over RCCL on a second stream while chunk c+1 is computed) and the final
+states with one more gather ("scaling": "weak").  RCCL is mandatory for --gpus > 1: gloo has to be asked for (--allow-gloo).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +38,34 @@ FP64_PEAK_TFLOPS = 78.6    # vector fp64 = matrix fp64 on MI355X (256 CU x 4 SIM
 def b_step(nb, ml, mu, record):
     """algorithmic bytes per instance-step, step-per-launch form"""
     return 2 * (104 * nb + 8 * ml) + (104 * nb if record else 0) + 8 * mu
+
+
+def kernel_source_sha():
+    """fingerprint of the rollout kernel's sources: PMC-measured numbers in profiles/ are only quoted for the sources they were measured on"""
+    h = hashlib.sha256()
+    for f in ("rollout_chain.hip", "cclqr_chain.h", "cclqr_dev.h", "cclqr_newton.h", "cclqr_internal.h"):
+        h.update(open(os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_cpu_allowance():
+    """cores this process may use: the scheduler affinity mask, cut down by the cgroup CPU quota when there is one"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota)))
+    return cores, aff, quota
 
 
 def build_workload(pkg, n_links, n_inst, seed, rank):
@@ -58,6 +90,9 @@ def main():
     ap.add_argument("--no-record", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="launches per rollout (trajectory collected chunk by chunk); 0 = 1 on one GPU, 8 on several")
+    ap.add_argument("--allow-gloo", action="store_true", help="accept the gloo backend for --gpus > 1 (never a scaling measurement)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collective runs over gloo "
                          "(RCCL refuses two ranks on one device); the JSON line is marked and is not a scaling measurement")
@@ -67,9 +102,11 @@ def main():
     import torch.distributed as dist
     pkg = graft.load_package()
     capi = pkg._capi
-    rank, world, local = pkg.dist.init_from_env(backend="gloo" if args.rehearse_shared_gpu else None)
+    rank, world, local = pkg.dist.init_from_env(backend="gloo" if (args.rehearse_shared_gpu or args.allow_gloo) else None)
     if world != args.gpus and world > 1:
         args.gpus = world
+    if world > 1 and not (args.rehearse_shared_gpu or args.allow_gloo):
+        assert dist.get_backend() == "nccl", "multi-GPU runs collect over RCCL; pass --allow-gloo to run anything else"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP only (no CPU fallback)")
     if args.rehearse_shared_gpu:
@@ -93,43 +130,64 @@ def main():
     ctrl = lqr._ctrl_handle(mh)
     lanes, lds_bytes = mh.geometry()
 
+    chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 8)
+    assert T % chunks == 0, "--sim-steps must be a multiple of --chunks"
+    Tc = T // chunks
     z0_d = torch.from_numpy(z0).to(dev)
     zT_d = torch.empty_like(z0_d)
-    st_d = torch.zeros(n_inst, dtype=torch.int32, device=dev)
-    traj_d = torch.empty((n_inst, T, nb, 13), dtype=torch.float64, device=dev) if record else None
+    st_d = torch.zeros((chunks, n_inst), dtype=torch.int32, device=dev)
+    lam_d = torch.zeros((n_inst, ml), dtype=torch.float64, device=dev) if chunks > 1 else None
+    collect = world > 1 or chunks > 1          # trajectories leave the rank (or are re-assembled) chunk by chunk
+    tg = pkg.dist.TrajectoryGather(rank, world, n_inst, T, nb, chunks, dev) if (record and collect) else None
+    traj_d = torch.empty((n_inst, T, nb, 13), dtype=torch.float64, device=dev) if (record and not collect) else None
     stream = torch.cuda.current_stream().cuda_stream
+    kern_ev = []
 
-    def one_step():
-        capi.rollout_dev(mh, ctrl, n_inst, T, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(),
-                         st_d.data_ptr(), stream)
+    def one_rollout(timed):
+        """one bench step: the whole horizon for this rank's instances (+ the collection on rank 0 when there is one)"""
+        for c in range(chunks):
+            if tg is not None:
+                tg.wait_slab_free(c)
+                traj_ptr = tg.slab(c).data_ptr()
+            else:
+                traj_ptr = traj_d.data_ptr() if record else 0
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            capi.rollout_dev(mh, ctrl, n_inst, Tc, c * Tc + 1, (z0_d if c == 0 else zT_d).data_ptr(), lam_d.data_ptr() if lam_d is not None else 0,
+                             0, 0, traj_ptr, zT_d.data_ptr(), st_d[c].data_ptr(), stream)
+            if timed:
+                e1.record()
+                kern_ev.append((e0, e1))
+            if tg is not None:
+                tg.submit(c)
+        if tg is not None:
+            tg.finish()
         if world > 1:
             return pkg.dist.gather_to_root(zT_d, n_inst * world, rank, world)   # RCCL fan-in of the final states
         return zT_d
 
-    if world > 1:   # open the RCCL peer connections the gather uses, whatever --warmup says (communicator set-up is not a step)
+    if world > 1:   # open the RCCL peer connections the gathers use, whatever --warmup says (communicator set-up is not a step)
         pkg.dist.gather_to_root(torch.zeros((1, 1), dtype=torch.float64, device=dev), world, rank, world)
     for _ in range(args.warmup):
-        one_step()
+        one_rollout(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        capi.rollout_dev(mh, ctrl, n_inst, T, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(),
-                         st_d.data_ptr(), stream)
-        ev[i][1].record()
-        if world > 1:
-            pkg.dist.gather_to_root(zT_d, n_inst * world, rank, world)
+        one_rollout(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = pkg.dist.max_over_ranks(elapsed, dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    kern_ms_launch = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) if kern_ev else float("nan")   # average launch
+    kern_ms = kern_ms_launch * chunks                                                                      # kernel time of one rollout
     status = st_d.cpu().numpy()
-    n_bad = int((status <= 0).sum())
+    n_bad = int((status <= 0).any(axis=0).sum())
+    status = np.abs(status).max(axis=0)
+    gathered = tg.bytes_gathered / max(1, args.steps + args.warmup) if tg is not None else 0
 
     backend_name = dist.get_backend() if world > 1 else None
     if world > 1:
@@ -140,15 +198,16 @@ def main():
     total_units = float(n_inst) * world * T * args.steps
     value = total_units / elapsed
     bs = b_step(nb, ml, mu, record)
-    alg_bytes_per_launch = bs * float(n_inst) * T
-    achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    alg_bytes_per_launch = bs * float(n_inst) * Tc            # one launch = Tc steps of every instance of this rank
+    achieved = alg_bytes_per_launch / (kern_ms_launch * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            if tj.get("config") == {"links": n_links, "instances_per_gpu": n_inst, "sim_steps": T, "record": record}:
-                traffic = tj.get("hbm_bytes_per_launch")      # PMC-measured for exactly this launch shape (profiles/README.md)
+            same_shape = tj.get("config") == {"links": n_links, "instances_per_gpu": n_inst, "sim_steps": Tc, "record": record}
+            if same_shape and tj.get("kernel_source_sha") == kernel_source_sha():
+                traffic = tj.get("hbm_bytes_per_launch")      # PMC-measured for exactly this launch shape AND these kernel sources
         except Exception:
             traffic = None
     out = {
@@ -159,10 +218,13 @@ def main():
         "config": {"workload": "lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, "
                                "y0~U(-0.5,0.5) phi_i~U(-0.2,0.2)" % (n_links, nb, T * t.dt),
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,
-                   "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes},
+                   "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes, "launches_per_rollout": chunks},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "rollout_kernel<%d, false>" % lanes, "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_instance_step": bs},
+                     "traffic": traffic, "kernel": "rollout_chain_kernel<%d, %d, 0>" % (lanes, capi.chain_layout_links(nb)),
+                     "kernel_ms": kern_ms_launch, "launches_per_rollout": chunks, "algorithmic_bytes_per_instance_step": bs,
+                     "kernel_source_sha": kernel_source_sha()},
+        "collection": {"trajectory_bytes_gathered_to_rank0_per_rollout": gathered, "chunks": chunks,
+                       "exposed_ms_per_rollout": 1e3 * elapsed / max(1, args.steps) - kern_ms},
         "newton": {"max_iters_mean": float(status.mean()), "max_iters_max": int(status.max()), "failed_instances": n_bad},
         "setup": {"lqr_construct_s": setup_s, "riccati_kbreak": int(lqr.kbreak)},
     }
@@ -210,22 +272,41 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T):
                               "gflops_lower_bound": f_ric * nsteps / setup_s / 1e9, "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}}
 
 
+def build_native_oracle():
+    """the CPU baseline build of the oracle: -O3 -march=native, compiled HERE (on the box that runs the bench: a -march=native
+    object built elsewhere may not run), next to the portable -O2 checker build that the tests use"""
+    src = os.path.join(ROOT, "oracle", "cclqr_oracle.c")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liborc_native.so")
+    flags = ["-O3", "-march=native", "-fPIC", "-fopenmp", "-std=gnu11", "-ffp-contract=off"]
+    subprocess.check_call(["gcc"] + flags + ["-shared", "-o", so, src, "-lm"])
+    return so, " ".join(flags)
+
+
 def cpu_baseline_and_flops(pkg, t, lqr, z0, T, gpu_value, kern_ms, n_inst):
-    """oracle (CPU restatement, NOT ConstrainedControl.jl itself) on a bounded sample of the same workload, all host cores"""
+    """oracle (CPU restatement, NOT ConstrainedControl.jl itself) on a bounded sample of the same workload on the host cores this
+    process is allowed to use; reports the single-thread rate and the parallel efficiency next to the all-core rate"""
     from oracle import orc
-    cores = os.cpu_count() or 1
+    cores, affinity, quota = host_cpu_allowance()
+    flags = "-O2 (oracle/Makefile)"
+    try:
+        so, flags = build_native_oracle()
+        orc.use_library(so)
+    except Exception as e:      # no compiler on the box: the portable build is the baseline
+        sys.stderr.write("bench: native oracle build failed (%s); using oracle/liborc.so\n" % (e,))
     octrl = orc.ctrl_desc(t.nb, lqr.ctrl_joints, K=lqr.K, N=lqr.N, zd=lqr.zd)
-    # calibrate: one instance, 50 steps
-    t0 = time.time()
-    orc.rollout(t, octrl, z0[:1], 50, nthreads=1)
-    per = (time.time() - t0) / 50.0
     sample_steps = min(T, 200)
-    n_s = max(cores, min(len(z0), int(15.0 * cores / max(per * sample_steps, 1e-9))))
+    # single thread: 2 instances x sample_steps
+    t0 = time.time()
+    orc.rollout(t, octrl, z0[:2], sample_steps, nthreads=1)
+    v_one = 2 * sample_steps / (time.time() - t0)
+    n_s = max(cores, min(len(z0), int(15.0 * cores * v_one / sample_steps)))      # ~15 s of work on all cores
     n_s = (n_s // cores) * cores
     t0 = time.time()
     orc.rollout(t, octrl, z0[:n_s], sample_steps, nthreads=cores)
-    dt_all = time.time() - t0
-    v_all = n_s * sample_steps / dt_all
+    v_all = n_s * sample_steps / (time.time() - t0)
+    orc.use_library(None)
     # counted flops per instance-step (instrumented build), same inputs
     orc.flops_reset()
     orc.rollout(t, octrl, z0[:4], sample_steps, nthreads=1, flops=True)
@@ -233,8 +314,9 @@ def cpu_baseline_and_flops(pkg, t, lqr, z0, T, gpu_value, kern_ms, n_inst):
     tf = f_step * gpu_value / 1e12
     return {
         "cpu_baseline": {"value": v_all, "unit": "instance-steps/s", "cores": cores, "kind": "port",
-                         "sample": "%d instances x %d steps of the same workload, oracle/liborc.so (gcc -O2, OpenMP over instances); "
-                                   "single-thread rate %.0f" % (n_s, sample_steps, 1.0 / per)},
+                         "single_thread_value": v_one, "parallel_efficiency": v_all / (cores * v_one),
+                         "affinity_cores": affinity, "cgroup_cpu_quota": quota, "build_flags": flags,
+                         "sample": "%d instances x %d steps of the same workload, the oracle (OpenMP over instances, %d threads)" % (n_s, sample_steps, cores)},
         "roofline_fp64_valu": {"bound": "fp64 vector ALU (the binding unit; SURVEY 8d)", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "flops_per_instance_step_counted_by_oracle": f_step},
     }

@@ -106,6 +106,11 @@ def device_count():
     return n.value
 
 
+def chain_layout_links(nb):
+    """links the chain kernel's LDS image is laid out for (= csrc/rollout_chain.hip chain_layout_links): names the instantiation"""
+    return 8 if nb <= 8 else (16 if nb <= 16 else (17 if nb == 17 else 32))
+
+
 def set_device(dev):
     check(lib().cclqr_set_device(C.c_int32(dev)))
 

@@ -1,8 +1,8 @@
 """Instance sharding across the GPUs of one node: instances never interact, so every rank rolls out a
-contiguous block with no data-path collective; the only exchange is the gather of results to rank 0 (RCCL over xGMI on
-GPUs, gloo on CPU for tests).  One process per GPU, torch.distributed for the plumbing."""
+contiguous block with no data-path collective; the only exchange is the collection of results on rank 0 -- final states,
+and the recorded trajectories (`Storage`, lqr_tracking.jl:32-35) in time chunks that travel while the next chunk is being
+computed.  RCCL over xGMI on GPUs, gloo on CPU for tests.  One process per GPU, torch.distributed for the plumbing."""
 import os
-import sys
 
 import numpy as np
 
@@ -20,7 +20,11 @@ def shard(array, rank, world):
 
 
 def init_from_env(backend=None):
-    """torch.distributed init from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun); returns (rank, world, local_rank)"""
+    """torch.distributed init from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun); returns (rank, world, local_rank).
+
+    backend None = "nccl" (RCCL) when a GPU is visible, else "gloo".  There is NO fallback: if RCCL cannot be initialised the
+    error propagates and the job ends non-zero on every rank -- a multi-GPU line can never silently be a gloo run.  gloo on a GPU
+    box has to be asked for by name (bench.py --allow-gloo / --rehearse-shared-gpu)."""
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,17 +36,10 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-            try:
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-                probe = torch.zeros(1, device=torch.device("cuda", local))
-                dist.all_reduce(probe)           # RCCL creates its communicator lazily: fail here, not inside the timed region
-                torch.cuda.synchronize()
-            except Exception as e:               # the instances do not need the collective; the final-state gather can run on host buffers
-                sys.stderr.write("cclqr.dist: RCCL unavailable (%s); gathering through gloo on host buffers\n" % (e,))
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+            probe = torch.zeros(1, device=torch.device("cuda", local))
+            dist.all_reduce(probe)           # RCCL creates its communicator lazily: fail here, not inside the timed region
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -71,6 +68,85 @@ def gather_to_root(local, n_total, rank, world, dst=0):
     if rank != dst:
         return None
     return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0).to(dev)
+
+
+class TrajectoryGather:
+    """Collection of the recorded trajectories of all ranks on rank 0, in time chunks, overlapped with compute.
+
+    Every rank rolls its `n_local` instances out in `chunks` launches of `T / chunks` steps (the k0 continuation of
+    cclqr_rollout_dev) into one of two chunk slabs [n_local][Tc][nb][13].  After the launch of chunk c has been enqueued,
+    `submit(c, slab)` enqueues -- on a second stream that waits for that launch only -- ONE rooted gather of the slab (RCCL:
+    a grouped send/recv fan-in, so each of the N-1 peers uses its own xGMI link into the root) and, on rank 0, the copies of
+    the N received slabs into the final Storage layout out[n_total][T][nb][13].  The compute stream goes on with chunk c+1 and
+    only waits (`wait_slab_free`) before it overwrites a slab that is still being sent.
+
+    Cost model: per GPU 104 nb bytes per instance-step leave over one link at <= 153 GB/s; at the measured
+    24 M instance-steps/s and nb = 17 that is 42 GB/s per GPU = 27 % of a link, so the transfer hides behind compute except
+    for the last chunk: exposed time ~ (bytes of one chunk) / link rate + the root's copies."""
+
+    def __init__(self, rank, world, n_local, T, nb, chunks, device, dtype=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        assert T % chunks == 0, "sim steps must be a multiple of the number of trajectory chunks"
+        self.rank, self.world, self.n, self.T, self.nb, self.H, self.Tc = rank, world, n_local, T, nb, chunks, T // chunks
+        self.device = device
+        dtype = dtype or torch.float64
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.gloo_on_gpu = self.cuda and world > 1 and dist.get_backend() == "gloo"
+        self.slabs = [torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=device) for _ in range(2)]
+        self.out = torch.empty((n_local * world, T, nb, 13), dtype=dtype, device=device) if rank == 0 else None
+        self.recv = None
+        if rank == 0 and world > 1:
+            rdev = "cpu" if self.gloo_on_gpu else device
+            self.recv = [[torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=rdev) for _ in range(world)] for _ in range(2)]
+        self.comm = torch.cuda.Stream(device=device) if self.cuda else None
+        self.free_ev = [None, None]
+        self.bytes_gathered = 0
+
+    def slab(self, c):
+        return self.slabs[c % 2]
+
+    def wait_slab_free(self, c):
+        """the compute stream waits until the gather that last used chunk c's slab has finished"""
+        ev = self.free_ev[c % 2]
+        if ev is not None and self.cuda:
+            self.torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def submit(self, c):
+        """enqueue the collection of chunk c (its rollout launch is already enqueued on the current stream)"""
+        torch, dist = self.torch, self.dist
+        slab = self.slabs[c % 2]
+        t0, t1 = c * self.Tc, (c + 1) * self.Tc
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.comm.wait_event(done)
+            ctx = torch.cuda.stream(self.comm)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.world == 1:
+                self.out[:, t0:t1].copy_(slab)
+            else:
+                send = slab.cpu() if self.gloo_on_gpu else slab
+                bufs = self.recv[c % 2] if self.rank == 0 else None
+                dist.gather(send, bufs, dst=0)
+                self.bytes_gathered += slab.numel() * slab.element_size() * (self.world - 1) if self.rank == 0 else 0
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.out[r * self.n:(r + 1) * self.n, t0:t1].copy_(bufs[r], non_blocking=True)
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+                self.free_ev[c % 2] = ev
+
+    def finish(self):
+        """the current stream waits for every outstanding collection; returns out [n_total][T][nb][13] on rank 0 (None elsewhere)"""
+        if self.cuda:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.comm)
+        return self.out
 
 
 def max_over_ranks(value, device=None):

@@ -40,11 +40,23 @@ def build(force=False):
 _libs = {}
 
 
+def use_library(path):
+    """time another build of the SAME source as the plain library (bench.py's -O3 -march=native baseline build); None restores
+    oracle/liborc.so.  The checker used by the tests is always the portable build."""
+    _libs.pop("plain", None)
+    _libs["_override"] = path
+    if path is None:
+        _libs.pop("_override", None)
+
+
 def lib(flops=False):
     key = "flops" if flops else "plain"
     if key not in _libs:
         build()
-        L = C.CDLL(os.path.join(_HERE, "liborc_flops.so" if flops else "liborc.so"))
+        so = os.path.join(_HERE, "liborc_flops.so" if flops else "liborc.so")
+        if not flops and _libs.get("_override"):
+            so = _libs["_override"]
+        L = C.CDLL(so)
         L.orc_step.restype = C.c_int
         L.orc_rollout.restype = C.c_int
         L.orc_linearize.restype = C.c_int

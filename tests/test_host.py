@@ -97,17 +97,39 @@ n_total = 11
 z0 = np.arange(n_total * 2 * 13, dtype=np.float64).reshape(n_total, 2, 13)
 out = pkg.dist.sharded_rollout_numpy(lambda blk: blk * 2.0 + rank * 0.0, z0, rank, world)
 t = pkg.dist.max_over_ranks(1.0 + rank)
+# chunked trajectory collection (dist.TrajectoryGather): 4 chunks of 6 steps, slabs reused (2 buffers), final Storage layout on rank 0
+n_local, T, nb, H = 5, 24, 3, 4
+full = (np.arange(n_local * T * nb * 13, dtype=np.float64).reshape(n_local, T, nb, 13) + 1e6 * rank)
+tg = pkg.dist.TrajectoryGather(rank, world, n_local, T, nb, H, "cpu")
+for c in range(H):
+    tg.wait_slab_free(c)
+    tg.slab(c).copy_(torch.from_numpy(full[:, c * (T // H):(c + 1) * (T // H)]))     # stands for the chunk's rollout launch
+    tg.submit(c)
+traj = tg.finish()
 if rank == 0:
     assert out.shape == z0.shape and np.array_equal(out, z0 * 2.0), "gather mismatch"
     assert t == float(world)
+    want = np.concatenate([np.arange(n_local * T * nb * 13, dtype=np.float64).reshape(n_local, T, nb, 13) + 1e6 * r for r in range(world)])
+    assert traj.shape == (n_local * world, T, nb, 13) and np.array_equal(traj.numpy(), want), "chunked trajectory gather mismatch"
+    assert tg.bytes_gathered == n_local * T * nb * 13 * 8 * (world - 1)
     print("GLOO_OK")
 else:
-    assert out is None
+    assert out is None and traj is None
 '''
 
 
+def test_no_silent_gloo_fallback():
+    """dist.init_from_env never replaces RCCL by gloo on its own (ADVICE r1): the only way to gloo is to ask for it by name"""
+    src = open(os.path.join(ROOT, "constrainedcontrol.jl_amd", "dist.py")).read()
+    body = src[src.index("def init_from_env"):src.index("def gather_to_root")]
+    assert "except" not in body and body.count("init_process_group") == 2
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'dist.get_backend() == "nccl"' in bench and "--allow-gloo" in bench
+
+
 def test_gloo_world2_shard_and_gather(tmp_path):
-    """the N>1 path of bench.py (shard instances, gather final states to rank 0) with 2 CPU ranks"""
+    """the N>1 path of bench.py with 2 CPU ranks: shard instances, collect the trajectory chunks (slab reuse, final Storage layout
+    bit for bit) and the final states on rank 0"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER % {"root": ROOT})
     port = 29600 + os.getpid() % 300
