@@ -364,6 +364,29 @@ static void Q_to_phi(const double *Q, const double *q, double *out) {
         }
     FL(120);
 }
+/* One joint evaluated from explicit parameters -- the SAME joint_eval / Q_to_phi as every tree joint -- for oracle/loops.py, the
+ * dense-KKT stepper that handles closed kinematic loops (examples/lqr_deltabot.jl).  g[5]; Ga, Gb [5][6] = dg/d(x, phi) of the parent /
+ * child body (phi: q (x) (1, phi)).  xa, qa = NULL: the parent is the origin (Ga = 0). */
+void orc_joint_blocks(int32_t type, const double *p1, const double *p2, const double *axis, const double *qoff, const double *xa,
+                      const double *qa, const double *xb, const double *qb, double *g, double *Ga, double *Gb) {
+    static __thread mech_t M;
+    M.nb = M.ne = 1; M.type[0] = type;
+    memcpy(M.p1[0], p1, 24); memcpy(M.p2[0], p2, 24); memcpy(M.qoff[0], qoff, 32);
+    double n = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    for (int i = 0; i < 3; i++) M.ax[0][i] = axis[i] / n;
+    orth_rows(M.ax[0], M.V12[0]);
+    const int has_a = xa != NULL;
+    if (!has_a) { xa = X0; qa = QID; }
+    double Xa[15], Qa[20], Xb[15], Qb[20], Pa[15], Pb[15];
+    joint_eval(&M, 0, xa, qa, xb, qb, g, Xa, Qa, Xb, Qb, 1);
+    Q_to_phi(Qa, qa, Pa); Q_to_phi(Qb, qb, Pb);
+    for (int r = 0; r < 5; r++)
+        for (int c = 0; c < 3; c++) {
+            Ga[r * 6 + c] = has_a ? Xa[r * 3 + c] : 0.0; Ga[r * 6 + 3 + c] = has_a ? Pa[r * 3 + c] : 0.0;
+            Gb[r * 6 + c] = Xb[r * 3 + c]; Gb[r * 6 + 3 + c] = Pb[r * 3 + c];
+        }
+}
+
 /* (5x4) Q -> (5x3) Q * (dt/2) L(qk) [-w'/sq ; I]  (derivative w.r.t. w+ of q+ = qk (x) (dt/2)(sq, w+)) */
 static void Q_to_omega(const double *Q, const double *qk, const double *w, double sq, double dt, double *out) {
     double L[16], T[12];

@@ -80,6 +80,11 @@ int orc_step(const orc_mech_desc *m, double *z, double *lam, const double *uj);
 /* step with lambda treated as an exogenous input and no constraint solve (for validating the linearisation) */
 void orc_step_fixed_lambda(const orc_mech_desc *m, const double *z, const double *lam, const double *uj, double *znext);
 
+/* one joint from explicit parameters (g[5], Ga/Gb [5][6] = dg/d(x, phi) of parent / child; xa = qa = NULL: parent is the origin):
+ * building block of oracle/loops.py, the dense-KKT stepper for closed loops (examples/lqr_deltabot.jl:25-33) */
+void orc_joint_blocks(int32_t type, const double *p1, const double *p2, const double *axis, const double *qoff, const double *xa,
+                      const double *qa, const double *xb, const double *qb, double *g, double *Ga, double *Gb);
+
 /* constraint values g (5*ne) at state z */
 void orc_constraints(const orc_mech_desc *m, const double *z, double *g);
 
