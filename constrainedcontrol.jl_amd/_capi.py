@@ -271,3 +271,12 @@ def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5):
     check(lib().cclqr_riccati_tracking(mech.ptr, C.c_int32(mu), _i(cj), _d(zd), _d(Fd), _d(f64(Q).reshape(mx, mx)), _d(f64(R).reshape(mu, mu)),
                                        C.c_int32(N), C.c_double(tol), _d(K), C.byref(kb)))
     return K, kb.value
+
+
+def rate_or_refusal(n_units, seconds, status):
+    """throughput string of a run, or a refusal when any instance came back with status <= 0 (a rate of failed rollouts means nothing)"""
+    import numpy as np
+    bad = int((np.asarray(status) <= 0).sum())
+    if bad:
+        return "NO RATE: %d of %d instances failed (status <= 0)" % (bad, np.asarray(status).size)
+    return "%.3g inst-steps/s" % (n_units / seconds)

@@ -521,8 +521,9 @@ HD void ck_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
     for (int i = 0; i < 5; i++) L[Y.DL + 5 * P.mid + i] = b[i];
 }
 // back substitution step j: dl_l = y_l - Z_l dl_nbr; front 0 (lanes 0..4, one row each) l = mid+1+j, nbr = l-1; front 1 (lanes
-// 8..12) l = mid-1-j, nbr = l+1.  (A one-lane-per-front sweep with the next link's Z prefetched was measured slower: 6.2 k
-// against 4.7 k cycles per Newton iteration at 17 links.)
+// 8..12) l = mid-1-j, nbr = l+1.  Measured alternatives, all slower than these 4.7 k cycles per Newton iteration at 17 links: a
+// one-lane-per-front sweep with the next link's Z prefetched (6.2 k), and keeping dl in the five lanes' registers with a DPP
+// rotation instead of the LDS round trip (5.7 k branch-free, 8.5 k as the compiler first laid it out).
 HD void ck_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
     const int front = t >> 3, row = t & 7;
     if (t >= 16 || row >= 5) return;

@@ -32,6 +32,13 @@ struct CtrlDesc            # cclqr_ctrl_desc
     npid::Int32; pid_joint::Ptr{Int32}
     pid_P::Ptr{Float64}; pid_I::Ptr{Float64}; pid_D::Ptr{Float64}; pid_goal::Ptr{Float64}     # PID{T,N}, src/control/pid.jl:3-11
     noise_philox::Int32; noise_seed::UInt64                                                    # reproducible stand-in for randn()
+    n_ctrl::Int32                                                                              # > 1: one (K, zd, Fd) table per instance
+end
+
+struct RolloutOpts         # cclqr_rollout_opts
+    first_instance::Int64
+    pid_state_dev::Ptr{Float64}
+    pid_state_len::Int64
 end
 
 const REVOLUTE = Int32(0)
@@ -132,12 +139,14 @@ end
 "Device controller tables from the fields of an LQR / TrackingLQR (lqr.jl:3-15, lqr_tracking.jl:3-15).
  K: mx x mu x nK, zd: 13 x Nb x nsp, Fd: mu x nsp, N = horizon steps (0 for LQR{T,Inf}), ctrl = 0-based joint indices."
 function CtrlHandle(h::MechHandle, ctrl::Vector{Int32}, K::Array{Float64,3}, N::Integer, zd::Array{Float64,3}, Fd::Matrix{Float64};
-                    fric::Union{Nothing,Vector{Float64}} = nothing, noise_scale = 0.0)
+                    fric::Union{Nothing,Vector{Float64}} = nothing, noise_scale = 0.0, n_ctrl::Integer = 0)
     c = Ref{Ptr{Cvoid}}(C_NULL)
+    nc = max(n_ctrl, 1)          # n_ctrl > 1: K is mx x mu x (nK * n_ctrl), zd 13 x Nb x (nsp * n_ctrl), Fd mu x (nsp * n_ctrl): one table per instance
     GC.@preserve ctrl K zd Fd fric begin
-        d = CtrlDesc(length(ctrl), pointer(ctrl), size(K, 3), N, pointer(K), size(zd, 3), pointer(zd), pointer(Fd),
+        d = CtrlDesc(length(ctrl), pointer(ctrl), size(K, 3) ÷ nc, N, pointer(K), size(zd, 3) ÷ nc, pointer(zd), pointer(Fd),
                      fric === nothing ? Ptr{Float64}(C_NULL) : pointer(fric), noise_scale,
-                     0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, UInt64(0))
+                     0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, UInt64(0),
+                     n_ctrl)
         check(ccall((:cclqr_ctrl_create, lib), Cint, (Ptr{Cvoid}, Ref{CtrlDesc}, Ref{Ptr{Cvoid}}), h.ptr, d, c))
     end
     obj = CtrlHandle(c[])
@@ -154,6 +163,19 @@ function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, ste
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
                 h.ptr, c.ptr, n, steps, k0, z0, noise === nothing ? C_NULL : noise, record ? traj : C_NULL, zT, status))
     traj, zT, status
+end
+
+"Device-pointer rollout with explicit options (cclqr_rollout_ex): all pointers are device addresses (e.g. from AMDGPU.jl), the launch is
+ asynchronous on `stream`.  first_instance = global index of instance 1 of this shard (noise stream and per-instance controller table),
+ pid_state = device buffer n_inst x Nb x 2 carrying the PID integrators between launches (C_NULL: none)."
+function rollout_dev!(h::MechHandle, c::CtrlHandle, n::Integer, steps::Integer, k0::Integer, z0::Ptr{Float64}, lam::Ptr{Float64},
+                      traj::Ptr{Float64}, zT::Ptr{Float64}, status::Ptr{Int32}; noise::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_stride = 0,
+                      first_instance = 0, pid_state::Ptr{Float64} = Ptr{Float64}(C_NULL), stream::Ptr{Cvoid} = C_NULL)
+    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2)
+    check(ccall((:cclqr_rollout_ex, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
+                 Ref{RolloutOpts}, Ptr{Cvoid}),
+                h.ptr, c.ptr, n, steps, k0, z0, lam, noise, noise_stride, traj, zT, status, o, stream))
 end
 
 "Riccati launch shape: 0 = by problem size, 1 = one persistent workgroup per problem, 2 = tiled over the device (same results)."

@@ -17,7 +17,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """a GPU test that does not come back within three minutes is a hang, not a slow test: fail it instead of blocking the session"""
+    """a GPU test that does not come back within three minutes is a hang, not a slow test.  pytest-timeout's "thread" method cannot
+    interrupt a thread that sits in a HIP call: it dumps the stacks and ENDS THE WHOLE SESSION with os._exit -- the run reports the
+    hanging test and stops there (later tests do not run), instead of blocking the box until gpurun's own limit."""
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:

@@ -250,3 +250,23 @@ def test_emulated_maximum_size_32_bodies(cclqr, orc, emu):
     _, traj, st = emu_rollout(emu, orc, t, oc, z0, 12)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-10
+
+
+def test_chain_emulator_under_address_and_undefined_sanitizers(tmp_path):
+    """the emulator's LDS image is allocated at its exact size and NaN-poisoned (tests/emu/emu_chain.cpp); here it is
+    built with -fsanitize=address,undefined and run on cartpole chains of 2, 8, 17 and 32 bodies (both lane-group sizes, every
+    layout instantiation): an out-of-range LDS offset or an uninitialised read in the kernel's phase functions fails this test
+    instead of reading a neighbour's zeros."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu_dir = os.path.join(root, "tests", "emu")
+    exe = str(tmp_path / "asan_emu")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-x", "hip", "--offload-host-only", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-I/opt/rocm/include", "-o", exe,
+                           os.path.join(emu_dir, "emu_chain.cpp"), os.path.join(emu_dir, "asan_main.cpp")], stderr=subprocess.DEVNULL)
+    for n_links in (1, 7, 16, 31):
+        r = subprocess.run([exe, str(n_links), "12"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "rc 0 status" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
+        status = int(r.stdout.split("status")[1].split()[0])
+        assert status > 0

@@ -20,5 +20,5 @@ for label, ctrl, ns in (("open loop + friction + noise (the script's uncontrol!)
     t0 = time.time(); st = pkg.simulate(mech, pkg.Storage(1000, 4), ctrl, record=False, z0=z0, fric=ex["fric"], noise=noise, noise_scale=ns); dt = time.time() - t0
     ang = np.degrees(2 * np.arctan2(st.zT[:, 1:, 4], st.zT[:, 1:, 3]))
     err = np.abs((ang - 180 + 180) % 360 - 180)
-    print("%s: %.2fs (%.3g inst-steps/s incl. copies); status ok %d/%d; final |angle-180| median %s  90%% %s; cart y median %.3f" % (
-        label, dt, n * 1000 / dt, (st.status > 0).sum(), n, np.median(err, axis=0).round(1), np.percentile(err, 90, axis=0).round(1), np.median(np.abs(st.zT[:, 0, 1]))))
+    print("%s: %.2fs (%s incl. copies); status ok %d/%d; final |angle-180| median %s  90%% %s; cart y median %.3f" % (
+        label, dt, pkg._capi.rate_or_refusal(n * 1000, dt, st.status), (st.status > 0).sum(), n, np.median(err, axis=0).round(1), np.percentile(err, 90, axis=0).round(1), np.median(np.abs(st.zT[:, 0, 1]))))

@@ -13,4 +13,4 @@ capi.rollout(mh, ctrl, z0[:64], 10)
 for steps, rec in ((1000, False), (200, True)):
     t0 = time.time(); zT, traj, st = capi.rollout(mh, ctrl, z0, steps, record=rec); dt = time.time() - t0
     gb = (traj.nbytes if rec else 0) / 1e9
-    print("host-pointer cclqr_rollout 8192 x %d steps record=%s: %.3f s -> %.3g inst-steps/s (trajectory %.2f GB to pageable host memory)" % (steps, rec, dt, 8192 * steps / dt, gb))
+    print("host-pointer cclqr_rollout 8192 x %d steps record=%s: %.3f s -> %s (trajectory %.2f GB to pageable host memory)" % (steps, rec, dt, capi.rate_or_refusal(8192 * steps, dt, st), gb))

@@ -24,7 +24,7 @@ t0 = time.time(); zT, _, st = capi.rollout(mh, ctrl, z0, steps); dt = time.time(
 read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 tot = v[:13].sum()
-print("n_links %d inst %d steps %d: %.3fs %.3g inst-steps/s; newton iters/step %.2f evals/step %.2f" % (n_links, ninst, steps, dt, ninst * steps / dt, v[13] / v[15], v[14] / v[15]))
+print("n_links %d inst %d steps %d: %.3fs %s; newton iters/step %.2f evals/step %.2f" % (n_links, ninst, steps, dt, capi.rate_or_refusal(ninst * steps, dt, st), v[13] / v[15], v[14] / v[15]))
 for i, n in enumerate(names):
     print("  %-16s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / v[15]))
 print("  total cycles/step (per wave) %.0f" % (tot / v[15]))

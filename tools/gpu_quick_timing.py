@@ -17,4 +17,4 @@ mech = capi.MechHandle(t); ctrl = capi.CtrlHandle(mech, [0], K=K, N=1000, zd=zd)
 print("geometry", mech.geometry())
 for rep in range(3):
     t0 = time.time(); zT, _, st = capi.rollout(mech, ctrl, z0, steps); dt = time.time() - t0
-    print("n_links %d inst %d steps %d: %.3fs -> %.3g inst-steps/s (host-pointer API incl. copies); status min %d max %d mean %.2f" % (n_links, ninst, steps, dt, ninst * steps / dt, st.min(), st.max(), st.mean()))
+    print("n_links %d inst %d steps %d: %.3fs -> %s (host-pointer API incl. copies); status min %d max %d mean %.2f" % (n_links, ninst, steps, dt, capi.rate_or_refusal(ninst * steps, dt, st), st.min(), st.max(), st.mean()))

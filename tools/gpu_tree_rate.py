@@ -14,7 +14,7 @@ def rate(name, t, z0, n=8192, steps=300):
     zz = np.tile(z0[None], (n, 1, 1))
     capi.rollout(mh, ctrl, zz[:64], 10)
     t0 = time.time(); zT, _, st = capi.rollout(mh, ctrl, zz, steps); dt = time.time() - t0
-    print("%-28s nb=%2d lanes/LDS %s: %.3g inst-steps/s, Newton iters max %d" % (name, t.nb, mh.geometry(), n * steps / dt, st.max()))
+    print("%-28s nb=%2d lanes/LDS %s: %s, Newton iters max %d" % (name, t.nb, mh.geometry(), capi.rate_or_refusal(n * steps, dt, st), st.max()))
 
 
 ex = pkg.examples.dual_cartpole(); rate("dual cartpole (tree)", ex["mech"].tables(), ex["mech"].state())
