@@ -15,7 +15,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
+           "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex", "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
 class CclqrError(RuntimeError):
@@ -35,6 +35,10 @@ class CtrlDesc(C.Structure):
                 ("nsp", C.c_int32), ("zd", _dp), ("Fd", _dp), ("fric", _dp), ("noise_scale", C.c_double),
                 ("npid", C.c_int32), ("pid_joint", _ip), ("pid_P", _dp), ("pid_I", _dp), ("pid_D", _dp), ("pid_goal", _dp),
                 ("noise_philox", C.c_int32), ("noise_seed", C.c_uint64), ("n_ctrl", C.c_int32)]
+
+
+class RiccatiOpts(C.Structure):
+    _fields_ = [("path", C.c_int32), ("bf16_terms", C.c_int32)]
 
 
 class RolloutOpts(C.Structure):
@@ -240,8 +244,9 @@ def linearize(mech, zd, ctrl_joint, Fd=None):
     return A, Bu, Bl, G
 
 
-def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5):
-    """batched dlqr: A [nprob][mx][mx] (or [mx][mx]) -> K [nprob][N-1][mu][mx], kbreak [nprob]"""
+def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0):
+    """batched dlqr: A [nprob][mx][mx] (or [mx][mx]) -> K [nprob][N-1][mu][mx], kbreak [nprob].
+    path: 0 auto / 1 resident / 2 tiled; bf16_terms: 0 = fp64 MFMA (parity), 1..3 = split-bf16 measured-error mode (cclqr_riccati_opts)"""
     A = f64(A)
     single = A.ndim == 2
     mx = A.shape[-1]
@@ -255,12 +260,13 @@ def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5):
     Q, R = f64(Q).reshape(mx, mx), f64(R).reshape(mu, mu)
     K = np.zeros((nprob, max(N - 1, 0), mu, mx))
     kb = np.zeros(nprob, dtype=np.int32)
-    check(lib().cclqr_riccati(C.c_int32(nprob), C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl), _d(G), _d(Q), _d(R),
-                              C.c_int32(N), C.c_double(tol), _d(K), _i(kb)))
+    o = RiccatiOpts(int(path), int(bf16_terms))
+    check(lib().cclqr_riccati_ex(C.c_int32(nprob), C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl), _d(G), _d(Q), _d(R),
+                                 C.c_int32(N), C.c_double(tol), _d(K), _i(kb), C.byref(o)))
     return (K[0], int(kb[0])) if single else (K, kb)
 
 
-def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5):
+def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5, path=0, bf16_terms=0):
     t = mech.tables
     cj = i32(ctrl_joint).reshape(-1)
     mu, mx = len(cj), 12 * t.nb
@@ -268,8 +274,9 @@ def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5):
     Fd = f64(Fd).reshape(N, mu)
     K = np.zeros((N - 1, mu, mx))
     kb = C.c_int32(0)
-    check(lib().cclqr_riccati_tracking(mech.ptr, C.c_int32(mu), _i(cj), _d(zd), _d(Fd), _d(f64(Q).reshape(mx, mx)), _d(f64(R).reshape(mu, mu)),
-                                       C.c_int32(N), C.c_double(tol), _d(K), C.byref(kb)))
+    o = RiccatiOpts(int(path), int(bf16_terms))
+    check(lib().cclqr_riccati_tracking_ex(mech.ptr, C.c_int32(mu), _i(cj), _d(zd), _d(Fd), _d(f64(Q).reshape(mx, mx)), _d(f64(R).reshape(mu, mu)),
+                                          C.c_int32(N), C.c_double(tol), _d(K), C.byref(kb), C.byref(o)))
     return K, kb.value
 
 

@@ -21,6 +21,35 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* cclqr_last_error(void) { return g_err.c_str(); }
+
+// Device workspaces of the host-pointer entry points (linearize / riccati / rollout staging) are kept per thread and reused by the
+// next call instead of a hipMalloc + hipFree (both synchronise the device) per call; cclqr_release_workspaces() returns them.
+struct WsCache {
+    std::vector<std::pair<void*, size_t>> blocks;
+    size_t used = 0;
+};
+static thread_local WsCache g_ws;
+static hipError_t ws_get(void** p, size_t bytes) {
+    WsCache& w = g_ws;
+    if (bytes == 0) bytes = 8;
+    if (w.used == w.blocks.size()) w.blocks.push_back({nullptr, 0});
+    auto& b = w.blocks[w.used];
+    if (b.second < bytes) {
+        if (b.first) { hipError_t e = hipFree(b.first); b.first = nullptr; b.second = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&b.first, bytes);
+        if (e != hipSuccess) { b.first = nullptr; return e; }
+        b.second = bytes;
+    }
+    *p = b.first;
+    w.used++;
+    return hipSuccess;
+}
+struct WsScope { ~WsScope() { g_ws.used = 0; } };     // every block is free again when the entry point returns
+extern "C" int cclqr_release_workspaces(void) {
+    for (auto& b : g_ws.blocks) if (b.first) (void)hipFree(b.first);
+    g_ws.blocks.clear(); g_ws.used = 0;
+    return CCLQR_OK;
+}
 extern "C" int cclqr_version(void) { return 100; }
 extern "C" int cclqr_device_count(int32_t* n) {
     int c = 0;
@@ -162,11 +191,12 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
     double *dz0 = nullptr, *dzT = nullptr, *dtraj = nullptr, *dnoise = nullptr;
     int32_t* dst = nullptr;
     int rc = CCLQR_OK;
-    hipError_t e = hipMalloc((void**)&dz0, n_inst * nz * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dzT, n_inst * nz * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dst, n_inst * sizeof(int32_t));
-    if (e == hipSuccess && traj) e = hipMalloc((void**)&dtraj, n_inst * steps * nz * sizeof(double));
-    if (e == hipSuccess && noise) e = hipMalloc((void**)&dnoise, (size_t)n_inst * steps * sizeof(double));
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dz0, n_inst * nz * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dzT, n_inst * nz * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dst, n_inst * sizeof(int32_t));
+    if (e == hipSuccess && traj) e = ws_get((void**)&dtraj, n_inst * steps * nz * sizeof(double));
+    if (e == hipSuccess && noise) e = ws_get((void**)&dnoise, (size_t)n_inst * steps * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dz0, z0, n_inst * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && noise) e = hipMemcpy(dnoise, noise, (size_t)n_inst * steps * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -180,7 +210,6 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
     if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(zT, dzT, n_inst * nz * sizeof(double), hipMemcpyDeviceToHost);
     if (rc == CCLQR_OK && e == hipSuccess && traj) e = hipMemcpy(traj, dtraj, n_inst * steps * nz * sizeof(double), hipMemcpyDeviceToHost);
     if (rc == CCLQR_OK && e == hipSuccess && status) e = hipMemcpy(status, dst, n_inst * sizeof(int32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(dz0); (void)hipFree(dzT); (void)hipFree(dst); (void)hipFree(dtraj); (void)hipFree(dnoise);
     if (rc != CCLQR_OK) return rc;
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("rollout: ") + hipGetErrorString(e));
     return CCLQR_OK;
@@ -204,13 +233,14 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     double *dzd = nullptr, *dFd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
     int* dst = nullptr;
     std::vector<int> st(nk);
-    hipError_t e = hipMalloc((void**)&dzd, nk * nz * sizeof(double));
-    if (e == hipSuccess && Fd && mu > 0) e = hipMalloc((void**)&dFd, (size_t)nk * mu * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dA, nk * mx * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBl, nk * mx * ml * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dG, nk * ml * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dst, nk * sizeof(int));
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dzd, nk * nz * sizeof(double));
+    if (e == hipSuccess && Fd && mu > 0) e = ws_get((void**)&dFd, (size_t)nk * mu * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dA, nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, nk * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, nk * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dst, nk * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
     a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
@@ -221,7 +251,6 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     if (e == hipSuccess) e = hipMemcpy(Bl, dBl, nk * mx * ml * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(G, dG, nk * ml * mx * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nk * sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(dzd); (void)hipFree(dFd); (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG); (void)hipFree(dst);
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("linearize: ") + hipGetErrorString(e));
     for (int k = 0; k < nk; k++)
         if (st[k] <= 0) return fail(CCLQR_ENOCONV, "Newton did not converge at the setpoint of knot " + std::to_string(k));
@@ -230,21 +259,25 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
 
 // shared tail of the two dlqr entry points: run the recursion on device-resident (A,Bu,Bl,G), download K and kbreak
 static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varying, double tol, const double* dA, const double* dBu,
-                       const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak) {
+                       const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak,
+                       const cclqr_riccati_opts* opts) {
     const size_t nK = (size_t)nprob * (N > 1 ? N - 1 : 0) * mu * mx;
     double *dQ = nullptr, *dR = nullptr, *dK = nullptr, *dwork = nullptr;
     int *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
     std::vector<int> st(nprob), kb(nprob);
     RicArgs a;
     a.nprob = nprob; a.mx = mx; a.mu = mu; a.ml = ml; a.N = N; a.time_varying = time_varying; a.tol = tol;
+    a.path = opts ? opts->path : 0;
+    a.bf16_terms = opts ? opts->bf16_terms : 0;
+    if (a.path < 0 || a.path > 2 || a.bf16_terms < 0 || a.bf16_terms > 3) return fail(CCLQR_EINVAL, "riccati options: path in 0..2, bf16_terms in 0..3");
     const size_t wd = ric_total_work_doubles(a);
-    hipError_t e = hipMalloc((void**)&dQ, (size_t)mx * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dK, (nK + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dwork, wd * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dstop, nprob * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&dkb, nprob * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&dst, nprob * sizeof(int));
+    hipError_t e = ws_get((void**)&dQ, (size_t)mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dK, (nK + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dwork, wd * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dstop, nprob * sizeof(int));
+    if (e == hipSuccess) e = ws_get((void**)&dkb, nprob * sizeof(int));
+    if (e == hipSuccess) e = ws_get((void**)&dst, nprob * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(dQ, Q, (size_t)mx * mx * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && mu > 0) e = hipMemcpy(dR, R, (size_t)mu * mu * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(dK, 0, (nK + 1) * sizeof(double));
@@ -255,7 +288,6 @@ static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varyin
     if (e == hipSuccess && nK) e = hipMemcpy(K, dK, nK * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(kb.data(), dkb, nprob * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nprob * sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dK); (void)hipFree(dwork); (void)hipFree(dkb); (void)hipFree(dst); (void)hipFree(dstop);
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati: ") + hipGetErrorString(e));
     for (int p = 0; p < nprob; p++) {
         if (kbreak) kbreak[p] = kb[p];
@@ -272,27 +304,39 @@ extern "C" int cclqr_riccati_path(int32_t path) {
 
 extern "C" int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double* A, const double* Bu, const double* Bl,
                              const double* G, const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
+    return cclqr_riccati_ex(nprob, mx, mu, ml, A, Bu, Bl, G, Q, R, N, tol, K, kbreak, nullptr);
+}
+
+extern "C" int cclqr_riccati_ex(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double* A, const double* Bu, const double* Bl,
+                                const double* G, const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak,
+                                const cclqr_riccati_opts* opts) {
     if (!A || !Q || (mu > 0 && (!Bu || !R)) || (ml > 0 && (!Bl || !G)) || !K) return fail(CCLQR_EINVAL, "null argument");
     if (nprob < 1 || mx < 1 || mu < 0 || ml < 0 || N < 1) return fail(CCLQR_EINVAL, "bad sizes");
     double *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
     const size_t np = nprob;
-    hipError_t e = hipMalloc((void**)&dA, np * mx * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (np * mx * mu + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBl, (np * mx * ml + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dG, (np * ml * mx + 1) * sizeof(double));
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dA, np * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, (np * mx * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, (np * mx * ml + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, (np * ml * mx + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dA, A, np * mx * mx * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && mu > 0) e = hipMemcpy(dBu, Bu, np * mx * mu * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && ml > 0) e = hipMemcpy(dBl, Bl, np * mx * ml * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && ml > 0) e = hipMemcpy(dG, G, np * ml * mx * sizeof(double), hipMemcpyHostToDevice);
     int rc = CCLQR_OK;
-    if (e == hipSuccess) rc = run_riccati(nprob, mx, mu, ml, N, 0, tol, dA, dBu, dBl, dG, Q, R, K, kbreak);
-    (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG);
+    if (e == hipSuccess) rc = run_riccati(nprob, mx, mu, ml, N, 0, tol, dA, dBu, dBl, dG, Q, R, K, kbreak, opts);
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati upload: ") + hipGetErrorString(e));
     return rc;
 }
 
 extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int32_t* ctrl_joint, const double* zd, const double* Fd,
                                       const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
+    return cclqr_riccati_tracking_ex(m, mu, ctrl_joint, zd, Fd, Q, R, N, tol, K, kbreak, nullptr);
+}
+
+extern "C" int cclqr_riccati_tracking_ex(const cclqr_mech* m, int32_t mu, const int32_t* ctrl_joint, const double* zd, const double* Fd,
+                                         const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak,
+                                         const cclqr_riccati_opts* opts) {
     if (!m || !zd || !Q || !K || (mu > 0 && (!ctrl_joint || !R))) return fail(CCLQR_EINVAL, "null argument");
     if (N < 2 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "bad sizes");
     const int nb = m->nb, nk = N - 1;
@@ -308,13 +352,14 @@ extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int
     int* dst = nullptr;
     std::vector<int> st(nk);
     // knots 1..N-1 (lqr_tracking.jl:87-88): linearise all of them in one launch, keep the matrices on the device
-    hipError_t e = hipMalloc((void**)&dzd, nk * nz * sizeof(double));
-    if (e == hipSuccess && Fd && mu > 0) e = hipMalloc((void**)&dFd, (size_t)nk * mu * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dA, nk * mx * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBl, nk * mx * ml * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dG, nk * ml * mx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dst, nk * sizeof(int));
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dzd, nk * nz * sizeof(double));
+    if (e == hipSuccess && Fd && mu > 0) e = ws_get((void**)&dFd, (size_t)nk * mu * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dA, nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, (nk * mx * (size_t)(mu > 0 ? mu : 1)) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, nk * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, nk * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dst, nk * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
     a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
@@ -324,9 +369,8 @@ extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int
     if (e == hipSuccess) {
         for (int k = 0; k < nk && rc == CCLQR_OK; k++)
             if (st[k] <= 0) rc = fail(CCLQR_ENOCONV, "Newton did not converge at the setpoint of knot " + std::to_string(k));
-        if (rc == CCLQR_OK) rc = run_riccati(1, (int)mx, mu, (int)ml, N, 1, tol, dA, dBu, dBl, dG, Q, R, K, kbreak);
+        if (rc == CCLQR_OK) rc = run_riccati(1, (int)mx, mu, (int)ml, N, 1, tol, dA, dBu, dBl, dG, Q, R, K, kbreak, opts);
     }
-    (void)hipFree(dzd); (void)hipFree(dFd); (void)hipFree(dA); (void)hipFree(dBu); (void)hipFree(dBl); (void)hipFree(dG); (void)hipFree(dst);
     if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati_tracking: ") + hipGetErrorString(e));
     return rc;
 }

@@ -57,6 +57,8 @@ struct RicArgs {
     int* status;             // [nprob]
     double* work;            // ric_total_work_doubles(args) doubles
     int* stop;               // [nprob] scratch flags of the tiled path
+    int path;                // 0: the process default (set_riccati_path), 1 resident, 2 tiled
+    int bf16_terms;          // 0: fp64 MFMA; 1..3: split-bf16 products with fp32 accumulation (tiled path)
 };
 size_t ric_total_work_doubles(const RicArgs& a);
 void set_riccati_path(int p);   // 0 auto / 1: LDS-resident workgroup per problem whenever it fits; 2: tiled (three launches per backward step)

@@ -202,6 +202,8 @@ struct RicGrid {
     const double *A, *Bu, *Bl, *G, *Q, *R;
     double *AD, *W, *Abar, *P, *Ku, *KRK, *part, *TSp, *scratch, *K;
     int *stop, *kbreak, *status;
+    int bf16_terms;    // 0: fp64 MFMA (parity mode); 1..3: the two mx^3 products of a backward step on bf16 MFMA with fp32 accumulation,
+                       // every fp64 operand split into that many bf16 terms (measured-error mode, BASELINE configs[3]; tiled path only)
 };
 
 template <bool LDSM>
@@ -277,6 +279,74 @@ __device__ inline void tile_mfma_splitk(int K, FA la, FB lb, double (*red)[1024]
     __syncthreads();
 }
 
+// ---- measured-error mode (BASELINE configs[3] "dense Riccati on MFMA bf16 -> fp32 accumulate"): the same 32x32 split-k tile on
+// v_mfma_f32_16x16x16_bf16.  Every fp64 operand x is split on the fly into NS bf16 terms x ~ t0 + t1 + t2 (t0 = bf16(x),
+// t1 = bf16(x - t0), ...), the products t_i(A) t_j(B) with i + j < NS are accumulated in fp32 (NS = 1: one product = plain bf16;
+// 2: three; 3: six) and the tile goes back to fp64 after the wave reduction.  What limits the accuracy is the term count for
+// NS <= 2 and the fp32 accumulator for NS = 3; the error of the resulting gains and the time are REPORTED (tools/gpu_riccati_bf16.py,
+// tests/test_gpu_setup.py::test_riccati_bf16_split_mode_error_is_measured), the fp64 path stays the parity mode.
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ short bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_float(short b) { return __uint_as_float(((unsigned)(unsigned short)b) << 16); }
+template <int NS>
+__device__ __forceinline__ void bf16_split(double x, short* t) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const short b = bf16_rne((float)x);
+        t[s] = b;
+        x -= (double)bf16_to_float(b);
+    }
+}
+template <int NS, class FA, class FB>
+__device__ inline void tile_mfma_splitk_bf16(int K, FA la, FB lb, double (*red)[1024]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    v4f acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    const int ngroups = (K + 15) >> 4;                     // k-groups of 16: lane (li, lk) holds k = 16 g + 4 lk + 0..3
+    for (int g = wave; g < ngroups; g += 4) {
+        v4s at[2][NS], bt[2][NS];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 16 * g + 4 * lk + j;
+                short ta[NS], tb[NS];
+                bf16_split<NS>(k < K ? la(k, h) : 0.0, ta);
+                bf16_split<NS>(k < K ? lb(k, h) : 0.0, tb);
+#pragma unroll
+                for (int s = 0; s < NS; s++) { at[h][s][j] = ta[s]; bt[h][s][j] = tb[s]; }
+            }
+#pragma unroll
+        for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+            for (int hj = 0; hj < 2; hj++)
+#pragma unroll
+                for (int sa = NS - 1; sa >= 0; sa--)        // smallest products first
+#pragma unroll
+                    for (int sb = NS - 1; sb >= 0; sb--)
+                        if (sa + sb < NS) acc[hi][hj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[hi][sa], bt[hj][sb], acc[hi][hj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int hi = 0; hi < 2; hi++)
+#pragma unroll
+        for (int hj = 0; hj < 2; hj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave][(16 * hi + 4 * lk + r) * 32 + 16 * hj + li] = (double)acc[hi][hj][r];
+    __syncthreads();
+}
+// dispatch on the precision mode of the launch
+template <class FA, class FB>
+__device__ inline void tile_product(int bf16_terms, int K, FA la, FB lb, double (*red)[1024]) {
+    if (bf16_terms == 0) tile_mfma_splitk(K, la, lb, red);
+    else if (bf16_terms == 1) tile_mfma_splitk_bf16<1>(K, la, lb, red);
+    else if (bf16_terms == 2) tile_mfma_splitk_bf16<2>(K, la, lb, red);
+    else tile_mfma_splitk_bf16<3>(K, la, lb, red);
+}
+
 // has problem `prob` already stopped, or does the step before this one (k+1) meet the break criterion?  (uniform over the workgroup)
 __device__ inline bool ric_stopped(const RicGrid& a, int prob, int k, int ntile_p, int* flag) {
     if (threadIdx.x < 64) {             // first wavefront: strided partial sums, then a butterfly -- the same order in every workgroup
@@ -308,7 +378,7 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_pa_kernel(RicGrid a, int k) 
     const bool iok[2] = {i0 + li < mx, i0 + 16 + li < mx}, jok[2] = {j0 + li < na, j0 + 16 + li < na};
     const int mu = a.mu, ti = blockIdx.x / a.tn;
     for (int t = tid; t < 32 * mu; t += TILE_THREADS) { const int r = t / mu, q = t % mu; Dl[t] = (i0 + r < mx) ? AD[(size_t)(i0 + r) * na + mx + q] : 0.0; }
-    tile_mfma_splitk(mx,
+    tile_product(a.bf16_terms, mx,
         [&](int kk, int h) { return iok[h] ? P[(size_t)kk * mx + i0 + 16 * h + li] : 0.0; },      // Pk symmetric
         [&](int kk, int h) { return jok[h] ? AD[(size_t)kk * na + j0 + 16 * h + li] : 0.0; }, red);
     for (int e = tid; e < 1024; e += TILE_THREADS) {
@@ -452,7 +522,7 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_pn_kernel(RicGrid a, int k) 
     }
     const double* Abar = a.Abar + (size_t)prob * mx * mx;
     const bool iok[2] = {i0 + li < mx, i0 + 16 + li < mx}, jok[2] = {j0 + li < mx, j0 + 16 + li < mx};
-    tile_mfma_splitk(mx,
+    tile_product(a.bf16_terms, mx,
         [&](int kk, int h) { return iok[h] ? Abar[(size_t)kk * mx + i0 + 16 * h + li] : 0.0; },
         [&](int kk, int h) { return jok[h] ? W[(size_t)kk * na + j0 + 16 * h + li] : 0.0; }, red);
     double acc = 0.0;
@@ -701,8 +771,9 @@ size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_
 static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024; }
 // resident (one workgroup per problem, P and W in LDS) whenever it fits; otherwise the tiled three-launch step
 static bool ric_use_tiled(const RicArgs& a) {
-    if (!ric_resident_fits(a)) return true;
-    if (g_ric_path != 0) return g_ric_path == 2;
+    if (!ric_resident_fits(a) || a.bf16_terms > 0) return true;       // the measured-error mode exists on the tiled path only
+    const int path = a.path != 0 ? a.path : g_ric_path;
+    if (path != 0) return path == 2;
     // measured crossover: a single 84..96-state problem is faster spread over the device (41 vs 59 us per step), small problems
     // and large batches are faster resident (mx 48: 14 vs 20 us; 1024 x mx 84: 0.54 vs 0.74 ms per step)
     return a.mx >= 64 && a.nprob < 128;
@@ -714,7 +785,7 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
     RicGrid g;
     g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
-    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol;
+    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms;
     g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = a.stop;
     const size_t np = a.nprob, nlin = g.nlin, mx = a.mx, na = g.na, mu = a.mu, ml = a.ml;
     double* o = a.work;

@@ -105,7 +105,29 @@ int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t m
 int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
                   const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
 
-/* Tuning knob for the two dlqr entry points (lqr.jl:141, lqr_tracking.jl:73): 0 = choose by problem size and count (default), 1 = one
+/* Options of cclqr_riccati_ex / cclqr_riccati_tracking_ex (NULL or all zero = defaults).
+ *   path        launch shape: 0 = choose by problem size and count, 1 = one LDS-resident workgroup per problem whenever the problem fits
+ *               (mx up to ~96), 2 = every backward step tiled over the whole device.  Same results either way.
+ *   bf16_terms  0 = fp64 MFMA, the PARITY mode (gains equal the reference recursion's to 1e-7).  1..3 = measured-error mode of
+ *               BASELINE configs[3] ("dense Riccati on MFMA bf16 -> fp32 accumulate"): the two mx^3 products of a backward step
+ *               (lqr.jl:170) run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, every fp64 operand split into that many bf16
+ *               terms (1 = plain bf16, 3 = bf16x3); forces path 2.  Its gain error and speed are reported, not promised
+ *               (DESIGN.md 4.3): it does NOT reproduce the fp64 gains and the 1e-5 break test of lqr.jl:172 never fires. */
+typedef struct {
+    int32_t path;
+    int32_t bf16_terms;
+} cclqr_riccati_opts;
+
+int cclqr_riccati_ex(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
+                     const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak, const cclqr_riccati_opts *opts);
+int cclqr_riccati_tracking_ex(const cclqr_mech *m, int32_t mu, const int32_t *ctrl_joint, const double *zd, const double *Fd, const double *Q,
+                              const double *R, int32_t N, double tol, double *K, int32_t *kbreak, const cclqr_riccati_opts *opts);
+
+/* Device workspaces of the host-pointer entry points (cclqr_linearize, cclqr_riccati*, cclqr_rollout) are cached per calling thread and
+ * reused by the next call; this returns them to the driver (they are re-allocated on demand). */
+int cclqr_release_workspaces(void);
+
+/* Deprecated process-wide default of cclqr_riccati_opts.path (kept one round).  Tuning knob for the two dlqr entry points (lqr.jl:141, lqr_tracking.jl:73): 0 = choose by problem size and count (default), 1 = one
  * LDS-resident workgroup per problem whenever the problem fits (mx up to ~96), 2 = every backward step tiled over the whole device.
  * Same results either way. */
 int cclqr_riccati_path(int32_t path);

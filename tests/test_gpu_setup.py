@@ -341,3 +341,31 @@ def test_plain_c_program_through_the_abi(cclqr, orc, tmp_path):
     zo, _, sto = orc.rollout(t, orc.ctrl_desc(2, [0], K=Ko, N=1000, zd=zd), z0, 1000)
     assert all(s > 0 for s in st) and (sto > 0).all()
     assert np.abs(zT - zo).max() < 1e-8
+
+
+def test_riccati_bf16_split_mode_error_is_measured(cclqr, orc):
+    """BASELINE configs[3] ("dense Riccati on MFMA bf16 -> fp32 accumulate") as a measured-error option (cclqr_riccati_opts.bf16_terms):
+    the two mx^3 products of every backward step on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, fp64 operands split into 1..3
+    bf16 terms.  The fp64 MFMA path stays the parity mode; this test records what the option costs in accuracy on the Sawyer problem
+    (mx 84, mu 7, ml 35): bf16x3 reproduces the gains to ~5e-6, bf16x2 to ~2e-4, plain bf16 does not reproduce them at all (the
+    recursion amplifies its 4e-3 rounding to O(10)), and the 1e-5 break test of lqr.jl:172 never fires in any of them."""
+    import json
+    import os
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    t = ex["mech"].tables()
+    mech = capi.MechHandle(t)
+    A, Bu, Bl, G = (m[0] for m in capi.linearize(mech, ex["mech"].state()[None], list(range(7)), np.zeros((1, 7))))
+    Q, R, N = np.eye(84) * 1000.0 * t.dt, np.eye(7) * t.dt, 600
+    Kref, kbref = capi.riccati(A, Bu, Bl, G, Q, R, N, path=2)
+    Ko, kbo = orc.riccati(A, Bu, Bl, G, Q, R, N)
+    assert kbref == kbo and np.abs(Kref - Ko).max() < 1e-7 * np.abs(Ko).max()           # the parity mode
+    err = {}
+    for terms in (3, 2, 1):
+        K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N, bf16_terms=terms)
+        assert np.isfinite(K).all() and kb == 1                                         # fp32 noise in P: the break test never fires
+        err[terms] = np.abs(K - Kref).max() / np.abs(Kref).max()
+    assert err[3] < 1e-4 and err[3] < err[2] < 1e-2 and err[1] > 1e-2, err
+    with pytest.raises(capi.CclqrError):
+        capi.riccati(A, Bu, Bl, G, Q, R, N, bf16_terms=4)
