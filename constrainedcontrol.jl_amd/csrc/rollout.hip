@@ -10,7 +10,8 @@
 
 namespace cclqr {
 
-template <int G, bool TREE>
+// EXTRA: 0 = plain LQR / TrackingLQR feedback, 1 = + joint friction and injected / pre-generated noise, 2 = + PID (as in rollout_chain.hip)
+template <int G, bool TREE, int EXTRA>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     LaneRegs r;
     const int NL = newton_level_groups(G, nb), lg = t / nb, tl = t - lg * nb;   // lane groups of the level-parallel line search
     lane_load_consts(r, M, lg < NL ? tl : 0);
-    if (a.pid_state && a.k0 > 1 && valid && t < nb) { r.pid_int = a.pid_state[(inst * nb + t) * 2]; r.pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
+    if (EXTRA >= 2 && a.pid_state && a.k0 > 1 && valid && t < nb) { r.pid_int = a.pid_state[(inst * nb + t) * 2]; r.pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
 #ifdef CCLQR_PROFILE
     Prof prof;
     prof.start();
@@ -65,16 +66,14 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 double s = group_sum<G>(part);
                 if (t == 0 && valid) {
                     double u = (C->Fd ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
-                    if (C->noise_scale != 0.0) {
-                        if (a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
-                        else if (C->noise_philox) u += C->noise_scale * philox_normal(C->noise_key0, (unsigned long long)(a.inst0 + inst), k);
-                    }
+                    // noise: injected by the caller, or generated for this launch by philox_fill_kernel (capi.hip)
+                    if (EXTRA >= 1 && C->noise_scale != 0.0 && a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
                     L[Y.UJ + C->cj[i]] += u;
                 }
                 __syncthreads();
             }
         }
-        if (C->has_pid) {
+        if (EXTRA >= 2 && C->has_pid) {
             if (valid) ph_pid(t, nb, Y, L, r, C, dt, k == 1);
             __syncthreads();
         }
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.zT[inst * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
         if (a.lam) for (int e = t; e < 5 * nb; e += G) a.lam[inst * 5 * nb + e] = L[Y.LAM + e];
         if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
-        if (a.pid_state && t < nb) { a.pid_state[(inst * nb + t) * 2] = r.pid_int; a.pid_state[(inst * nb + t) * 2 + 1] = r.pid_last; }
+        if (EXTRA >= 2 && a.pid_state && t < nb) { a.pid_state[(inst * nb + t) * 2] = r.pid_int; a.pid_state[(inst * nb + t) * 2 + 1] = r.pid_last; }
     }
 #ifdef CCLQR_PROFILE
     prof.stamp(PF_IO);
@@ -134,10 +133,13 @@ size_t rollout_lds_bytes(int nb, int tree, int npairs) {
 }
 
 template <int G, bool TREE>
-static hipError_t launch_one(const RolloutArgs& a, unsigned grid, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<G, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static hipError_t launch_one(const RolloutArgs& a, int extra, unsigned grid, size_t lds, hipStream_t stream) {
+    const void* f = extra == 0 ? (const void*)rollout_kernel<G, TREE, 0> : (extra == 1 ? (const void*)rollout_kernel<G, TREE, 1> : (const void*)rollout_kernel<G, TREE, 2>);
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((rollout_kernel<G, TREE>), dim3(grid), dim3(64), lds, stream, a);
+    if (extra == 0) hipLaunchKernelGGL((rollout_kernel<G, TREE, 0>), dim3(grid), dim3(64), lds, stream, a);
+    else if (extra == 1) hipLaunchKernelGGL((rollout_kernel<G, TREE, 1>), dim3(grid), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((rollout_kernel<G, TREE, 2>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -148,7 +150,7 @@ hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, in
     const size_t lds = rollout_lds_bytes(nb, tree, npairs);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
-    return G == 16 ? launch_one<16, true>(a, grid, lds, stream) : (G == 32 ? launch_one<32, true>(a, grid, lds, stream) : launch_one<64, true>(a, grid, lds, stream));
+    return G == 16 ? launch_one<16, true>(a, extra, grid, lds, stream) : (G == 32 ? launch_one<32, true>(a, extra, grid, lds, stream) : launch_one<64, true>(a, extra, grid, lds, stream));
 }
 
 }  // namespace cclqr
