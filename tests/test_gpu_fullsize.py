@@ -239,3 +239,51 @@ def test_cfg3_as_scripted_upright_is_lost_on_both_paths(cclqr, orc):
     t = mech.tables()
     _, _, sto = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=lqr.K, N=lqr.N, zd=lqr.zd), z0[:8], 1000, nthreads=8)
     assert (sto < 0).all()
+
+
+def test_cfg4_distinct_setpoints_batched_lqr_drives_batched_rollout(cclqr, orc):
+    """"Riccati run per instance on distinct setpoints" end to end on the device -- 1024 Sawyer arms, each with its
+    OWN setpoint pose: one batched linearisation (1024 knots in one launch), one batched constrained Riccati (1024 problems of
+    mx 84 / mu 7 / ml 35, 699 backward steps, LDS-resident workgroup per problem), `Ku[1]` of every problem as its instance's
+    infinite-horizon controller (lqr.jl:40-43) through cclqr_ctrl_desc.n_ctrl, one batched rollout.  Every arm settles on its own setpoint; gains and
+    trajectories of sampled instances equal the oracle's."""
+    import json
+    import os
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    n = 1024
+    rng = np.random.default_rng(44)
+    ang = rng.uniform(-0.8, 0.8, (n, 7))                                      # a different pose per instance
+    off = rng.uniform(-0.002, 0.002, (n, 7))                                  # start inside the region of attraction (DESIGN 2)
+    zd, z0 = [], []
+    for p in range(n):
+        for e, a in zip(mech.eqconstraints, ang[p]):
+            cclqr.setJointPosition(mech, e, a)
+        zd.append(mech.state())
+        for e, a in zip(mech.eqconstraints, ang[p] + off[p]):
+            cclqr.setJointPosition(mech, e, a)
+        z0.append(mech.state())
+    zd, z0 = np.stack(zd), np.stack(z0)
+    mh = capi.MechHandle(t)
+    cj = list(range(7))
+    A, Bu, Bl, G = capi.linearize(mh, zd, cj, np.zeros((n, 7)))
+    Q, R, N = np.eye(84) * 1000.0 * t.dt, np.eye(7) * t.dt, 700
+    K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N)
+    Kinf = K[:, 0][:, None]                                                   # [n][1][7][84]: Ku[1] of every problem (lqr.jl:42 keeps exactly this)
+    for p in (0, 511, 1023):
+        Ao, Buo, Blo, Go = orc.linearize(t, zd[p], cj, np.zeros(7))
+        Ko, kbo = orc.riccati(Ao, Buo, Blo, Go, Q, R, N)
+        assert kb[p] == kbo and np.abs(Kinf[p, 0] - Ko[0]).max() < 1e-7 * np.abs(Ko[0]).max()
+    ctrl = capi.CtrlHandle(mh, cj, K=Kinf, N=0, zd=zd[:, None], n_ctrl=n)
+    steps = 600
+    zT, _, st = capi.rollout(mh, ctrl, z0, steps)
+    assert (st > 0).all()
+    assert np.abs(zT[:, :, 0:3] - zd[:, :, 0:3]).max() < 2e-4 and np.abs(zT[:, :, 7:]).max() < 1e-3      # each arm on ITS setpoint, at rest
+    assert np.abs(z0[:, :, 0:3] - zd[:, :, 0:3]).max() > 1e-3
+    sel = [0, 333, 1023]
+    oc = orc.ctrl_desc(7, cj, K=Kinf[sel], N=0, zd=zd[sel][:, None], n_ctrl=len(sel))
+    zo, _, sto = orc.rollout(t, oc, z0[sel], steps)
+    assert (sto > 0).all() and np.abs(zo - zT[sel]).max() < 1e-9
