@@ -18,7 +18,10 @@ def _gains(orc, ex, t, zd, N=1000):
     return K
 
 
-@pytest.mark.parametrize("n_links,ninst,steps,hanging", [(1, 37, 300, False), (3, 9, 200, False), (7, 5, 150, True), (16, 3, 120, True)])
+# one case per instantiation of the chain kernel's (lanes, layout links): (16, 8) x2, (16, 8) full, (32, 16), (32, 17), (32, 32); odd instance
+# counts leave lane groups of the last wavefront without an instance
+@pytest.mark.parametrize("n_links,ninst,steps,hanging", [(1, 37, 300, False), (3, 9, 200, False), (7, 5, 150, True), (11, 5, 100, True),
+                                                          (16, 3, 120, True), (22, 3, 60, True)])
 def test_rollout_matches_oracle(cclqr, orc, n_links, ninst, steps, hanging):
     capi = cclqr._capi
     ex = cclqr.examples.cartpole_n(n_links)
