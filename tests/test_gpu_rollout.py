@@ -274,3 +274,61 @@ def test_per_instance_controller_tables(cclqr, orc):
         assert np.array_equal(out.cpu().numpy(), zT[8:20])
         with pytest.raises(capi.CclqrError):
             capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=20)
+
+
+_SHARDED_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+import __graft_entry__ as g
+pkg = g.load_package(); capi = pkg._capi
+rank, world, local = pkg.dist.init_from_env(backend="gloo")       # two ranks share the box's one GPU: RCCL refuses that, gloo carries the bytes
+torch.cuda.set_device(0); capi.set_device(0)
+dev = torch.device("cuda", 0)
+n_links, n_local, T, H = 16, 48, 64, 4
+ex = pkg.examples.cartpole_n(n_links); t = ex["mech"].tables(); nb = t.nb
+zd = pkg.examples.cartpole_states(n_links, [0.0], np.array([[np.pi] + [0.0] * (n_links - 1)]))[0]
+rng = np.random.default_rng(7)
+K = rng.normal(size=(T - 1, 1, 12 * nb)) * 0.05
+phi = rng.uniform(-0.2, 0.2, (n_local * world, n_links)); phi[:, 0] += np.pi
+z0_all = pkg.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n_local * world), phi)
+mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, [0], K=K, N=T, zd=zd)
+lo, hi = pkg.dist.shard_bounds(n_local * world, rank, world)
+z0 = torch.from_numpy(z0_all[lo:hi]).to(dev)
+zT = torch.empty_like(z0); st = torch.zeros(n_local, dtype=torch.int32, device=dev)
+lam = torch.zeros((n_local, 5 * nb), dtype=torch.float64, device=dev)
+tg = pkg.dist.TrajectoryGather(rank, world, n_local, T, nb, H, dev)
+Tc = T // H
+for c in range(H):
+    tg.wait_slab_free(c)
+    capi.rollout_dev(mh, ctrl, n_local, Tc, c * Tc + 1, (z0 if c == 0 else zT).data_ptr(), lam.data_ptr(), 0, 0, tg.slab(c).data_ptr(), zT.data_ptr(), st.data_ptr(),
+                     torch.cuda.current_stream().cuda_stream)
+    tg.submit(c)
+traj = tg.finish()
+zall = pkg.dist.gather_to_root(zT, n_local * world, rank, world)
+torch.cuda.synchronize()
+if rank == 0:
+    zT1, traj1, st1 = capi.rollout(mh, ctrl, z0_all, T, record=True)          # the whole batch, one launch, one process
+    assert (st1 > 0).all()
+    assert np.array_equal(traj.cpu().numpy(), traj1), "chunked + collected trajectory differs from the single launch"
+    assert np.array_equal(zall.cpu().numpy(), zT1)
+    print("SHARDED_OK", tg.bytes_gathered)
+"""
+
+
+def test_two_ranks_chunked_rollout_and_trajectory_collection(tmp_path):
+    """SURVEY 8e on the one GPU of the box: two processes roll out their instance shards in 4 launches of 16 steps (k0 continuation, state and
+    multipliers carried), every chunk's trajectory slab travels to rank 0 on a second stream while the next chunk is computed
+    (dist.TrajectoryGather; gloo here, RCCL on a multi-GPU node), and what rank 0 holds is bit for bit the trajectory of ONE launch of
+    the whole batch in one process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARDED_WORKER % {"root": root})
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "SHARDED_OK" in r.stdout
