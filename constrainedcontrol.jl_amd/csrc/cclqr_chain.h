@@ -37,14 +37,29 @@ struct LinkC {
     double dtm;        // dt / m
     double sxb, sxa;   // dt^2 / m of the own body / of the parent body (0 when the parent is the origin)
     double fric;       // viscous friction of the own joint
-    int type;          // 0 revolute, 1 prismatic
-    bool has_a, has_c, on;   // parent is a link (not the origin) / a child link exists / lane owns a link
+    // lane flags: bit 0 = the lane owns a link, bit 1 = the parent is a link (not the origin), bit 2 = a child link exists,
+    // bit 3 = the joint is revolute (else prismatic), bit 4 = the lane's instance exists, bit 5 = bits 0 and 4.  Kept as ONE
+    // vector register and tested where needed (LINK_FLAGS_FRESH makes the compiler re-test instead of holding six 64-bit lane
+    // masks in scalar registers for the whole kernel)
+    int flags;
+    HD bool on() const { return (flags & 1) != 0; }
+    HD bool has_a() const { return (flags & 2) != 0; }
+    HD bool has_c() const { return (flags & 4) != 0; }
+    HD bool rev() const { return (flags & 8) != 0; }
+    HD bool valid() const { return (flags & 16) != 0; }
+    HD bool live() const { return (flags & 32) != 0; }
+    HD void set_valid(bool v) { flags |= v ? (16 | ((flags & 1) << 5)) : 0; }
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LINK_FLAGS_FRESH(c) asm volatile("" : "+v"((c).flags))
+#else
+#define LINK_FLAGS_FRESH(c) ((void)0)
+#endif
 
 HD void link_load_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
     const bool on = t < nb;
     const int l = on ? t : 0;
-    c.on = on;
+
     c.m = M->m[l];
 #pragma unroll
     for (int i = 0; i < 9; i++) c.J[i] = M->J[l][i];
@@ -52,21 +67,21 @@ HD void link_load_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
     for (int i = 0; i < 3; i++) { c.p1[i] = M->p1[l][i]; c.p2[i] = M->p2[l][i]; c.axis[i] = M->axis[l][i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) c.qoc[i] = M->qoc[l][i];
-    c.type = M->type[l];
-    const int vrow = c.type == 0 ? 3 : 0;     // where V1, V2 sit among the rows
+    const int type = M->type[l];              // 0 revolute, 1 prismatic
+    const int vrow = type == 0 ? 3 : 0;       // where V1, V2 sit among the rows
 #pragma unroll
     for (int i = 0; i < 3; i++) { c.V12[i] = M->sel[l][vrow][i]; c.V12[3 + i] = M->sel[l][vrow + 1][i]; }
     const int pa = M->parent[l];
-    c.has_a = on && pa >= 0;
-    c.has_c = on && M->childl[l] >= 0;
+    const bool has_a = on && pa >= 0;
+    c.flags = (on ? 1 : 0) | (has_a ? 2 : 0) | ((on && M->childl[l] >= 0) ? 4 : 0) | (type == 0 ? 8 : 0);
     c.dtm = dt / c.m;
     c.sxb = dt * c.dtm;
-    c.sxa = c.has_a ? dt * dt / M->m[pa >= 0 ? pa : 0] : 0.0;
+    c.sxa = has_a ? dt * dt / M->m[pa >= 0 ? pa : 0] : 0.0;
     c.fric = 0.0;
 }
 // selector of constraint row `row` (compile-time row index)
 HD void row_sel(const LinkC& c, int row, double* s) {
-    const bool rev = c.type == 0;
+    const bool rev = c.rev();
     const int e = rev ? row : row - 2;          // unit vector index when the row is a unit row
     const bool unit = rev ? row < 3 : row >= 2;
     const int v = rev ? row - 3 : row;          // 0 / 1: V1 / V2 when it is not
@@ -91,7 +106,7 @@ HD void joint_eval_sparse(const LinkC& c, const double* xa, const double* qa, co
     double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
     qmul(qac, qb, rel);
     qmul(rel, c.qoc, e);
-    const bool rot2 = c.type != 0;     // row 2 is rotational for a prismatic joint
+    const bool rot2 = !c.rev();     // row 2 is rotational for a prismatic joint
     if (!JAC) {
 #pragma unroll
         for (int row = 0; row < 5; row++) {
@@ -161,7 +176,7 @@ HD void joint_eval_sparse(const LinkC& c, const double* xa, const double* qa, co
         for (int k = 0; k < 3; k++) {
             PB[row][k] = Nb ? (pb3[0] * Nb[k] + pb3[1] * Nb[3 + k] + pb3[2] * Nb[6 + k]) : pb3[k];
             const double na = Na ? (pa3[0] * Na[k] + pa3[1] * Na[3 + k] + pa3[2] * Na[6 + k]) : pa3[k];
-            PA[row][k] = c.has_a ? na : 0.0;
+            PA[row][k] = c.has_a() ? na : 0.0;
         }
     }
 }
@@ -177,7 +192,7 @@ HD void jac_t_apply(const LinkC& c, const double (*XT)[3], const double (*PB)[3]
 #pragma unroll
         for (int r = 0; r < 5; r++) { pb += PB[r][k] * y[r]; pa += PA[r][k] * y[r]; }
         own[k] = x; own[3 + k] = pb;
-        par[k] = c.has_a ? -x : 0.0; par[3 + k] = pa;
+        par[k] = c.has_a() ? -x : 0.0; par[3 + k] = pa;
     }
 }
 
@@ -192,13 +207,13 @@ HD void ck_control_error(const double* z, const double* d, double* dz) {
 // passive joint friction (trackingLQR_triple_cartpole.jl:93-101): -fric * relative joint velocity; za = parent state (13) or the origin's
 HD double ck_friction(const LinkC& c, const double* z, const double* za) {
     double rel;
-    if (c.type == 0) {
+    if (c.rev()) {
         rel = c.axis[0] * z[10] + c.axis[1] * z[11] + c.axis[2] * z[12];
-        if (c.has_a) rel -= c.axis[0] * za[10] + c.axis[1] * za[11] + c.axis[2] * za[12];
+        if (c.has_a()) rel -= c.axis[0] * za[10] + c.axis[1] * za[11] + c.axis[2] * za[12];
     } else {
         double dv[3], dva[3], Ra[9];
 #pragma unroll
-        for (int i = 0; i < 3; i++) dv[i] = z[7 + i] - (c.has_a ? za[7 + i] : 0.0);
+        for (int i = 0; i < 3; i++) dv[i] = z[7 + i] - (c.has_a() ? za[7 + i] : 0.0);
         rotmat(za + 3, Ra);
         mtv3(Ra, dv, dva);
         rel = c.axis[0] * dva[0] + c.axis[1] * dva[1] + c.axis[2] * dva[2];
@@ -216,7 +231,7 @@ inline double pid_angle(double sn, double cs) { return 2.0 * atan2(sn, cs); }
 HD double ck_pid(const LinkC& c, const double* z, const double* za, double P, double I, double D, double goal, double dt, bool first,
                  double& pid_int, double& pid_last) {
     double th;
-    if (c.type == 0) {
+    if (c.rev()) {
         const double qac[4] = {za[3], -za[4], -za[5], -za[6]};
         double rel[4], e[4];
         qmul(qac, z + 3, rel);
@@ -233,7 +248,7 @@ HD double ck_pid(const LinkC& c, const double* z, const double* za, double P, do
     }
     const double PI = 3.14159265358979323846;
     double e = goal - th;
-    if (c.type == 0) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
+    if (c.rev()) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
     if (first) pid_last = e;
     pid_int += e * dt;
     const double de = (e - pid_last) / dt;
@@ -249,7 +264,7 @@ HD void ck_joint_wrench(const LinkC& c, double u, const double* q, const double*
     const double f[3] = {c.axis[0] * u, c.axis[1] * u, c.axis[2] * u};
     double fw[3], fb[3];
     mv3(Ra, f, fw); mtv3(Rb, fw, fb);
-    if (c.type == 1) {
+    if (!c.rev()) {
         double cb[3], cp[3];
         cross3(c.p2, fb, cb); cross3(c.p1, f, cp);
 #pragma unroll
@@ -335,7 +350,7 @@ HD void ck_next_pose(const double* z, const double* s, double dt, double* xq) {
 HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3],
                       const double (*wPA)[3], const double* g, const double* d, const double* pd) {
     const double sx = c.sxb + c.sxa;
-    const int jp = c.has_a ? j - 1 : j, jc = c.has_c ? j + 1 : j;
+    const int jp = c.has_a() ? j - 1 : j, jc = c.has_c() ? j + 1 : j;
 #pragma unroll
     for (int q = 0; q < 5; q++) {
         const int o = gk_row(q), ob = q < 3 ? 3 : 0;   // offset of PB inside the row
@@ -363,11 +378,11 @@ HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L
         if (store) {     // blocks are stored column by column (element (r, q) at 5 q + r): a column is five consecutive doubles
 #pragma unroll
             for (int r = 0; r < 5; r++) L[Y.SJJ + 25 * j + 5 * q + r] = ojj[r];
-            if (c.has_a) {
+            if (c.has_a()) {
 #pragma unroll
                 for (int r = 0; r < 5; r++) L[Y.SJP + 25 * j + 5 * q + r] = ojp[r];
             }
-            if (c.has_c) {
+            if (c.has_c()) {
 #pragma unroll
                 for (int r = 0; r < 5; r++) L[Y.SPJ + 25 * jc + 5 * q + r] = ojc[r];
             }
@@ -414,7 +429,7 @@ HD void gk_t_apply(const LinkC& c, int j, const Lay& Y, const double* L, const d
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) { own[i] = x[i]; own[3 + i] = pb[i]; par[i] = c.has_a ? -x[i] : 0.0; par[3 + i] = pa[i]; }
+    for (int i = 0; i < 3; i++) { own[i] = x[i]; own[3 + i] = pb[i]; par[i] = c.has_a() ? -x[i] : 0.0; par[3 + i] = pa[i]; }
 }
 
 // ---- body solve: ds = D^-1 (d + cd) with cd = Gk_b(own joint)' dl + Gk_a(child joint)' dl_child (the latter arrives from the child lane)
@@ -435,14 +450,31 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
 //  * loads are issued in the order of need (S_ll, right-hand side, target, S_ql), so the pivot chain of the factorisation
 //    starts after the first 25 and hides the rest (carrying prefetched blocks across the barrier in registers instead made
 //    the register allocator spill all over the kernel);
+// Plan of the chain kernel: like tri_plan, but with BALANCED fronts when the chain has an odd number of links (17: 8 + 8 steps
+// instead of 7 + 9).  Both fronts then fold into the middle link in the same (last) step; front 1 writes its contribution
+// -S_ql Z, -S_ql y to a scratch block instead of the middle link's own blocks (`merge`), and the middle solve adds it.  The
+// scratch is the (SJP, SPJ) pair of the chain's second link, which front 1 consumed in its first step.
+struct TriPlanB { TriPlan P; int merge; };
+HD TriPlanB tri_plan_balanced(int cs, int cn) {
+    TriPlanB B;
+    B.P = tri_plan(cs, cn);
+    const int rest = cn - 1;
+    B.merge = (rest > 0 && rest % 2 == 0) ? 1 : 0;
+    if (B.merge) { B.P.nA = B.P.nB = rest / 2; B.P.mid = cs + B.P.nB; B.P.steps = rest / 2; }
+    return B;
+}
+HD int tri_scratch_S(const TriPlanB& B, const Lay& Y) { return Y.SJP + 25 * (B.P.cs + 1); }
+HD int tri_scratch_R(const TriPlanB& B, const Lay& Y) { return Y.SPJ + 25 * (B.P.cs + 1); }
 struct TriCur {
     int oLL, oQL, oRhs, oTgt, oOut;   // LDS offsets at the current step: S_ll, S_ql, this lane's right-hand side (column c of S_lq, or
                                       // r_l), its target (column c of S_qq, or r_q) and where its solution goes (column c of S_ll, or r_l)
     int dblk, dvec;                   // per-step increments of the block offsets / of this lane's vector offsets
     int n;                            // steps of this lane's front (0: the lane takes no part)
+    int imerge, oScr;                 // front 1 of a balanced plan: in step imerge the target is the scratch block (-1: never)
     bool isy;
 };
-HD TriCur tri_cursor(int t, const TriPlan& P, const Lay& Y) {
+HD TriCur tri_cursor(int t, const TriPlanB& B, const Lay& Y) {
+    const TriPlan& P = B.P;
     TriCur K;
     const int front = t >> 3, col = t & 7;
     const bool in = t < 16 && col < 6;
@@ -458,6 +490,8 @@ HD TriCur tri_cursor(int t, const TriPlan& P, const Lay& Y) {
     K.oRhs = K.isy ? Y.R + 5 * l : (front ? Y.SPJ : Y.SJP) + 25 * b + 5 * cc;
     K.oTgt = K.isy ? Y.R + 5 * q : Y.SJJ + 25 * q + 5 * cc;
     K.oOut = K.isy ? Y.R + 5 * l : Y.SJJ + 25 * l + 5 * cc;
+    K.imerge = (front && B.merge) ? P.nB - 1 : -1;
+    K.oScr = K.isy ? tri_scratch_R(B, Y) : tri_scratch_S(B, Y) + 5 * cc;
     return K;
 }
 // LU (no pivoting; S is SPD-like) of the row-major 5x5 block A in registers, packed as in lu5 (cclqr_dev.h)
@@ -489,15 +523,16 @@ HD bool tri_step(TriCur& K, int i, const double* L, double* tg, double* zy, int*
         for (int r = 0; r < 5; r++) lu[r * 5 + cI] = L[K.oLL + 5 * cI + r];
 #pragma unroll
     for (int r = 0; r < 5; r++) zy[r] = L[K.oRhs + r];
+    const bool mstep = i == K.imerge;          // both fronts fold into the middle link now: this one's share goes to the scratch block
 #pragma unroll
-    for (int r = 0; r < 5; r++) tg[r] = L[K.oTgt + r];
+    for (int r = 0; r < 5; r++) tg[r] = mstep ? 0.0 : L[K.oTgt + r];
 #pragma unroll
     for (int e = 0; e < 25; e++) sql[e] = L[K.oQL + e];
     lu5_factor(lu);
     lu5_solve(lu, zy);
 #pragma unroll
     for (int r = 0; r < 5; r++) tg[r] -= sql[r] * zy[0] + sql[5 + r] * zy[1] + sql[10 + r] * zy[2] + sql[15 + r] * zy[3] + sql[20 + r] * zy[4];
-    *otg = K.oTgt; *oout = K.oOut;
+    *otg = mstep ? K.oScr : K.oTgt; *oout = K.oOut;
     K.oLL += K.dblk; K.oQL += K.dblk; K.oRhs += K.dvec; K.oTgt += K.dvec; K.oOut += K.dvec;
     return true;
 }
@@ -505,16 +540,18 @@ HD void tri_step_store(double* L, int otg, int oout, const double* tg, const dou
 #pragma unroll
     for (int r = 0; r < 5; r++) { L[otg + r] = tg[r]; L[oout + r] = zy[r]; }
 }
-// middle link: both sides have been folded in; one lane factorises and solves
-HD void ck_tri_mid(int t, const TriPlan& P, const Lay& Y, double* L) {
+// middle link: both sides have been folded in (a balanced plan: front 1's share is added from the scratch block here); one lane
+// factorises and solves
+HD void ck_tri_mid(int t, const TriPlanB& B, const Lay& Y, double* L) {
     if (t != 0) return;
+    const TriPlan& P = B.P;
     double A[25], b[5];
 #pragma unroll
-    for (int i = 0; i < 5; i++) b[i] = L[Y.R + 5 * P.mid + i];
+    for (int i = 0; i < 5; i++) b[i] = L[Y.R + 5 * P.mid + i] + (B.merge ? L[tri_scratch_R(B, Y) + i] : 0.0);
 #pragma unroll
     for (int cI = 0; cI < 5; cI++)
 #pragma unroll
-        for (int r = 0; r < 5; r++) A[r * 5 + cI] = L[Y.SJJ + 25 * P.mid + 5 * cI + r];
+        for (int r = 0; r < 5; r++) A[r * 5 + cI] = L[Y.SJJ + 25 * P.mid + 5 * cI + r] + (B.merge ? L[tri_scratch_S(B, Y) + 5 * cI + r] : 0.0);
     lu5_factor(A);
     lu5_solve(A, b);
 #pragma unroll

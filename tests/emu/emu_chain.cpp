@@ -40,7 +40,7 @@ double chain_eval(Inst& I, double alpha, bool active) {
         LaneTmp& T = I.T[t];
         T.part = 0.0;
         for (int k = 0; k < 7; k++) T.xq[k] = I.S[t].z[k];
-        if (active && I.c[t].on) {
+        if (active && I.c[t].on()) {
             double cf[6], sv[6], cTR[6], DINV[9];
             for (int k = 0; k < 6; k++) { cf[k] = L[Y.C + 6 * t + k] - alpha * I.S[t].cd[k]; sv[k] = I.S[t].s[k] - alpha * I.S[t].ds[k]; cTR[k] = L[Y.D + 6 * t + k]; }
             T.part = ck_body_eval<JAC>(I.c[t], I.S[t].z, sv, cf, cTR, cTR + 3, I.dt, T.xq, I.S[t].d, DINV, T.NB);
@@ -50,17 +50,17 @@ double chain_eval(Inst& I, double alpha, bool active) {
     for (int t = 0; t < G; t++) {
         LaneTmp& T = I.T[t];
         const LinkC& c = I.c[t];
-        if (!(active && c.on)) continue;
-        const double* pxq = c.has_a ? I.T[t - 1].xq : ORIGIN13;
-        const double* pNB = c.has_a ? I.T[t - 1].NB : I.T[t].NB;
+        if (!(active && c.on())) continue;
+        const double* pxq = c.has_a() ? I.T[t - 1].xq : ORIGIN13;
+        const double* pNB = c.has_a() ? I.T[t - 1].NB : I.T[t].NB;
         joint_eval_sparse<JAC>(c, pxq, pxq + 3, T.xq, T.xq + 3, pNB, T.NB, T.g, T.wXT, T.wPB, T.wPA);
         for (int i = 0; i < 5; i++) T.part += T.g[i] * T.g[i];
     }
     if (JAC)
         for (int t = 0; t < G; t++) {
             const LinkC& c = I.c[t];
-            if (!(active && c.on)) continue;
-            const double* pd = c.has_a ? I.S[t - 1].d : I.S[t].d;
+            if (!(active && c.on())) continue;
+            const double* pd = c.has_a() ? I.S[t - 1].d : I.S[t].d;
             ck_schur_rows(c, t, true, Y, L, I.T[t].wXT, I.T[t].wPB, I.T[t].wPA, I.T[t].g, I.S[t].d, pd);
         }
     double acc = 0.0;
@@ -99,7 +99,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
     const int G = I.G;
     for (int t = 0; t < G; t++) {
         link_load_consts(I.c[t], M, t, nb, dt);
-        if (C->has_fric && I.c[t].on) I.c[t].fric = C->fric[t];
+        if (C->has_fric && I.c[t].on()) I.c[t].fric = C->fric[t];
     }
     std::vector<double> pid_int(G), pid_last(G);
     for (int64_t inst = 0; inst < n_inst; inst++) {
@@ -107,7 +107,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
         // what the kernel initialises: the multipliers (zero, or the caller's warm start)
         for (int t = 0; t < nb; t++) for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = 0.0;
         for (int t = 0; t < G; t++) {
-            const bool on = I.c[t].on;
+            const bool on = I.c[t].on();
             const int ut = on ? M->perm[t] : 0;
             for (int i = 0; i < 7; i++) I.S[t].z[i] = on ? z0[inst * nz + ut * 13 + i] : (i == 3 ? 1.0 : 0.0);
             for (int i = 0; i < 6; i++) { I.S[t].s[i] = on ? z0[inst * nz + ut * 13 + 7 + i] : 0.0; I.S[t].cd[i] = 0; I.S[t].d[i] = 0; I.S[t].ds[i] = 0; }
@@ -133,7 +133,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                 for (int i = 0; i < 6; i++) zf[13 * t + 7 + i] = I.S[t].s[i];
             }
             for (int t = 0; t < G; t++)
-                for (int i = 0; i < 13; i++) za[13 * t + i] = I.c[t].has_a ? zf[13 * (t - 1) + i] : ORIGIN13[i];
+                for (int i = 0; i < 13; i++) za[13 * t + i] = I.c[t].has_a() ? zf[13 * (t - 1) + i] : ORIGIN13[i];
             if (gate) {
                 for (int t = 0; t < nb; t++) {
                     double dz[12];
@@ -163,18 +163,18 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                 for (int t = 0; t < G; t++) ck_joint_wrench(I.c[t], uj[t], &zf[13 * t + 3], &za[13 * t + 3], &F[3 * t], &tau[3 * t], &W6[6 * t], &W6[6 * t + 3]);
                 for (int t = 0; t < G; t++) {
                     const LinkC& c = I.c[t];
-                    if (c.has_c) for (int i = 0; i < 3; i++) { F[3 * t + i] += W6[6 * (t + 1) + i]; tau[3 * t + i] += W6[6 * (t + 1) + 3 + i]; }
+                    if (c.has_c()) for (int i = 0; i < 3; i++) { F[3 * t + i] += W6[6 * (t + 1) + i]; tau[3 * t + i] += W6[6 * (t + 1) + 3 + i]; }
                     double cTR[6], gk[5], kXT[3][3], kPB[5][3], kPA[5][3], lam[5];
                     ck_step_invariants(c, &zf[13 * t], &F[3 * t], &tau[3 * t], dt, M->g, cTR, cTR + 3);
                     joint_eval_sparse<true>(c, &za[13 * t], &za[13 * t + 3], &zf[13 * t], &zf[13 * t + 3], nullptr, nullptr, gk, kXT, kPB, kPA);
-                    if (!c.on) continue;
+                    if (!c.on()) continue;
                     for (int i = 0; i < 5; i++) lam[i] = L[Y.LAM + 5 * t + i];
                     gk_store(t, Y, L, kXT, kPB, kPA);
                     for (int i = 0; i < 6; i++) L[Y.D + 6 * t + i] = cTR[i];
                     jac_t_apply(c, kXT, kPB, kPA, lam, &own[6 * t], &par[6 * t]);
                 }
                 for (int t = 0; t < nb; t++)
-                    for (int i = 0; i < 6; i++) { L[Y.C + 6 * t + i] = own[6 * t + i] + (I.c[t].has_c ? par[6 * (t + 1) + i] : 0.0); I.S[t].cd[i] = 0.0; }
+                    for (int i = 0; i < 6; i++) { L[Y.C + 6 * t + i] = own[6 * t + i] + (I.c[t].has_c() ? par[6 * (t + 1) + i] : 0.0); I.S[t].cd[i] = 0.0; }
             }
             // ---- newton
             bool done = dead, failed = false;
@@ -182,9 +182,10 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
             double normf0 = chain_eval<true>(I, 0.0, !done);
             for (int iter = 1; iter <= 100 && !done; iter++) {
                 for (int ci = 0; ci < M->nchains; ci++) {
-                    const TriPlan P = tri_plan(M->chain_start[ci], M->chain_len[ci]);
+                    const TriPlanB PB = tri_plan_balanced(M->chain_start[ci], M->chain_len[ci]);
+                    const TriPlan& P = PB.P;
                     std::vector<TriCur> K(G);
-                    for (int t = 0; t < G; t++) K[t] = tri_cursor(t, P, Y);
+                    for (int t = 0; t < G; t++) K[t] = tri_cursor(t, PB, Y);
                     for (int i = 0; i < P.steps; i++) {
                         double tg[64][5], zy[64][5];
                         int otg[64], oout[64];
@@ -192,7 +193,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                         for (int t = 0; t < G; t++) act[t] = tri_step(K[t], i, L, tg[t], zy[t], &otg[t], &oout[t]);     // every lane's loads come before any lane's stores
                         for (int t = 0; t < G; t++) if (act[t]) tri_step_store(L, otg[t], oout[t], tg[t], zy[t]);
                     }
-                    for (int t = 0; t < G; t++) ck_tri_mid(t, P, Y, L);
+                    for (int t = 0; t < G; t++) ck_tri_mid(t, PB, Y, L);
                     for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ck_tri_back(t, j, P, Y, L);
                 }
                 double pdn = 0.0;
@@ -202,7 +203,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                     for (int t = 0; t < nb; t++) {
                         double DINV[9];
                         for (int i = 0; i < 9; i++) DINV[i] = L[Y.DINV + 9 * t + i];
-                        for (int i = 0; i < 6; i++) I.S[t].cd[i] = own[6 * t + i] + (I.c[t].has_c ? par[6 * (t + 1) + i] : 0.0);
+                        for (int i = 0; i < 6; i++) I.S[t].cd[i] = own[6 * t + i] + (I.c[t].has_c() ? par[6 * (t + 1) + i] : 0.0);
                         ck_body_solve(I.c[t], I.S[t].d, I.S[t].cd, DINV, I.S[t].ds);
                         for (int i = 0; i < 6; i++) pdn += I.S[t].ds[i] * I.S[t].ds[i];
                         for (int i = 0; i < 5; i++) pdn += L[Y.DL + 5 * t + i] * L[Y.DL + 5 * t + i];
