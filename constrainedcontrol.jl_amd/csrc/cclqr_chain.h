@@ -48,6 +48,9 @@ struct LinkC {
     HD bool rev() const { return (flags & 8) != 0; }
     HD bool valid() const { return (flags & 16) != 0; }
     HD bool live() const { return (flags & 32) != 0; }
+    static const int DEAD = 64, BAD = 128;     // set by the rollout loop (see there)
+    HD bool dead() const { return (flags & DEAD) != 0; }
+    HD bool bad() const { return (flags & BAD) != 0; }
     HD void set_valid(bool v) { flags |= v ? (16 | ((flags & 1) << 5)) : 0; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -454,16 +457,20 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
 // instead of 7 + 9).  Both fronts then fold into the middle link in the same (last) step; front 1 writes its contribution
 // -S_ql Z, -S_ql y to a scratch block instead of the middle link's own blocks (`merge`), and the middle solve adds it.  The
 // scratch is the (SJP, SPJ) pair of the chain's second link, which front 1 consumed in its first step.
-struct TriPlanB { TriPlan P; int merge; };
-HD TriPlanB tri_plan_balanced(int cs, int cn) {
+// The swept chain may be a REDUCED one (every second link of the original, after cr_level below): its links are cs + st i,
+// i < cn, and the coupling blocks of neighbours x < x' = x + st sit where the level below left them: S_{x',x} in SJP[x']
+// ("lower" block of x'), S_{x,x'} in SPJ[x + 1] ("upper" block of x) -- for st = 1 the plain layout.
+struct TriPlanB { TriPlan P; int merge, st; };      // P.cs, P.mid are links; P.cn, P.nA, P.nB, P.steps count links of the swept chain
+HD TriPlanB tri_plan_balanced(int cs, int cn, int st = 1) {
     TriPlanB B;
-    B.P = tri_plan(cs, cn);
+    B.P = tri_plan(0, cn);
     const int rest = cn - 1;
     B.merge = (rest > 0 && rest % 2 == 0) ? 1 : 0;
-    if (B.merge) { B.P.nA = B.P.nB = rest / 2; B.P.mid = cs + B.P.nB; B.P.steps = rest / 2; }
+    if (B.merge) { B.P.nA = B.P.nB = rest / 2; B.P.steps = rest / 2; }
+    B.P.cs = cs; B.P.mid = cs + st * B.P.nB; B.st = st;
     return B;
 }
-HD int tri_scratch_S(const TriPlanB& B, const Lay& Y) { return Y.SJP + 25 * (B.P.cs + 1); }
+HD int tri_scratch_S(const TriPlanB& B, const Lay& Y) { return Y.SJP + 25 * (B.P.cs + B.st); }
 HD int tri_scratch_R(const TriPlanB& B, const Lay& Y) { return Y.SPJ + 25 * (B.P.cs + 1); }
 struct TriCur {
     int oLL, oQL, oRhs, oTgt, oOut;   // LDS offsets at the current step: S_ll, S_ql, this lane's right-hand side (column c of S_lq, or
@@ -480,14 +487,14 @@ HD TriCur tri_cursor(int t, const TriPlanB& B, const Lay& Y) {
     const bool in = t < 16 && col < 6;
     K.n = in ? (front ? P.nB : P.nA) : 0;
     K.isy = col == 5;
-    const int l = front ? P.cs : P.cs + P.cn - 1, q = front ? l + 1 : l - 1;
-    const int b = front ? q : l;                           // the link whose (SJP, SPJ) pair couples l and q
+    const int st = B.st;
+    const int l = front ? P.cs : P.cs + st * (P.cn - 1), q = front ? l + st : l - st;
     const int cc = col < 5 ? col : 0;
-    K.dblk = front ? 25 : -25;
-    K.dvec = K.isy ? (front ? 5 : -5) : K.dblk;
+    K.dblk = front ? 25 * st : -25 * st;
+    K.dvec = K.isy ? (front ? 5 * st : -5 * st) : K.dblk;
     K.oLL = Y.SJJ + 25 * l;
-    K.oQL = (front ? Y.SJP : Y.SPJ) + 25 * b;
-    K.oRhs = K.isy ? Y.R + 5 * l : (front ? Y.SPJ : Y.SJP) + 25 * b + 5 * cc;
+    K.oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * (q + 1);                                  // S_ql: lower block of q / upper block of q
+    K.oRhs = K.isy ? Y.R + 5 * l : (front ? Y.SPJ + 25 * (l + 1) : Y.SJP + 25 * l) + 5 * cc;   // S_lq: upper / lower block of l
     K.oTgt = K.isy ? Y.R + 5 * q : Y.SJJ + 25 * q + 5 * cc;
     K.oOut = K.isy ? Y.R + 5 * l : Y.SJJ + 25 * l + 5 * cc;
     K.imerge = (front && B.merge) ? P.nB - 1 : -1;
@@ -561,18 +568,173 @@ HD void ck_tri_mid(int t, const TriPlanB& B, const Lay& Y, double* L) {
 // 8..12) l = mid-1-j, nbr = l+1.  Measured alternatives, all slower than these 4.7 k cycles per Newton iteration at 17 links: a
 // one-lane-per-front sweep with the next link's Z prefetched (6.2 k), and keeping dl in the five lanes' registers with a DPP
 // rotation instead of the LDS round trip (5.7 k branch-free, 8.5 k as the compiler first laid it out).
-HD void ck_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
+HD void ck_tri_back(int t, int j, const TriPlanB& B, const Lay& Y, double* L) {
+    const TriPlan& P = B.P;
     const int front = t >> 3, row = t & 7;
     if (t >= 16 || row >= 5) return;
     if (j >= (front ? P.nB : P.nA)) return;
-    const int l = front ? P.mid - 1 - j : P.mid + 1 + j;
-    const int nbr = front ? l + 1 : l - 1;
+    const int l = front ? P.mid - B.st * (1 + j) : P.mid + B.st * (1 + j);
+    const int nbr = front ? l + B.st : l - B.st;
     double z[5], dn[5];
 #pragma unroll
     for (int cI = 0; cI < 5; cI++) { z[cI] = L[Y.SJJ + 25 * l + 5 * cI + row]; dn[cI] = L[Y.DL + 5 * nbr + cI]; }
     const double y = L[Y.R + 5 * l + row];
     L[Y.DL + 5 * l + row] = y - (z[0] * dn[0] + z[1] * dn[1] + z[2] * dn[2] + z[3] * dn[3] + z[4] * dn[4]);
 }
+
+// ---- one level of odd-even (cyclic) reduction ahead of the two-front sweep.  The sweep is a chain of dependent 5x5
+// factorisations (one per step and front); eliminating every second link FIRST costs about two such steps -- all odd links at once,
+// W lanes per link -- and halves the chain that is left.  For the links x_i = cs + st i, i < n, every odd i (l = x_i, p = l - st,
+// nx = l + st) gives, with the lower / upper block convention of TriPlanB:
+//   Z- = S_ll^-1 S_lp -> in place (lower block of l);  Z+ = S_ll^-1 S_l,nx -> in place (upper block of l);  y = S_ll^-1 r_l -> R[l]
+//   S_pp -= S_pl Z-;   S_p,nx = -S_pl Z+  -> upper block of p (over S_pl);    r_p  -= S_pl y          (phase A)
+//   S_nx,nx -= S_nx,l Z+;   S_nx,p = -S_nx,l Z- -> lower block of nx (over S_nx,l);   r_nx -= S_nx,l y   (phase B)
+// A and B are separate passes because link p of one odd link is link nx of the one below: both update the same S and r.
+// The 11 right-hand-side columns of a link (5 of Z-, 5 of Z+, y) are dealt to its W lanes, lane w taking k = w, w + W, ...;
+// every lane factorises S_ll itself (as in the sweep).  Afterwards dl_l = y - Z- dl_p - Z+ dl_nx (cr_back), after the sweep.
+template <int W>
+struct CrLane {
+    static const int NS = (11 + W - 1) / W;
+    int fl;                      // bit 0: the lane takes part, bit 1: the link has a next link, bit 2 + s: column slot s is in use
+    int w;                       // lane within the link: its columns are k = w + W s
+    int oLL, oPL, oNL;
+    int oRhs[NS], oA[NS], oB[NS];
+    double z[NS][5];
+    HD bool act() const { return (fl & 1) != 0; }
+    HD bool has_n() const { return (fl & 2) != 0; }
+    HD bool ok(int s) const { return (fl & (4 << s)) != 0; }
+    HD int kind(int s) const { const int k = w + W * s; return (k >= 5 ? 1 : 0) + (k >= 10 ? 1 : 0); }   // 0: column of Z-, 1: of Z+, 2: y
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CR_FLAGS_FRESH(K) asm volatile("" : "+v"((K).fl), "+v"((K).w))
+#else
+#define CR_FLAGS_FRESH(K) ((void)0)
+#endif
+template <int W>
+HD void cr_setup(CrLane<W>& K, int t, int cs, int n, int st, const Lay& Y, bool skip) {
+    const int i = t / W;
+    K.w = t - W * i;
+    const int nodd = n / 2, idx = 2 * i + 1;
+    const bool act = i < nodd && !skip, has_n = idx + 1 < n;
+    const int l = act ? cs + st * idx : cs + st, p = l - st, nx = l + st;
+    K.oLL = Y.SJJ + 25 * l;
+    K.oPL = Y.SPJ + 25 * (p + 1);
+    K.oNL = has_n ? Y.SJP + 25 * nx : K.oPL;
+    K.fl = (act ? 1 : 0) | (has_n ? 2 : 0);
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++) {
+        const int k = K.w + W * s;
+        const int T = K.kind(s), cI = k - 5 * T;
+        const bool ok = act && k < 11 && (T != 1 || has_n);
+        K.fl |= ok ? (4 << s) : 0;
+        const int up_l = has_n ? Y.SPJ + 25 * (l + 1) : K.oLL;     // never read when there is no next link; kept inside the image
+        K.oRhs[s] = T == 0 ? Y.SJP + 25 * l + 5 * cI : (T == 1 ? up_l + 5 * cI : Y.R + 5 * l);
+        K.oA[s] = T == 0 ? Y.SJJ + 25 * p + 5 * cI : (T == 1 ? K.oPL + 5 * cI : Y.R + 5 * p);
+        const int nn = has_n ? nx : p;
+        K.oB[s] = T == 0 ? K.oNL + 5 * cI : (T == 1 ? Y.SJJ + 25 * nn + 5 * cI : Y.R + 5 * nn);
+        if (!ok) { K.oRhs[s] = K.oLL; K.oA[s] = K.oLL; K.oB[s] = K.oLL; }
+    }
+}
+// phase A, loads and arithmetic: the lane's solutions z (kept for phase B) and its p-side columns tA; cr_store_a writes them AFTER
+// every lane has loaded (the caller puts the store behind this call in the wavefront's instruction stream).  A fill column
+// (S_p,nx, S_nx,p) replaces what its slot held: the old value enters with factor 0.
+template <int W>
+HD void cr_phase_a(CrLane<W>& K, const double* L, double (*tA)[5]) {
+    if (!K.act()) return;
+    double lu[25], blk[25];
+#pragma unroll
+    for (int cI = 0; cI < 5; cI++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) lu[r * 5 + cI] = L[K.oLL + 5 * cI + r];
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) K.z[s][r] = L[K.oRhs[s] + r];
+    lu5_factor(lu);
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++) lu5_solve(lu, K.z[s]);
+    SCHED_FENCE();      // the factorisation is dead here: the neighbour block and the targets take its registers (fetching them
+                        // ahead of the pivot chain costs ~80 registers more than the kernel has)
+#pragma unroll
+    for (int e = 0; e < 25; e++) blk[e] = L[K.oPL + e];
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) tA[s][r] = L[K.oA[s] + r];
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++) {
+        const double* z = K.z[s];
+        const double keep = K.kind(s) != 1 ? 1.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) tA[s][r] = keep * tA[s][r] - (blk[r] * z[0] + blk[5 + r] * z[1] + blk[10 + r] * z[2] + blk[15 + r] * z[3] + blk[20 + r] * z[4]);
+    }
+}
+template <int W>
+HD void cr_store_a(const CrLane<W>& K, double* L, const double (*tA)[5]) {
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++)
+        if (K.ok(s)) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) { L[K.oRhs[s] + r] = K.z[s][r]; L[K.oA[s] + r] = tA[s][r]; }
+        }
+}
+template <int W>
+HD void cr_phase_b(const CrLane<W>& K, const double* L, double (*tB)[5]) {
+    if (!(K.act() && K.has_n())) return;
+    double blk[25];
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) tB[s][r] = L[K.oB[s] + r];
+#pragma unroll
+    for (int e = 0; e < 25; e++) blk[e] = L[K.oNL + e];
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++) {
+        const double* z = K.z[s];
+        const double keep = K.kind(s) != 0 ? 1.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) tB[s][r] = keep * tB[s][r] - (blk[r] * z[0] + blk[5 + r] * z[1] + blk[10 + r] * z[2] + blk[15 + r] * z[3] + blk[20 + r] * z[4]);
+    }
+}
+template <int W>
+HD void cr_store_b(const CrLane<W>& K, double* L, const double (*tB)[5]) {
+#pragma unroll
+    for (int s = 0; s < CrLane<W>::NS; s++)
+        if (K.ok(s) && K.has_n()) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) L[K.oB[s] + r] = tB[s][r];
+        }
+}
+// multiplier steps of the eliminated (odd) links, rows dealt to the link's W lanes
+template <int W>
+HD void cr_back(int t, int cs, int n, int st, const Lay& Y, double* L, bool skip) {
+    const int i = t / W, w = t - W * i;
+    const int idx = 2 * i + 1;
+    if (!(i < n / 2) || skip) return;
+    const int l = cs + st * idx, p = l - st, nx = l + st;
+    const bool has_n = idx + 1 < n;
+    double dp[5], dn[5];
+#pragma unroll
+    for (int cI = 0; cI < 5; cI++) { dp[cI] = L[Y.DL + 5 * p + cI]; dn[cI] = has_n ? L[Y.DL + 5 * nx + cI] : 0.0; }
+    const int oZm = Y.SJP + 25 * l, oZp = has_n ? Y.SPJ + 25 * (l + 1) : oZm;
+    double out[(5 + W - 1) / W];
+#pragma unroll
+    for (int q = 0; q < (5 + W - 1) / W; q++) {
+        const int row = w + W * q, rr = row < 5 ? row : 0;
+        double acc = L[Y.R + 5 * l + rr];
+#pragma unroll
+        for (int cI = 0; cI < 5; cI++) { acc -= L[oZm + 5 * cI + rr] * dp[cI]; const double zp = L[oZp + 5 * cI + rr]; acc -= (has_n ? zp : 0.0) * dn[cI]; }
+        out[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < (5 + W - 1) / W; q++) {
+        const int row = w + W * q;
+        if (row < 5) L[Y.DL + 5 * l + row] = out[q];
+    }
+}
+// chains of at least this many links get one reduction level: below, the two passes cost what they save (9 links: 4 sweep steps
+// either way)
+#define CR_MIN_LINKS 12
 
 // LDS image of the chain kernel.  Gathered across lanes by the block-tridiagonal elimination: the Schur blocks, the
 // right-hand side R and the multiplier step DL.  Read by the neighbour lanes: the sparse G_k of every joint (GKA).  Private

@@ -10,11 +10,25 @@
 #include <limits>
 #include <math.h>
 #include <string>
+#include <array>
 #include <vector>
 
 using namespace cclqr;
 
 namespace {
+// one cyclic-reduction level as the kernel runs it: every lane's loads and arithmetic of a pass, then every lane's stores
+template <int W>
+static void cr_level_emu(int G, int cs, int cn, const cclqr::Lay& Y, double* L) {
+    using namespace cclqr;
+    std::vector<CrLane<W>> K(G);
+    std::vector<std::array<std::array<double, 5>, CrLane<W>::NS>> tc(G);
+    for (int t = 0; t < G; t++) cr_setup<W>(K[t], t, cs, cn, 1, Y, false);
+    for (int t = 0; t < G; t++) cr_phase_a<W>(K[t], L, reinterpret_cast<double(*)[5]>(tc[t].data()));
+    for (int t = 0; t < G; t++) if (K[t].act()) cr_store_a<W>(K[t], L, reinterpret_cast<const double(*)[5]>(tc[t].data()));
+    for (int t = 0; t < G; t++) cr_phase_b<W>(K[t], L, reinterpret_cast<double(*)[5]>(tc[t].data()));
+    for (int t = 0; t < G; t++) if (K[t].act()) cr_store_b<W>(K[t], L, reinterpret_cast<const double(*)[5]>(tc[t].data()));
+}
+
 struct LinkS { double z[7], s[6], ds[6], cd[6], d[6]; };
 struct LaneTmp { double xq[7], NB[9], g[5], wXT[3][3], wPB[5][3], wPA[5][3]; double part; };
 
@@ -182,7 +196,13 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
             double normf0 = chain_eval<true>(I, 0.0, !done);
             for (int iter = 1; iter <= 100 && !done; iter++) {
                 for (int ci = 0; ci < M->nchains; ci++) {
-                    const TriPlanB PB = tri_plan_balanced(M->chain_start[ci], M->chain_len[ci]);
+                    const int cs = M->chain_start[ci], cn = M->chain_len[ci];
+                    const bool cr = G == 32 && nb <= 17 && cn >= CR_MIN_LINKS;     // = CR && cr of the kernel
+                    const bool w2 = false;
+                    if (cr) {
+                        if (w2) cr_level_emu<2>(G, cs, cn, Y, L); else cr_level_emu<4>(G, cs, cn, Y, L);
+                    }
+                    const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1);
                     const TriPlan& P = PB.P;
                     std::vector<TriCur> K(G);
                     for (int t = 0; t < G; t++) K[t] = tri_cursor(t, PB, Y);
@@ -194,7 +214,8 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                         for (int t = 0; t < G; t++) if (act[t]) tri_step_store(L, otg[t], oout[t], tg[t], zy[t]);
                     }
                     for (int t = 0; t < G; t++) ck_tri_mid(t, PB, Y, L);
-                    for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ck_tri_back(t, j, P, Y, L);
+                    for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ck_tri_back(t, j, PB, Y, L);
+                    if (cr) for (int t = 0; t < G; t++) { if (w2) cr_back<2>(t, cs, cn, 1, Y, L, false); else cr_back<4>(t, cs, cn, 1, Y, L, false); }
                 }
                 double pdn = 0.0;
                 {

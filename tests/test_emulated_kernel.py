@@ -31,7 +31,8 @@ def emu_rollout(emu, orc, t, ctrl, z0, steps, noise=None, G=0):
     return zT, traj, st
 
 
-@pytest.mark.parametrize("n_links,steps,hanging,G", [(1, 150, False, 0), (1, 60, False, 64), (3, 100, False, 0), (7, 60, True, 0), (16, 25, True, 0)])
+@pytest.mark.parametrize("n_links,steps,hanging,G", [(1, 150, False, 0), (1, 60, False, 64), (3, 100, False, 0), (7, 60, True, 0), (16, 25, True, 0),
+                                                   (11, 20, True, 0), (12, 20, True, 0), (15, 20, True, 0)])   # 12/13/16 links: the reduction level with an even / odd count
 def test_emulated_rollout_matches_oracle(cclqr, orc, emu, n_links, steps, hanging, G):
     ex = cclqr.examples.cartpole_n(n_links)
     t = ex["mech"].tables()

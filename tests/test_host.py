@@ -254,7 +254,9 @@ def test_chain_rollout_kernel_resources(tmp_path):
         variant = int(re.search(r"ELi(\d)EEEv", name).group(1))
         if variant == 0:
             assert k["sgpr_spill"] == 0, (name, k)
-            assert k["vgpr"] <= 480, (name, k)           # margin below the 512-register file: not at the allocator's limit
+            assert k["vgpr_spill"] == 0, (name, k)
+            # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
+            assert k["vgpr"] <= (496 if "ILi32ELi1" in name else 440), (name, k)
         else:
             assert k["sgpr_spill"] <= 16, (name, k)
 
