@@ -265,11 +265,26 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T):
         run()
     torch.cuda.synchronize()
     dt2 = (time.perf_counter() - t0) / 5
+    # the same mechanism with the device filled (4096 instances at eight per wavefront are 512 wavefronts on 1024 SIMDs)
+    n16 = 16 * n
+    z16_d = z0_d.repeat(16, 1, 1)
+    zT16_d = torch.empty_like(z16_d)
+    st16_d = torch.zeros(n16, dtype=torch.int32, device=dev)
+    run16 = lambda: capi.rollout_dev(mh, ctrl, n16, 1000, 1, z16_d.data_ptr(), 0, 0, 0, 0, zT16_d.data_ptr(), st16_d.data_ptr(), stream)
+    run16()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run16()
+    torch.cuda.synchronize()
+    dt16 = (time.perf_counter() - t0) / 3
+    ok16 = bool((st16_d > 0).all().item())
     m = mu + ml
     f_ric = 4 * mx ** 3 + 4 * mx ** 2 * m + 2 * mx * (ml ** 2 + m ** 2) + 2 / 3 * m ** 3 + 2 / 3 * ml ** 3
     nsteps = T - max(int(lqr.kbreak), 1)
     return {"cartpole_cfg2": {"instances": n, "sim_steps": 1000, "value": n * 1000 / dt2, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt2,
-                              "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak)},
+                              "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak),
+                              "device_filled": {"instances": n16, "record": False, "value": (n16 * 1000 / dt16) if ok16 else None, "ms_per_rollout": 1e3 * dt16}},
             "riccati_setup": {"mx": mx, "backward_steps": nsteps, "flops_per_step": f_ric,
                               "note": "LQR construction of the headline workload = linearize + %d-step recursion (projected form, tiled over the device, fp64 MFMA); "
                                       "wall time incl. host<->device copies" % nsteps,

@@ -461,12 +461,15 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
 // i < cn, and the coupling blocks of neighbours x < x' = x + st sit where the level below left them: S_{x',x} in SJP[x']
 // ("lower" block of x'), S_{x,x'} in SPJ[x + 1] ("upper" block of x) -- for st = 1 the plain layout.
 struct TriPlanB { TriPlan P; int merge, st; };      // P.cs, P.mid are links; P.cn, P.nA, P.nB, P.steps count links of the swept chain
-HD TriPlanB tri_plan_balanced(int cs, int cn, int st = 1) {
+// fronts = 1: the 8-lane instantiation (mechanisms of up to 4 links, eight instances per wavefront) has room for one front only,
+// which sweeps from the leaf all the way to the chain's first link.
+HD TriPlanB tri_plan_balanced(int cs, int cn, int st = 1, int fronts = 2) {
     TriPlanB B;
     B.P = tri_plan(0, cn);
     const int rest = cn - 1;
-    B.merge = (rest > 0 && rest % 2 == 0) ? 1 : 0;
+    B.merge = (fronts == 2 && rest > 0 && rest % 2 == 0) ? 1 : 0;
     if (B.merge) { B.P.nA = B.P.nB = rest / 2; B.P.steps = rest / 2; }
+    if (fronts == 1) { B.P.nB = 0; B.P.nA = rest; B.P.steps = rest; }
     B.P.cs = cs; B.P.mid = cs + st * B.P.nB; B.st = st;
     return B;
 }

@@ -42,8 +42,22 @@ __device__ __forceinline__ double dpp_row_ror(double v) {
 }
 // sum over the G lanes of a group, result in every lane of the group: rotate-and-add inside each 16-lane row (DPP), then
 // combine rows (G = 32: one cross-row permute; G = 64: four scalar lane reads)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
+    if (G == 8) {     // 8-lane groups (half rows): mirror inside the half row, then the two quad exchanges; every lane adds the same
+                      // pairs (in either operand order), so all eight end up with the same bits
+        v += dpp_f64<0x141>(v);     // row_half_mirror: lane i <-> 7 - i
+        v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+        return v;
+    }
     v += dpp_row_ror<8>(v);
     v += dpp_row_ror<4>(v);
     v += dpp_row_ror<2>(v);

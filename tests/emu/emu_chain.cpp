@@ -101,10 +101,10 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
     const int nb = M->nb, nz = 13 * nb;
     const double dt = M->dt;
     Inst I;
-    I.G = G_override > 0 ? G_override : (nb <= 8 ? 16 : 32);
+    I.G = G_override > 0 ? G_override : (nb <= 4 ? 8 : (nb <= 8 ? 16 : 32));
     if (I.G < nb) return CCLQR_EINVAL;
     I.nb = nb; I.dt = dt;
-    I.Y = make_chain_layout(nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : 32)));     // = chain_layout_links(nb) of rollout_chain.hip
+    I.Y = make_chain_layout(nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : 32))));     // = chain_layout_links(nb) of rollout_chain.hip
     I.lds.resize(I.Y.total);          // exact size: an out-of-range offset is an out-of-bounds access for the sanitizer
     I.L = I.lds.data();
     I.c.resize(I.G); I.S.resize(I.G); I.T.resize(I.G);
@@ -202,7 +202,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                     if (cr) {
                         if (w2) cr_level_emu<2>(G, cs, cn, Y, L); else cr_level_emu<4>(G, cs, cn, Y, L);
                     }
-                    const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1);
+                    const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1, G >= 16 ? 2 : 1);
                     const TriPlan& P = PB.P;
                     std::vector<TriCur> K(G);
                     for (int t = 0; t < G; t++) K[t] = tri_cursor(t, PB, Y);
