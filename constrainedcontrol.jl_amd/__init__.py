@@ -4,7 +4,7 @@ The directory name carries a dot, so import it through `__graft_entry__.load_pac
 Arithmetic on the hot path happens only in csrc/ (HIP, through the C-ABI of include/cclqr.h); this package is
 the host-side mirror of the reference's plugin interface and never falls back to a CPU implementation.
 """
-from .mechanism import (Body, Box, EqualityConstraint, MechTables, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, RotY, RotZ,
+from .mechanism import (Body, Box, EqualityConstraint, FixedOrientation, MechTables, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, RotY, RotZ,
                         getid, mechanism_from_urdf_tables, minimal_to_maximal, one_quaternion, parse_urdf, qconj, qmul, setJointPosition, setPosition, setVelocity, vrotate)
 from . import examples
 from . import _capi

@@ -131,6 +131,7 @@ extern "C" int cclqr_set_pid_state(double* pid_state_dev) { g_pid_state = pid_st
 
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
+    if (m->host.loop) { if (lanes) *lanes = 64; if (lds_bytes) *lds_bytes = (int32_t)loop_lds_bytes(m->nb, m->nj); return CCLQR_OK; }
     if (lanes) *lanes = rollout_lanes_per_instance(m->nb, m->host.tree);
     if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs);
     return CCLQR_OK;
@@ -143,7 +144,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
-    if (rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    if (!m->host.loop && rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     const int64_t first = opts ? opts->first_instance : 0;
     if (first < 0) return fail(CCLQR_EINVAL, "negative first_instance");
     if (c->host.n_ctrl > 1 && first + n_inst > c->host.n_ctrl) return fail(CCLQR_EINVAL, "more instances than per-instance controller tables");
@@ -169,6 +170,11 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
+    if (m->host.loop) {      // closed loops: plain LQR law only (build_ctrl_tables refuses the others)
+        if (extra != 0 || noise) return fail(CCLQR_EUNSUPPORTED, "closed-loop mechanisms take the plain LQR law only");
+        HIPCHK(launch_rollout_loop(a, m->nb, m->nj, (hipStream_t)stream));
+        return CCLQR_OK;
+    }
     HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, (hipStream_t)stream));
     return CCLQR_OK;
 }
@@ -218,6 +224,7 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
 extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
                                double* A, double* Bu, double* Bl, double* G) {
     if (!m || !zd || !A || !Bl || !G || (mu > 0 && (!ctrl_joint || !Bu))) return fail(CCLQR_EINVAL, "null argument");
+    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "linearsystem of a closed-loop mechanism (redundant constraint rows) is outside this build's scope");
     if (nk < 0 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
     const int nb = m->nb;
@@ -338,6 +345,7 @@ extern "C" int cclqr_riccati_tracking_ex(const cclqr_mech* m, int32_t mu, const 
                                          const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak,
                                          const cclqr_riccati_opts* opts) {
     if (!m || !zd || !Q || !K || (mu > 0 && (!ctrl_joint || !R))) return fail(CCLQR_EINVAL, "null argument");
+    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "TrackingLQR of a closed-loop mechanism is outside this build's scope");
     if (N < 2 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "bad sizes");
     const int nb = m->nb, nk = N - 1;
     const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb;

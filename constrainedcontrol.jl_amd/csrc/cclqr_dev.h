@@ -20,6 +20,7 @@
 #define CCLQR_MAXL 32          // links per mechanism supported by the device path
 #define CCLQR_MAXK 4           // child joints per body (general trees)
 #define CCLQR_MAXP 48          // sibling pairs (joints that share their parent body)
+#define CCLQR_MAXI 8           // joints around one body of a closed-loop mechanism
 #define HD __host__ __device__ __forceinline__
 
 namespace cclqr {
@@ -53,6 +54,11 @@ struct MechDev {
     int el_lx[CCLQR_MAXL][CCLQR_MAXK];                 // S_{l,x_g}   (holds Z_{l,x_g} = S_ll^-1 S_{l,x_g} afterwards)
     int el_xl[CCLQR_MAXL][CCLQR_MAXK];                 // S_{x_g,l}
     int el_t[CCLQR_MAXL][CCLQR_MAXK][CCLQR_MAXK];      // [g'][g]: S_{x_g',x_g}
+    // ---- closed loops (loop != 0; cclqr_loop.h): nj >= nb joints, bodies and joints in the caller's order (perm, jperm = identity);
+    // m, J are indexed by body; parent (parent BODY or -1), type, p1, p2, axis, qoc, sel, rotmask by joint; jchild = child body
+    int loop, nj;
+    int jchild[CCLQR_MAXL];
+    int inc_n[8], inc_j[8][CCLQR_MAXI], inc_side[8][CCLQR_MAXI];   // joints around body b; side 0: b is the child, 1: the parent
 };
 
 // ---- controller tables in device memory ----

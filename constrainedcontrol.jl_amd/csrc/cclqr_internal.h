@@ -34,6 +34,9 @@ int chain_lanes_per_instance(int nb);
 int chain_layout_links(int nb);
 size_t chain_lds_bytes(int nb);
 hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, hipStream_t stream);
+// closed-loop mechanisms (rollout_loop.hip)
+size_t loop_lds_bytes(int nb, int nj);
+hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, hipStream_t stream);
 
 struct LinArgs {
     const MechDev* M;
@@ -71,6 +74,7 @@ struct cclqr_mech {
     cclqr::MechDev host;       // internal link order
     cclqr::MechDev* dev;
     int nb;
+    int nj;                    // joints: nb for trees, >= nb for closed-loop mechanisms
     int link_of_body[CCLQR_MAXL];   // user body  -> internal link
     int link_of_joint[CCLQR_MAXL];  // user joint -> internal link (= link of its child body)
     int device;

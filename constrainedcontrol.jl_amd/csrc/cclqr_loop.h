@@ -1,0 +1,248 @@
+// cclqr_loop.h -- phase functions of the rollout kernel for mechanisms with CLOSED kinematic loops (examples/lqr_deltabot.jl:25-33:
+// five bodies, seven joints, 33 constraint rows on 30 body coordinates).  Same discretisation, Newton rules and sign conventions
+// as the tree kernels (cclqr_dev.h / cclqr_newton.h); what changes is the bookkeeping and the linear solve:
+//   * bodies and joints are separate index sets (joint j: parent body ja = M->parent[j] or the origin, child body jb =
+//     M->jchild[j]); a body lists its incident joints (M->inc_*), in the caller's joint order;
+//   * a loop makes the constraint rows redundant, so the Schur complement S = G_v D^-1 G_k' on the multipliers is singular
+//     (rank 28 of 35 for the deltabot, FixedOrientation padded to five rows with two null rows): it is assembled DENSE and solved by
+//     Gaussian elimination with complete pivoting that stops at the numerical rank.  Multipliers are then one solution of a
+//     consistent singular system (the pivoted basic solution); velocities and poses -- what a rollout returns -- are unique.
+// One instance per wavefront; lane t < nb owns body t, lane t < nj owns joint t, lane r < 5 nj owns row r of S.
+// Shared with tests/emu/emu_loop.cpp, which runs the same functions lane by lane on the CPU.
+#pragma once
+#include "cclqr_dev.h"
+
+namespace cclqr {
+
+#define CCLQR_LOOP_MAXB 8      // bodies
+#define CCLQR_LOOP_MAXJ 12     // joints: 5 rows each, one row of S per lane of the wavefront
+#define LOOP_RANK_TOL 1e-11    // pivots below this fraction of the first pivot are rank deficiency
+
+// LDS image of one instance.  Body-indexed arrays keep the names (and meaning) of the tree kernels' layout so that their body phases
+// (ph_body_eval, ph_control_error, ph_gain_partial, ph_accept, ph_update) run unchanged; joint-indexed arrays have nj entries.
+// SS = the dense system [S | r], row stride 5 nj + 1 (+1 if that is even: odd stride, conflict-free column walks).
+HD int loop_row_stride(int nj) { const int w = 5 * nj + 1; return (w & 1) ? w : w + 1; }
+HD Lay make_loop_layout(int nb, int nj) {
+    Lay L; int o = 0;
+    L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;   L.DS = o; o += 6 * nb;
+    L.LAM = o; o += 5 * nj;  L.LT = o; o += 5 * nj;  L.DL = o; o += 5 * nj;
+    L.XQ = o; o += 7 * nb;   L.NB = o; o += 9 * nb;  L.DINV = o; o += 9 * nb; L.DTM = o; o += nb;
+    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nj;   L.R = o; o += 5 * nj;      // R: column permutation of the pivoting (as doubles)
+    L.GKA = o; o += BLK * nj; L.GKB = o; o += BLK * nj; L.GVA = o; o += BLK * nj; L.GVB = o; o += BLK * nj;
+    L.UJ = o; o += nj;
+    L.C = o; o += 6 * nb;    L.CD = o; o += 6 * nb;
+    L.DZ = o; o += 12 * nb;
+    L.SS = o; o += 5 * nj * loop_row_stride(nj);
+    L.SJJ = L.SJP = L.SPJ = 0;
+    L.total = o | 1;
+    return L;
+}
+
+// constants of the owned body (t < nb: m, J) and of the owned joint (t < nj: vertices, axis, offset, row selectors)
+HD void loop_load_consts(LaneRegs& r, const MechDev* M, int t) {
+    const int b = t < M->nb ? t : 0, j = t < M->nj ? t : 0;
+    r.m = M->m[b];
+    for (int i = 0; i < 9; i++) r.J[i] = M->J[b][i];
+    for (int i = 0; i < 3; i++) { r.p1[i] = M->p1[j][i]; r.p2[i] = M->p2[j][i]; r.axis[i] = M->axis[j][i]; }
+    for (int i = 0; i < 4; i++) r.qoc[i] = M->qoc[j][i];
+    for (int i = 0; i < 5; i++)
+        for (int k = 0; k < 3; k++) r.sel[i][k] = M->sel[j][i][k];
+    r.parent = M->parent[j]; r.childl = M->jchild[j]; r.rotmask = M->rotmask[j]; r.type = M->type[j];
+    for (int i = 0; i < 3; i++) { r.cT[i] = 0; r.cR[i] = 0; }
+    r.pid_int = 0.0; r.pid_last = 0.0;
+}
+
+// F1: joint inputs -> force / torque on body t (SURVEY 8a-bis 'Joint input': a revolute applies +-u axis as a torque, a prismatic
+// +-u axis as a force at the joint's vertices; a FixedOrientation constraint takes no input), per-step invariants, solution guess
+HD void lp_forces(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M) {
+    if (t >= M->nb) return;
+    const double dt = M->dt;
+    const double* z = L + Y.Z + 13 * t;
+    double F[3] = {0, 0, 0}, tau[3] = {0, 0, 0}, Rb[9];
+    rotmat(z + 3, Rb);
+    for (int k = 0; k < M->inc_n[t]; k++) {
+        const int j = M->inc_j[t][k];
+        const double u = L[Y.UJ + j];
+        if (u == 0.0 || M->type[j] > 1) continue;
+        const double f[3] = {M->axis[j][0] * u, M->axis[j][1] * u, M->axis[j][2] * u};     // in the parent body's frame
+        if (M->inc_side[t][k] == 0) {         // body t is the joint's child
+            const int a = M->parent[j];
+            double Ra[9], fw[3], fb[3];
+            rotmat(a >= 0 ? L + Y.Z + 13 * a + 3 : QID_, Ra);
+            mv3(Ra, f, fw); mtv3(Rb, fw, fb);
+            if (M->type[j] == 1) { double c[3]; cross3(M->p2[j], fb, c); for (int i = 0; i < 3; i++) { F[i] += fw[i]; tau[i] += c[i]; } }
+            else for (int i = 0; i < 3; i++) tau[i] += fb[i];
+        } else {                              // body t is the joint's parent
+            if (M->type[j] == 1) {
+                double fw[3], cr[3];
+                mv3(Rb, f, fw); cross3(M->p1[j], f, cr);
+                for (int i = 0; i < 3; i++) { F[i] -= fw[i]; tau[i] -= cr[i]; }
+            } else for (int i = 0; i < 3; i++) tau[i] -= f[i];
+        }
+    }
+    const double* v1 = z + 7; const double* w1 = z + 10;
+    const double sq1 = sqrt(4.0 / (dt * dt) - (w1[0] * w1[0] + w1[1] * w1[1] + w1[2] * w1[2]));
+    double Jw1[3], c1[3];
+    mv3(r.J, w1, Jw1); cross3(w1, Jw1, c1);
+    for (int i = 0; i < 3; i++) {
+        r.cT[i] = r.m * (-v1[i] / dt + (i == 2 ? -M->g : 0.0)) - F[i];
+        r.cR[i] = -(sq1 * Jw1[i] - c1[i]) - 2.0 * tau[i];
+        L[Y.S + 6 * t + i] = v1[i]; L[Y.S + 6 * t + 3 + i] = w1[i];
+    }
+    L[Y.DTM + t] = dt / r.m;
+}
+
+// F2: constraint Jacobians of joint t at the current knot (force mapping G_k)
+HD void lp_knot_jac(int t, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M) {
+    if (t >= M->nj) return;
+    const int a = r.parent, b = r.childl;
+    const double X0[3] = {0, 0, 0};
+    const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
+    const double* zb = L + Y.Z + 13 * b;
+    double g[5];
+    joint_eval<true>(r, za ? za : X0, za ? za + 3 : QID_, zb, zb + 3, a >= 0, 1.0, 1.0, nullptr, nullptr, g, L + Y.GKA + BLK * t, L + Y.GKB + BLK * t);
+}
+
+// sum over the joints around body t of (its side of G_k)' y_j, y at offset oy (5 per joint)
+HD void lp_gk_t_apply(int t, const Lay& Y, const double* L, const MechDev* M, int oy, double* out) {
+    for (int c = 0; c < 6; c++) out[c] = 0.0;
+    for (int k = 0; k < M->inc_n[t]; k++) {
+        const int j = M->inc_j[t][k];
+        const double* gk = L + (M->inc_side[t][k] ? Y.GKA : Y.GKB) + BLK * j;
+        const double* y = L + oy + 5 * j;
+        for (int c = 0; c < 6; c++) out[c] += gk[c] * y[0] + gk[6 + c] * y[1] + gk[12 + c] * y[2] + gk[18 + c] * y[3] + gk[24 + c] * y[4];
+    }
+}
+// F3: C_b = sum G_k' lambda at the knot's multipliers
+HD void lp_force_map(int t, const Lay& Y, double* L, const MechDev* M) {
+    if (t >= M->nb) return;
+    double c[6];
+    lp_gk_t_apply(t, Y, L, M, Y.LAM, c);
+    for (int i = 0; i < 6; i++) { L[Y.C + 6 * t + i] = c[i]; L[Y.CD + 6 * t + i] = 0.0; }
+}
+
+// E2: joint t at the next knot: g and W = G_v D^-1 (JAC) or g only; returns |g_t|^2
+template <bool JAC>
+HD double lp_joint_eval(int t, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M) {
+    if (t >= M->nj) return 0.0;
+    const int a = r.parent, b = r.childl;
+    const double dt = M->dt;
+    const double X0[3] = {0, 0, 0};
+    const double* pa = (a >= 0) ? L + Y.XQ + 7 * a : nullptr;
+    const double* pb = L + Y.XQ + 7 * b;
+    double g[5];
+    joint_eval<JAC>(r, pa ? pa : X0, pa ? pa + 3 : QID_, pb, pb + 3, a >= 0, (a >= 0) ? dt * L[Y.DTM + a] : 0.0, dt * L[Y.DTM + b],
+                    (a >= 0) ? L + Y.NB + 9 * a : nullptr, L + Y.NB + 9 * b, g, L + Y.GVA + BLK * t, L + Y.GVB + BLK * t);
+    double acc = 0.0;
+    for (int i = 0; i < 5; i++) { L[Y.G + 5 * t + i] = g[i]; acc += g[i] * g[i]; }
+    return acc;
+}
+
+// S: row `row` of the dense system [S | r] (lane = row; joint i = row / 5):
+//   S[(i,ri)][(j,rj)] = sum over the bodies joints i and j share of  W_side(i)[ri] . Gk_side(j)[rj]
+//   r[(i,ri)] = g_i[ri] - W_b(i)[ri] . d_{jb(i)} - W_a(i)[ri] . d_{ja(i)}
+HD void lp_schur_row(int row, const Lay& Y, double* L, const MechDev* M) {
+    const int nj = M->nj, mr = 5 * nj;
+    if (row >= mr) return;
+    const int i = row / 5, ri = row - 5 * i;
+    const int ia = M->parent[i], ib = M->jchild[i];
+    double wa[6], wb[6];
+    for (int c = 0; c < 6; c++) { wa[c] = L[Y.GVA + BLK * i + 6 * ri + c]; wb[c] = L[Y.GVB + BLK * i + 6 * ri + c]; }
+    double* out = L + Y.SS + row * loop_row_stride(nj);
+    for (int j = 0; j < nj; j++) {
+        const int ja = M->parent[j], jb = M->jchild[j];
+        const bool bb = ib == jb, ba = ib == ja, ab = ia >= 0 && ia == jb, aa = ia >= 0 && ia == ja;
+        for (int rj = 0; rj < 5; rj++) {
+            const double* ka = L + Y.GKA + BLK * j + 6 * rj;
+            const double* kb = L + Y.GKB + BLK * j + 6 * rj;
+            double s = 0.0;
+            if (bb) s += dot6(wb, kb);
+            if (ba) s += dot6(wb, ka);
+            if (ab) s += dot6(wa, kb);
+            if (aa) s += dot6(wa, ka);
+            out[5 * j + rj] = s;
+        }
+    }
+    double rr = L[Y.G + 5 * i + ri] - dot6(wb, L + Y.D + 6 * ib);
+    if (ia >= 0) rr -= dot6(wa, L + Y.D + 6 * ia);
+    out[mr] = rr;
+}
+
+// ---- dense solve with complete pivoting, one pivot step at a time (the caller separates the sub-steps by wave barriers).
+// Lane = row.  `perm` (L[Y.R + c], stored as doubles) maps the working column c to the multiplier it stands for.
+// search: this lane's largest |a| over the remaining columns (value, column); the caller takes the wavefront's maximum
+HD void lp_pivot_search(int row, int k, int mr, int stride, const Lay& Y, const double* L, double* best, int* bcol) {
+    *best = -1.0; *bcol = k;
+    if (row < k || row >= mr) return;
+    const double* a = L + Y.SS + row * stride;
+    for (int c = k; c < mr; c++) { const double v = fabs(a[c]); if (v > *best) { *best = v; *bcol = c; } }
+}
+// swap rows k <-> pr (lanes = columns here) and columns k <-> pc (lanes = rows); two calls, a barrier between them
+HD void lp_swap_rows(int t, int k, int pr, int mr, int stride, const Lay& Y, double* L) {
+    if (pr == k || t > mr) return;
+    double* a = L + Y.SS + k * stride + t; double* b = L + Y.SS + pr * stride + t;
+    const double x = *a; *a = *b; *b = x;
+}
+HD void lp_swap_cols(int t, int k, int pc, int mr, int stride, const Lay& Y, double* L) {
+    if (pc == k) return;
+    if (t < mr) { double* a = L + Y.SS + t * stride; const double x = a[k]; a[k] = a[pc]; a[pc] = x; }
+    if (t == mr) { const double x = L[Y.R + k]; L[Y.R + k] = L[Y.R + pc]; L[Y.R + pc] = x; }
+}
+// eliminate column k below the pivot (lane = row > k)
+HD void lp_eliminate(int row, int k, int mr, int stride, const Lay& Y, double* L) {
+    if (row <= k || row >= mr) return;
+    const double* p = L + Y.SS + k * stride;
+    double* a = L + Y.SS + row * stride;
+    const double f = a[k] / p[k];
+    if (f == 0.0) return;
+    for (int c = k + 1; c <= mr; c++) a[c] -= f * p[c];
+    a[k] = 0.0;
+}
+// back substitution step k (rank-1 .. 0): x_k = r_k / a_kk ; rows above subtract a_ik x_k from their right-hand side
+HD void lp_back_step(int row, int k, int mr, int stride, const Lay& Y, double* L) {
+    if (row > k || row >= mr) return;
+    const double* p = L + Y.SS + k * stride;
+    const double xk = p[mr] / p[k];
+    double* a = L + Y.SS + row * stride;
+    if (row < k) a[mr] -= a[k] * xk;
+}
+// scatter: dl[perm[c]] = x_c for c < rank (x_c = r_c / a_cc after the back substitution), 0 beyond
+HD void lp_scatter(int c, int rank, int mr, int stride, const Lay& Y, double* L) {
+    if (c >= mr) return;
+    const double* a = L + Y.SS + c * stride;
+    const int dst = (int)L[Y.R + c];
+    L[Y.DL + dst] = c < rank ? a[mr] / a[c] : 0.0;
+}
+
+// body solve: cd = sum G_k' dl ; ds = D^-1 (d + cd)
+HD void lp_body_solve(int t, const Lay& Y, double* L, const MechDev* M) {
+    if (t >= M->nb) return;
+    double cd[6], tv[6], Di[9];
+    lp_gk_t_apply(t, Y, L, M, Y.DL, cd);
+    for (int c = 0; c < 6; c++) tv[c] = L[Y.D + 6 * t + c] + cd[c];
+    for (int i = 0; i < 9; i++) Di[i] = L[Y.DINV + 9 * t + i];
+    const double dtm = L[Y.DTM + t];
+    for (int c = 0; c < 3; c++) {
+        L[Y.DS + 6 * t + c] = tv[c] * dtm;
+        L[Y.DS + 6 * t + 3 + c] = Di[3 * c] * tv[3] + Di[3 * c + 1] * tv[4] + Di[3 * c + 2] * tv[5];
+    }
+    for (int c = 0; c < 6; c++) L[Y.CD + 6 * t + c] = cd[c];
+}
+// trial point st = s - alpha ds (body t), lt = lam - alpha dl (joint t); returns the lane's share of ||(ds, dl)||^2
+HD double lp_trial(int t, const Lay& Y, double* L, const MechDev* M, double alpha) {
+    double acc = 0.0;
+    if (t < M->nb)
+        for (int i = 0; i < 6; i++) { const double dv = L[Y.DS + 6 * t + i]; L[Y.ST + 6 * t + i] = L[Y.S + 6 * t + i] - alpha * dv; acc += dv * dv; }
+    if (t < M->nj)
+        for (int i = 0; i < 5; i++) { const double ev = L[Y.DL + 5 * t + i]; L[Y.LT + 5 * t + i] = L[Y.LAM + 5 * t + i] - alpha * ev; acc += ev * ev; }
+    return acc;
+}
+// accept the trial point: s, lambda <- trial ; C -= alpha CD
+HD void lp_accept(int t, const Lay& Y, double* L, const MechDev* M, double alpha) {
+    if (t < M->nb)
+        for (int i = 0; i < 6; i++) { L[Y.S + 6 * t + i] = L[Y.ST + 6 * t + i]; L[Y.C + 6 * t + i] -= alpha * L[Y.CD + 6 * t + i]; L[Y.CD + 6 * t + i] = 0.0; }
+    if (t < M->nj)
+        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = L[Y.LT + 5 * t + i];
+}
+
+}  // namespace cclqr

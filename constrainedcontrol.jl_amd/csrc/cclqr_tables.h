@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/cclqr.h"
 #include "cclqr_internal.h"
+#include "cclqr_loop.h"
 #include <math.h>
 #include <string.h>
 #include <string>
@@ -26,12 +27,85 @@ static inline void orth_rows(const double* a, double* V12) {
 }
 
 
+// joint constants that do not depend on the link order: unit axis, vertices, conj(qoffset), row selectors and row kinds.
+// Revolute = Translational3 + Rotational2, Prismatic = Translational2 + Rotational3, FixedOrientation = Rotational3 padded with two
+// null rows in front (the row layout of a prismatic joint with nothing selected translationally)
+static inline int fill_joint_consts(const cclqr_mech_desc* d, int j, MechDev& H, int l, std::string& err) {
+    double ax[3] = {d->axis[3 * j], d->axis[3 * j + 1], d->axis[3 * j + 2]};
+    const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (n == 0.0) { err = "zero joint axis"; return CCLQR_EINVAL; }
+    for (int i = 0; i < 3; i++) { ax[i] /= n; H.axis[l][i] = ax[i]; H.p1[l][i] = d->p1[3 * j + i]; H.p2[l][i] = d->p2[3 * j + i]; }
+    H.qoc[l][0] = d->qoff[4 * j];
+    for (int i = 1; i < 4; i++) H.qoc[l][i] = -d->qoff[4 * j + i];
+    double V12[6];
+    orth_rows(ax, V12);
+    const int nt = (d->type[j] == CCLQR_REVOLUTE) ? 3 : 2;
+    H.rotmask[l] = 0;
+    for (int r = 0; r < 5; r++) {
+        const bool rot = r >= nt;
+        const int q = rot ? r - nt : r, nrows = rot ? 5 - nt : nt;
+        if (rot) H.rotmask[l] |= 1 << r;
+        for (int i = 0; i < 3; i++) H.sel[l][r][i] = (nrows == 3) ? (i == q ? 1.0 : 0.0) : V12[3 * q + i];
+        if (d->type[j] == CCLQR_FIXED_ORIENTATION && !rot)
+            for (int i = 0; i < 3; i++) H.sel[l][r][i] = 0.0;
+    }
+    H.type[l] = d->type[j];
+    return CCLQR_OK;
+}
+
+// Mechanism whose constraint graph has cycles (or a FixedOrientation constraint): bodies and joints keep the caller's order
+static inline int build_loop_tables(const cclqr_mech_desc* d, cclqr_mech* m, std::string& err) {
+    const int nb = d->nb, nj = d->ne;
+    if (nb > CCLQR_LOOP_MAXB || nj > CCLQR_LOOP_MAXJ) { err = "closed-loop mechanisms: up to 8 bodies and 12 joints"; return CCLQR_EUNSUPPORTED; }
+    memset(&m->host, 0, sizeof(MechDev));
+    m->nb = nb; m->nj = nj;
+    MechDev& H = m->host;
+    H.nb = nb; H.nj = nj; H.loop = 1; H.dt = d->dt; H.g = d->g;
+    for (int b = 0; b < nb; b++) {
+        m->link_of_body[b] = b; H.perm[b] = b;
+        H.m[b] = d->mass[b];
+        if (!(H.m[b] > 0)) { err = "non-positive mass"; return CCLQR_EINVAL; }
+        for (int i = 0; i < 9; i++) H.J[b][i] = d->inertia[9 * b + i];
+    }
+    std::vector<int> seen(nb, 0);
+    for (int j = 0; j < nj; j++) {
+        const int a = d->parent[j], b = d->child[j];
+        if (b < 0 || b >= nb || a < -1 || a >= nb || a == b) { err = "joint references a body out of range"; return CCLQR_EINVAL; }
+        if (d->type[j] < CCLQR_REVOLUTE || d->type[j] > CCLQR_FIXED_ORIENTATION) { err = "unknown joint type"; return CCLQR_EINVAL; }
+        m->link_of_joint[j] = j; H.jperm[j] = j;
+        H.parent[j] = a; H.jchild[j] = b; H.childl[j] = -1;
+        int rc = fill_joint_consts(d, j, H, j, err);
+        if (rc != CCLQR_OK) return rc;
+        for (int side = 0; side < 2; side++) {
+            const int body = side ? a : b;
+            if (body < 0) continue;
+            if (H.inc_n[body] >= CCLQR_MAXI) { err = "more than 8 joints around one body"; return CCLQR_EUNSUPPORTED; }
+            H.inc_j[body][H.inc_n[body]] = j; H.inc_side[body][H.inc_n[body]] = side; H.inc_n[body]++;
+            seen[body] = 1;
+        }
+    }
+    for (int b = 0; b < nb; b++)
+        if (!seen[b]) { err = "a body without any joint"; return CCLQR_EINVAL; }
+    return CCLQR_OK;
+}
+
 // fills m->host, m->nb, m->link_of_*; returns CCLQR_OK or an error code with a message in err
 static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std::string& err) {
     const int nb = d->nb;
-    if (nb < 1 || d->ne != nb) { err = "need ne == nb >= 1 (tree with one 1-DoF joint per body)"; return CCLQR_EINVAL; }
-    if (nb > CCLQR_MAXL) { err = "more than 32 bodies"; return CCLQR_EUNSUPPORTED; }
+    if (nb < 1 || d->ne < nb) { err = "need ne >= nb >= 1 (every body hangs off at least one joint)"; return CCLQR_EINVAL; }
     if (!(d->dt > 0)) { err = "dt must be positive"; return CCLQR_EINVAL; }
+    {   // closed loops: more joints than bodies, a body that is the child of two joints, or a FixedOrientation constraint
+        bool loop = d->ne != nb;
+        std::vector<int> cnt(nb > 0 ? nb : 1, 0);
+        for (int j = 0; j < d->ne && !loop; j++) {
+            const int b = d->child[j];
+            if (b >= 0 && b < nb && ++cnt[b] > 1) loop = true;
+            if (d->type[j] == CCLQR_FIXED_ORIENTATION) loop = true;
+        }
+        if (loop) return build_loop_tables(d, m, err);
+    }
+    m->nj = nb;
+    if (nb > CCLQR_MAXL) { err = "more than 32 bodies"; return CCLQR_EUNSUPPORTED; }
     std::vector<int> pj(nb, -1), nchild(nb, 0);
     for (int j = 0; j < nb; j++) {
         int a = d->parent[j], b = d->child[j];
@@ -169,7 +243,8 @@ struct CtrlHostTables {
 };
 static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* d, CtrlHostTables& T, std::string& err) {
     const int nb = m->nb, mx = 12 * nb;
-    if (d->mu < 0 || d->mu > nb) { err = "Missmatched length for constraints"; return CCLQR_EINVAL; }
+    const int nj = m->nj;
+    if (d->mu < 0 || d->mu > nj) { err = "Missmatched length for constraints"; return CCLQR_EINVAL; }
     if (d->nsp < 1 || !d->zd) { err = "Missmatched length for bodies"; return CCLQR_EINVAL; }
     if (d->K && d->nK < 1) { err = "gain table without entries"; return CCLQR_EINVAL; }
     CtrlDev& H = T.H;
@@ -177,9 +252,10 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
     H.mu = d->mu; H.nK = d->K ? d->nK : 0; H.N = d->N; H.nsp = d->nsp; H.noise_scale = d->noise_scale;
     for (int i = 0; i < d->mu; i++) {
         int j = d->ctrl_joint[i];
-        if (j < 0 || j >= nb) { err = "controlled joint out of range"; return CCLQR_EINVAL; }
+        if (j < 0 || j >= nj) { err = "controlled joint out of range"; return CCLQR_EINVAL; }
         H.cj[i] = m->link_of_joint[j];
     }
+    if (m->host.loop && (d->fric || d->npid > 0 || d->noise_scale != 0.0)) { err = "closed-loop mechanisms take the plain LQR law only (no friction, noise or PID)"; return CCLQR_EUNSUPPORTED; }
     if (d->fric)
         for (int j = 0; j < nb; j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
     H.noise_philox = d->noise_philox ? 1 : 0;

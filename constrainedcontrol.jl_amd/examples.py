@@ -2,7 +2,7 @@
 Every number below is read from the cited script; nothing else of the scripts is reproduced."""
 import numpy as np
 
-from .mechanism import (Box, EqualityConstraint, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, setJointPosition, setPosition)
+from .mechanism import (Box, EqualityConstraint, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, getid, setJointPosition, setPosition)
 
 EX = np.array([1.0, 0.0, 0.0])
 EY = np.array([0.0, 1.0, 0.0])
@@ -205,3 +205,33 @@ def tree_mechanism(parents, seed=0, g=-9.81, prismatic=()):
     for e in joints:                                    # bodies are listed parents-first, so this places root to leaf
         setJointPosition(mech, e, rng.uniform(-0.6, 0.6))
     return dict(mech=mech, bodies=bodies, joints=joints)
+
+
+def deltabot():
+    """examples/lqr_deltabot.jl:7-53: a planar five-bar mechanism with a platform held level -- five bodies, seven equality
+    constraints (two floor revolutes and a FixedOrientation to the origin, two knees, two platform revolutes: 33 constraint rows on 30
+    body coordinates, i.e. closed loops), placed at the script's pose; Fτd = +-6.7879484 on the platform joints holds it at rest.
+    Returns the mechanism, the controlled constraint ids (platl, platr) and the holding inputs."""
+    from .mechanism import FixedOrientation
+    L = 1.0
+    ex = [1.0, 0.0, 0.0]
+    pll, pul, pp = np.array([0, 0, L / 2]), np.array([0, 0, L / 4]), np.array([0, 0, L / 4 * np.sqrt(2)])     # :11-16
+    origin = Origin()
+    lowerlegl, lowerlegr = Box(0.1, 0.1, L, L, "lowerlegl"), Box(0.1, 0.1, L, L, "lowerlegr")                  # :18-19
+    upperlegl, upperlegr = Box(0.1, 0.1, L / 2, L / 2, "upperlegl"), Box(0.1, 0.1, L / 2, L / 2, "upperlegr")  # :20-21
+    platform = Box(0.1, 0.1, L / 2 * np.sqrt(2), L / 2 * np.sqrt(2), "platform")                               # :22
+    platl = EqualityConstraint(Revolute(platform, upperlegl, ex, p1=pp, p2=pul), "platl")                      # :28
+    platr = EqualityConstraint(Revolute(platform, upperlegr, ex, p1=-pp, p2=pul), "platr")                     # :29
+    floorl = EqualityConstraint(Revolute(origin, lowerlegl, ex, p2=-pll), "floorl")                             # :25 (floorlr)
+    floorr = EqualityConstraint(Revolute(origin, lowerlegr, ex, p2=-pll), "floorr")
+    flooro = EqualityConstraint(FixedOrientation(origin, platform, qoffset=RotX(np.pi / 2)), "flooro")
+    kneel = EqualityConstraint(Revolute(lowerlegl, upperlegl, ex, p1=pll, p2=-pul), "kneel")                    # :26
+    kneer = EqualityConstraint(Revolute(lowerlegr, upperlegr, ex, p1=pll, p2=-pul), "kneer")                    # :27
+    links = [lowerlegl, lowerlegr, upperlegl, upperlegr, platform]                                               # :31
+    mech = Mechanism(origin, links, [platl, platr, floorl, floorr, flooro, kneel, kneer], g=-9.81, dt=0.01)      # :32-36
+    setPosition(origin, lowerlegl, p2=-pll, Δq=RotX(np.pi / 4))                                                  # :37
+    setPosition(origin, lowerlegr, p2=-pll, Δq=RotX(-np.pi / 4))                                                 # :38
+    setPosition(lowerlegl, upperlegl, p1=pll, p2=-pul, Δq=RotX(-np.pi / 2))                                      # :39
+    setPosition(lowerlegr, upperlegr, p1=pll, p2=-pul, Δq=RotX(np.pi / 2))                                       # :40
+    setPosition(upperlegl, platform, p1=pul, p2=pp, Δq=RotX(3 * np.pi / 4))                                      # :41
+    return {"mech": mech, "eqcids": [getid(platl), getid(platr)], "Fd": np.array([6.7879484, -6.7879484])}      # :53

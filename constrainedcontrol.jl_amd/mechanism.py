@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-REVOLUTE, PRISMATIC = 0, 1
+REVOLUTE, PRISMATIC, FIXED_ORIENTATION = 0, 1, 2
 
 
 # ------------------------------------------------------------------ quaternions (scalar first)
@@ -119,6 +119,12 @@ def Prismatic(body1, body2, axis, p1=None, p2=None, qoffset=None):
     return _Joint(PRISMATIC, body1, body2, axis, p1, p2, qoffset)
 
 
+def FixedOrientation(body1, body2, qoffset=None):
+    """FixedOrientation(body1, body2; qoffset) — the three rotational rows only (examples/lqr_deltabot.jl:25); makes the
+    mechanism a closed-loop one for the device (cclqr.h CCLQR_FIXED_ORIENTATION)"""
+    return _Joint(FIXED_ORIENTATION, body1, body2, (1.0, 0.0, 0.0), None, None, qoffset)
+
+
 class EqualityConstraint:
     def __init__(self, joint, name=""):
         self.joint = joint
@@ -128,7 +134,7 @@ class EqualityConstraint:
         self.name = name
 
     def __len__(self):
-        return 5  # Revolute and Prismatic both remove 5 DoF
+        return 3 if self.joint.kind == FIXED_ORIENTATION else 5  # Revolute and Prismatic both remove 5 DoF
 
 
 def getid(c):
@@ -206,13 +212,13 @@ class Mechanism:
 
     def tables(self):
         nb, ne = len(self.bodies), len(self.eqconstraints)
-        if ne != nb:
-            raise ValueError("only tree mechanisms with one 1-DoF joint per body are supported (Nb=%d, Ne=%d); "
-                             "closed loops (lqr_deltabot.jl) are out of scope" % (nb, ne))
         parent = [e.joint.body1.id - 1 for e in self.eqconstraints]
         child = [e.joint.body2.id - 1 for e in self.eqconstraints]
-        if sorted(child) != list(range(nb)):
-            raise ValueError("every body must be the child of exactly one joint")
+        # closed loops (examples/lqr_deltabot.jl:25-33): more joints than bodies, a body that is the child of two joints, or a
+        # FixedOrientation constraint.  The device rolls them out (rollout_loop.hip); LQR construction on them is out of scope.
+        self.has_loops = ne != nb or sorted(child) != list(range(nb)) or any(e.joint.kind == FIXED_ORIENTATION for e in self.eqconstraints)
+        if ne < nb or not set(range(nb)) <= set(child) | {p for p in parent if p >= 0}:
+            raise ValueError("every body must hang off at least one joint (Nb=%d, Ne=%d)" % (nb, ne))
         return MechTables(nb, ne, self.Δt, self.g, [b.m for b in self.bodies], [b.J.reshape(9) for b in self.bodies], parent, child,
                           [e.joint.kind for e in self.eqconstraints], [e.joint.p1 for e in self.eqconstraints],
                           [e.joint.p2 for e in self.eqconstraints], [e.joint.axis for e in self.eqconstraints],

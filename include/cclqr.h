@@ -27,13 +27,17 @@ extern "C" {
 #define CCLQR_ESINGULAR -2    /* G*Bl or M singular        (LAPACK exception from lqr.jl:151,160) */
 #define CCLQR_ENOCONV -3      /* soft: Newton / Riccati did not converge (lqr.jl:41 `@info`) */
 #define CCLQR_EHIP -4         /* HIP runtime error; cclqr_last_error() has the text */
-#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (closed loops, > 4 child joints on a body, nb > 32) */
+#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (LQR construction on closed loops, > 4 child joints on a body, nb > 32) */
 
 #define CCLQR_REVOLUTE 0      /* EqualityConstraint(Revolute(a, b, axis; p1, p2, qoffset)),  examples/lqr_cartpole.jl:26 */
 #define CCLQR_PRISMATIC 1     /* EqualityConstraint(Prismatic(a, b, axis; p1, p2, qoffset)), examples/lqr_cartpole.jl:25 */
+#define CCLQR_FIXED_ORIENTATION 2 /* EqualityConstraint(FixedOrientation(a, b; qoffset)), examples/lqr_deltabot.jl:25 (closed-loop mechanisms) */
 
 /* Mechanism(origin, bodies, eqconstraints; g, Δt) -- examples/lqr_cartpole.jl:32.
- * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints. */
+ * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
+ * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
+ * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (plain LQR law, one instance per wavefront, multipliers lam
+ * [n_inst][5*ne]); cclqr_linearize / cclqr_riccati_tracking return CCLQR_EUNSUPPORTED for them. */
 typedef struct {
     int32_t nb, ne;
     double dt, g;          /* mechanism.Δt (lqr.jl:65), gravity along z */

@@ -1,0 +1,149 @@
+// emu_loop.cpp -- TEST INFRASTRUCTURE ONLY (never linked into libcclqr.so).
+// Runs the closed-loop rollout kernel's __host__ __device__ phase functions (csrc/cclqr_loop.h and the body phases of
+// csrc/cclqr_dev.h it shares with the tree kernel) serially on the CPU, lane by lane, in the phase order of csrc/rollout_loop.hip,
+// so that the dense singular solve, the incidence bookkeeping and the LDS layout can be checked against oracle/loops.py without a
+// GPU.  The LDS image has exactly the kernel's size (an out-of-range offset is an out-of-bounds access for a sanitizer build).
+#include "../../constrainedcontrol.jl_amd/csrc/cclqr_tables.h"
+#include "../../constrainedcontrol.jl_amd/csrc/cclqr_loop.h"
+#include <math.h>
+#include <string>
+#include <vector>
+
+using namespace cclqr;
+
+namespace {
+struct LoopInst {
+    const MechDev* M;
+    Lay Y;
+    std::vector<double> lds;
+    double* L;
+    std::vector<LaneRegs> r;
+};
+
+template <bool JAC>
+double loop_eval(LoopInst& I, int s_off, double alpha) {
+    const MechDev* M = I.M;
+    double acc = 0.0;
+    for (int t = 0; t < 64; t++) acc += ph_body_eval<JAC>(t, M->nb, I.Y, I.L, I.r[t], M->dt, s_off, alpha);
+    for (int t = 0; t < 64; t++) acc += lp_joint_eval<JAC>(t, I.Y, I.L, I.r[t], M);
+    return sqrt(acc);
+}
+
+void loop_solve(LoopInst& I) {
+    const MechDev* M = I.M;
+    const Lay& Y = I.Y;
+    double* L = I.L;
+    const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
+    for (int t = 0; t < 64; t++) lp_schur_row(t, Y, L, M);
+    for (int t = 0; t < mr; t++) L[Y.R + t] = (double)t;
+    int rank = mr;
+    double first = 0.0;
+    for (int k = 0; k < mr; k++) {
+        double best = -1.0; int brow = 0, bcol = 0;
+        for (int t = 0; t < 64; t++) {     // the wavefront arg-max: ties to the smaller (row, column)
+            double v; int c;
+            lp_pivot_search(t, k, mr, stride, Y, L, &v, &c);
+            if (v > best) { best = v; brow = t; bcol = c; }
+        }
+        if (k == 0) first = best;
+        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) { rank = k; break; }
+        for (int t = 0; t < 64; t++) lp_swap_rows(t, k, brow, mr, stride, Y, L);
+        for (int t = 0; t < 64; t++) lp_swap_cols(t, k, bcol, mr, stride, Y, L);
+        for (int t = 0; t < 64; t++) lp_eliminate(t, k, mr, stride, Y, L);
+    }
+    for (int k = rank - 1; k >= 0; k--) {
+        // lanes run in lock step on the GPU (every lane reads the pivot row's right-hand side before row k itself is left alone): row
+        // k is not written in step k, so a serial sweep is equivalent
+        for (int t = 0; t < 64; t++) lp_back_step(t, k, mr, stride, Y, L);
+    }
+    for (int t = 0; t < 64; t++) lp_scatter(t, rank, mr, stride, Y, L);
+}
+}  // namespace
+
+extern "C" int emu_loop_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd, int64_t n_inst, int steps, int k0, const double* z0,
+                                double* lam, double* traj, double* zT, int* status) {
+    cclqr_mech m;
+    std::string err;
+    int rc = build_mech_tables(md, &m, err);
+    if (rc) return rc;
+    if (!m.host.loop) return CCLQR_EUNSUPPORTED;
+    CtrlHostTables Tb;
+    rc = build_ctrl_tables(&m, cd, Tb, err);
+    if (rc) return rc;
+    Tb.H.K = Tb.K.empty() ? nullptr : Tb.K.data();
+    Tb.H.zd = Tb.zd.data();
+    Tb.H.Fd = Tb.Fd.empty() ? nullptr : Tb.Fd.data();
+    const MechDev* M = &m.host;
+    const CtrlDev* C = &Tb.H;
+    const int nb = M->nb, nj = M->nj, nz = 13 * nb;
+    LoopInst I;
+    I.M = M;
+    I.Y = make_loop_layout(nb, nj);
+    I.lds.assign(I.Y.total, 0.0);
+    I.L = I.lds.data();
+    I.r.resize(64);
+    const Lay& Y = I.Y;
+    double* L = I.L;
+    for (int t = 0; t < 64; t++) loop_load_consts(I.r[t], M, t);
+    for (int64_t inst = 0; inst < n_inst; inst++) {
+        for (int e = 0; e < Y.total; e++) L[e] = 0.0;
+        for (int e = 0; e < nz; e++) L[Y.Z + e] = z0[inst * nz + e];
+        if (lam && k0 > 1) for (int e = 0; e < 5 * nj; e++) L[Y.LAM + e] = lam[inst * 5 * nj + e];
+        int worst = 0;
+        bool bad = false, dead = false;
+        for (int kk = 0; kk < steps; kk++) {
+            const int k = k0 + kk;
+            if (traj) for (int e = 0; e < nz; e++) traj[((size_t)inst * steps + kk) * nz + e] = L[Y.Z + e];
+            const bool gate = (C->N <= 0) || (k < C->N);
+            const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
+            const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
+            if (gate) for (int t = 0; t < 64; t++) ph_control_error(t, nb, Y, L, I.r[t], C, C->zd + inst * C->zd_stride + (size_t)ksp * nz);
+            for (int t = 0; t < nj; t++) L[Y.UJ + t] = 0.0;
+            if (gate)
+                for (int i = 0; i < C->mu; i++) {
+                    double s = 0.0;
+                    if (C->K) for (int t = 0; t < 64; t++) s += ph_gain_partial(t, 64, nb, Y, L, C->K + inst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb);
+                    L[Y.UJ + C->cj[i]] += (C->Fd ? C->Fd[inst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
+                }
+            for (int t = 0; t < 64; t++) lp_forces(t, Y, L, I.r[t], M);
+            for (int t = 0; t < 64; t++) lp_knot_jac(t, Y, L, I.r[t], M);
+            for (int t = 0; t < 64; t++) lp_force_map(t, Y, L, M);
+            bool done = dead, failed = false;
+            int its = 0;
+            double normf0 = loop_eval<true>(I, Y.S, 0.0);
+            for (int iter = 1; iter <= 100 && !done; iter++) {
+                loop_solve(I);
+                for (int t = 0; t < 64; t++) lp_body_solve(t, Y, L, M);
+                double alpha = 1.0, normf1 = 0.0, pd = 0.0;
+                for (int t = 0; t < 64; t++) pd += lp_trial(t, Y, L, M, alpha);
+                const double nd = sqrt(pd);
+                for (int ls = 0; ls <= 10; ls++) {
+                    normf1 = loop_eval<false>(I, Y.ST, alpha);
+                    if (!(normf1 > normf0) || ls == 10) break;
+                    alpha *= 0.5;
+                    for (int t = 0; t < 64; t++) lp_trial(t, Y, L, M, alpha);
+                }
+                for (int t = 0; t < 64; t++) lp_accept(t, Y, L, M, alpha);
+                its = iter;
+                if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
+                if (!(normf1 < 1e300)) { done = true; failed = true; }
+                if (!done) normf0 = loop_eval<true>(I, Y.S, 0.0);
+            }
+            if (!dead) {
+                const bool conv = done && !failed;
+                if (!conv) bad = true;
+                if (its > worst) worst = its;
+                if (!conv && its < 100) {
+                    dead = true;
+                    for (int b = 0; b < nb; b++) for (int i = 0; i < 6; i++) L[Y.Z + 13 * b + 7 + i] = 0.0;
+                } else {
+                    for (int t = 0; t < 64; t++) ph_update(t, nb, Y, L);
+                }
+            }
+        }
+        for (int e = 0; e < nz; e++) zT[inst * nz + e] = L[Y.Z + e];
+        if (lam) for (int e = 0; e < 5 * nj; e++) lam[inst * 5 * nj + e] = L[Y.LAM + e];
+        if (status) status[inst] = bad ? -worst : worst;
+    }
+    return CCLQR_OK;
+}

@@ -271,3 +271,66 @@ def test_chain_emulator_under_address_and_undefined_sanitizers(tmp_path):
         assert r.returncode == 0 and "rc 0 status" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
         status = int(r.stdout.split("status")[1].split()[0])
         assert status > 0
+
+
+def emu_loop_rollout(emu, orc, t, ctrl, z0, steps):
+    m = orc.mech_desc(t)
+    z0 = np.ascontiguousarray(z0, dtype=np.float64).reshape(-1, t.nb, 13)
+    n = z0.shape[0]
+    traj, zT, st, lam = np.zeros((n, steps, t.nb, 13)), np.zeros_like(z0), np.zeros(n, dtype=np.int32), np.zeros((n, 5 * t.ne))
+    rc = emu.emu_loop_rollout(C.byref(m.desc), C.byref(ctrl.desc), C.c_int64(n), C.c_int(steps), C.c_int(1), z0.ctypes.data_as(dp), lam.ctypes.data_as(dp),
+                              traj.ctypes.data_as(dp), zT.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0
+    return zT, traj, st
+
+
+def loop_feedback_reference(lm, z, Fd, K, zd, steps):
+    """oracle side of a closed-loop rollout: u = Fd - K dz (lqr.jl:92-111, error order x, v, q~, w per body) on the controlled joints
+    0, 1 of oracle/loops.py's deltabot, stepped by its dense-KKT minimum-norm Newton"""
+    from oracle import loops
+    traj, lam = [], np.zeros(lm.nrows)
+    for _ in range(steps):
+        traj.append(z.copy())
+        u = np.zeros(len(lm.joints))
+        if K is None:
+            u[:2] = Fd
+        else:
+            dz = np.zeros((lm.nb, 12))
+            for b in range(lm.nb):
+                qe = loops.qmul(np.concatenate([[zd[b, 3]], -zd[b, 4:7]]), z[b, 3:7])
+                dz[b] = np.concatenate([z[b, 0:3] - zd[b, 0:3], z[b, 7:10] - zd[b, 7:10], qe[1:], z[b, 10:13] - zd[b, 10:13]])
+            u[:2] = Fd - K @ dz.ravel()
+        z, lam, _ = lm.step(z, lam, u)
+    return np.array(traj), z
+
+
+def test_emulated_closed_loop_deltabot(cclqr, orc, emu):
+    """examples/lqr_deltabot.jl:25-53 on the closed-loop kernel's phase functions (csrc/cclqr_loop.h): the reference's holding torque
+    keeps the script's pose at rest; with 80 % of it, and with a feedback law on top, the trajectory equals the oracle's dense-KKT
+    minimum-norm solution (oracle/loops.py) although the device solves the singular Schur complement by rank-truncated pivoting --
+    velocities and poses are unique, multipliers are not"""
+    from oracle import loops
+    ex = cclqr.examples.deltabot()
+    mech = ex["mech"]
+    t = mech.tables()
+    assert mech.has_loops and (t.nb, t.ne) == (5, 7)
+    cj = [mech.joint_index(e) for e in ex["eqcids"]]
+    lm, z, u = loops.deltabot()
+    z0 = mech.state()
+    assert np.abs(z0 - z).max() == 0.0 and cj == [0, 1]
+    zd = z0[None].copy()
+    hold = orc.ctrl_desc(t.nb, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2))
+    zT, _, st = emu_loop_rollout(emu, orc, t, hold, z0, 50)
+    assert st[0] > 0 and np.abs(zT[0] - z0).max() < 1e-6            # 6.7879484 is the torque to eight digits: at rest to 1e-6
+    steps = 25
+    weak = orc.ctrl_desc(t.nb, cj, K=None, N=0, zd=zd, Fd=0.8 * ex["Fd"].reshape(1, 2))
+    zT, traj, st = emu_loop_rollout(emu, orc, t, weak, z0, steps)
+    ref, zref = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], None, zd[0], steps)
+    assert st[0] > 0 and np.abs(zT[0] - z0).max() > 0.5             # it falls a long way
+    assert np.abs(traj[0] - ref).max() < 1e-10 and np.abs(zT[0] - zref).max() < 1e-10
+    rng = np.random.default_rng(3)
+    K = rng.normal(size=(1, 2, 12 * t.nb)) * 2.0
+    fb = orc.ctrl_desc(t.nb, cj, K=K, N=0, zd=zd, Fd=0.8 * ex["Fd"].reshape(1, 2))
+    zT, traj, st = emu_loop_rollout(emu, orc, t, fb, z0, steps)
+    ref, zref = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], K[0], zd[0], steps)
+    assert st[0] > 0 and np.abs(traj[0] - ref).max() < 1e-9 and np.abs(zT[0] - zref).max() < 1e-9

@@ -276,6 +276,51 @@ def test_per_instance_controller_tables(cclqr, orc):
             capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=20)
 
 
+def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
+    """examples/lqr_deltabot.jl:25-53 through the C-ABI (`rollout_loop_kernel`, csrc/rollout_loop.hip): 33 constraint rows on 30 body
+    coordinates.  (i) the reference's own number: Fτd = +-6.7879484 on the platform joints holds the script's pose at rest; (ii) with
+    80 % of it, open loop and with a feedback law u = Fτd - K dz on top, every instance's trajectory equals the oracle's dense-KKT
+    minimum-norm solution (oracle/loops.py) to 1e-9; (iii) the batch is bitwise independent of the instance's position; (iv) LQR
+    construction on the loop mechanism is refused loudly, not approximated"""
+    from oracle import loops
+    from test_emulated_kernel import loop_feedback_reference
+    capi = cclqr._capi
+    ex = cclqr.examples.deltabot()
+    mech_py = ex["mech"]
+    t = mech_py.tables()
+    cj = [mech_py.joint_index(e) for e in ex["eqcids"]]
+    lm, z, u = loops.deltabot()
+    z0 = mech_py.state()
+    zd = z0[None].copy()
+    mech = capi.MechHandle(t)
+    assert mech.geometry()[0] == 64
+    hold = capi.CtrlHandle(mech, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2))
+    zT, _, st = capi.rollout(mech, hold, z0[None], 50)            # (the torque is given to eight digits: the residual acceleration ~5e-8 m/s2 grows from there)
+    assert st[0] > 0 and np.abs(zT[0] - z0).max() < 1e-6
+    steps, n = 25, 5
+    rng = np.random.default_rng(3)
+    K = rng.normal(size=(n, 1, 2, 12 * t.nb)) * 2.0
+    K[0] = 0.0                                                      # instance 0: open loop
+    scale = np.linspace(0.8, 0.6, n)
+    Fd = scale[:, None, None] * ex["Fd"].reshape(1, 1, 2)
+    ctrl = capi.CtrlHandle(mech, cj, K=K, N=0, zd=np.repeat(zd[None], n, 0), Fd=Fd, n_ctrl=n)
+    zb = np.repeat(z0[None], n, 0)
+    zT, traj, st = capi.rollout(mech, ctrl, zb, steps, record=True)
+    assert (st > 0).all()
+    for i in range(n):
+        ref, zref = loop_feedback_reference(lm, z.copy(), Fd[i, 0], None if i == 0 else K[i, 0], zd[0], steps)
+        assert np.abs(traj[i] - ref).max() < TOL and np.abs(zT[i] - zref).max() < TOL, i
+        assert np.abs(lm.constraints(zT[i])).max() < 1e-12
+    assert np.abs(zT[0] - z0).max() > 0.5
+    one = capi.CtrlHandle(mech, cj, K=K[3], N=0, zd=zd, Fd=Fd[3])
+    zT1, traj1, _ = capi.rollout(mech, one, z0[None], steps, record=True)
+    assert np.array_equal(zT1[0], zT[3]) and np.array_equal(traj1[0], traj[3])
+    with pytest.raises(capi.CclqrError) as e:
+        capi.linearize(mech, zd, cj)
+    assert e.value.code == -5
+
+
+
 _SHARDED_WORKER = r"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, %(root)r)

@@ -67,14 +67,22 @@ def test_mechanism_mirror_reproduces_script_placements(cclqr):
     assert np.allclose(t.inertia[1].reshape(3, 3), np.diag([1.01, 1.01, 0.02]) / 12)
 
 
-def test_mechanism_rejects_unsupported_topologies(cclqr):
+def test_mechanism_topologies(cclqr):
     o = cclqr.Origin()
     a, b = cclqr.Box(1, 1, 1, 1), cclqr.Box(1, 1, 1, 1)
     j1 = cclqr.EqualityConstraint(cclqr.Revolute(o, a, [1, 0, 0]))
     j2 = cclqr.EqualityConstraint(cclqr.Revolute(a, b, [1, 0, 0]))
     j3 = cclqr.EqualityConstraint(cclqr.Revolute(o, b, [1, 0, 0]))
+    m = cclqr.Mechanism(o, [a, b], [j1, j2, j3])       # closed loop (lqr_deltabot.jl): accepted, flagged, rolled out by rollout_loop.hip
+    t = m.tables()
+    assert m.has_loops and (t.nb, t.ne, t.ml) == (2, 3, 15)
+    assert not cclqr.Mechanism(o, [a, b], [j1, j2]).has_loops
     with pytest.raises(ValueError):
-        cclqr.Mechanism(o, [a, b], [j1, j2, j3])       # closed loop (lqr_deltabot.jl) is out of scope
+        cclqr.Mechanism(o, [a, b], [j1])               # a body without any joint
+    ex = cclqr.examples.deltabot()                     # examples/lqr_deltabot.jl:25-41
+    t = ex["mech"].tables()
+    assert ex["mech"].has_loops and (t.nb, t.ne) == (5, 7) and list(t.type) == [0, 0, 0, 0, 2, 0, 0]
+    assert sum(len(e) for e in ex["mech"].eqconstraints) == 33
 
 
 def test_shard_bounds_cover_everything(cclqr):
@@ -259,6 +267,14 @@ def test_chain_rollout_kernel_resources(tmp_path):
             assert k["vgpr"] <= (496 if "ILi32ELi1" in name else 440), (name, k)
         else:
             assert k["sgpr_spill"] <= 16, (name, k)
+
+
+def test_loop_rollout_kernel_resources(tmp_path):
+    """the closed-loop rollout kernel (csrc/rollout_loop.hip) cross-compiles for gfx950 without scratch memory"""
+    kernels = _kernel_resources(tmp_path, "rollout_loop.hip", "rollout_loop_kernel")
+    assert len(kernels) == 1, sorted(kernels)
+    for name, k in kernels.items():
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
 
 
 def test_rollout_kernel_resources(tmp_path):
