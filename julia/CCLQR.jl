@@ -43,6 +43,7 @@ end
 
 const REVOLUTE = Int32(0)
 const PRISMATIC = Int32(1)
+const FIXED_ORIENTATION = Int32(2)     # FixedOrientation(a, b; qoffset): one Rotational3 constraint (examples/lqr_deltabot.jl:25)
 
 lasterror() = unsafe_string(ccall((:cclqr_last_error, lib), Cstring, ()))
 function check(rc::Integer)
@@ -66,11 +67,13 @@ function mech_tables(mechanism)
     inertia = reduce(vcat, [vec(permutedims(Matrix(b.J))) for b in bodies])          # row-major 3x3 per body
     parent = Int32[get(bodyindex, e.parentid, Int32(-1)) for e in eqcs]                # origin -> -1
     child = Int32[bodyindex[e.childids[1]] for e in eqcs]
-    typ = Int32[length(e.constraints[1]) == 3 ? REVOLUTE : PRISMATIC for e in eqcs]   # Translational3+Rotational2 | Translational2+Rotational3
-    p1 = reduce(vcat, [Vector{Float64}(e.constraints[1].vertices[1]) for e in eqcs])
-    p2 = reduce(vcat, [Vector{Float64}(e.constraints[1].vertices[2]) for e in eqcs])
-    axis = reduce(vcat, [Vector{Float64}(vec(typ[i] == REVOLUTE ? e.constraints[2].V3 : e.constraints[1].V3)) for (i, e) in enumerate(eqcs)])
-    qoff = reduce(vcat, [Float64[q.s, q.v1, q.v2, q.v3] for q in (e.constraints[2].qoffset for e in eqcs)])
+    # Translational3+Rotational2 | Translational2+Rotational3 | a lone Rotational3 (closed-loop mechanisms: rollout only, include/cclqr.h)
+    typ = Int32[length(e.constraints) == 1 ? FIXED_ORIENTATION : (length(e.constraints[1]) == 3 ? REVOLUTE : PRISMATIC) for e in eqcs]
+    lone(i) = typ[i] == FIXED_ORIENTATION
+    p1 = reduce(vcat, [lone(i) ? zeros(3) : Vector{Float64}(e.constraints[1].vertices[1]) for (i, e) in enumerate(eqcs)])
+    p2 = reduce(vcat, [lone(i) ? zeros(3) : Vector{Float64}(e.constraints[1].vertices[2]) for (i, e) in enumerate(eqcs)])
+    axis = reduce(vcat, [lone(i) ? [1.0, 0.0, 0.0] : Vector{Float64}(vec(typ[i] == REVOLUTE ? e.constraints[2].V3 : e.constraints[1].V3)) for (i, e) in enumerate(eqcs)])
+    qoff = reduce(vcat, [Float64[q.s, q.v1, q.v2, q.v3] for q in (e.constraints[end].qoffset for e in eqcs)])
     return (; nb, ne, dt = Float64(mechanism.Δt), g = Float64(mechanism.g), mass, inertia, parent, child, typ, p1, p2, axis, qoff)
 end
 
