@@ -267,9 +267,17 @@ __device__ inline void tile_mfma_splitk(int K, FA la, FB lb, double (*red)[1024]
 #pragma unroll
                 for (int hj = 0; hj < 2; hj++) acc[hi][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][hi], bv[u][hj], acc[hi][hj], 0, 0, 0);
     };
+    // every pass is one round trip to L2 (its loads are issued together, its MFMAs wait for them), so the tail is covered by the
+    // FEWEST passes -- a masked pass of 8 or 4 rather than a string of passes of 2 (mx = 204: 13 k-groups per wavefront = 8 + 8
+    // masked instead of 8 + 2 + 2 + 2; the masked groups cost idle MFMAs, not latency)
     int g0 = wave;
     for (; g0 + 4 * 7 < ngroups; g0 += 4 * 8) pass(std::integral_constant<int, 8>{}, g0);
-    for (; g0 < ngroups; g0 += 4 * 2) pass(std::integral_constant<int, 2>{}, g0);
+    while (g0 < ngroups) {
+        const int left = (ngroups - g0 + 3) >> 2;        // k-groups this wavefront still has
+        if (left > 4) { pass(std::integral_constant<int, 8>{}, g0); g0 += 4 * 8; }
+        else if (left > 2) { pass(std::integral_constant<int, 4>{}, g0); g0 += 4 * 4; }
+        else { pass(std::integral_constant<int, 2>{}, g0); g0 += 4 * 2; }
+    }
 #pragma unroll
     for (int hi = 0; hi < 2; hi++)
 #pragma unroll
