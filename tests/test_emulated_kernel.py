@@ -265,9 +265,19 @@ def test_chain_emulator_under_address_and_undefined_sanitizers(tmp_path):
     exe = str(tmp_path / "asan_emu")
     subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-x", "hip", "--offload-host-only", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-I/opt/rocm/include", "-o", exe,
-                           os.path.join(emu_dir, "emu_chain.cpp"), os.path.join(emu_dir, "asan_main.cpp")], stderr=subprocess.DEVNULL)
-    for n_links in (1, 7, 16, 31):
-        r = subprocess.run([exe, str(n_links), "12"], capture_output=True, text=True, timeout=300)
+                           os.path.join(emu_dir, "emu_chain.cpp"), os.path.join(emu_dir, "emu_loop.cpp"), os.path.join(emu_dir, "asan_main.cpp")],
+                          stderr=subprocess.DEVNULL)
+    # the closed-loop kernel's phases on the deltabot (tables, pose and 90 % of the holding inputs handed over as a flat file)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    ex = pkg.examples.deltabot()
+    t = ex["mech"].tables()
+    flat = np.concatenate([[t.nb, t.ne, t.dt, t.g], t.mass, t.inertia.ravel(), t.parent, t.child, t.type, t.p1.ravel(), t.p2.ravel(), t.axis.ravel(),
+                           t.qoff.ravel(), ex["mech"].state().ravel(), 0.9 * ex["Fd"]]).astype(np.float64)
+    flat.tofile(str(tmp_path / "deltabot.bin"))
+    runs = [[exe, str(n_links), "12"] for n_links in (1, 7, 16, 31)] + [[exe, "loop", str(tmp_path / "deltabot.bin"), "12"]]
+    for cmd in runs:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "rc 0 status" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
         status = int(r.stdout.split("status")[1].split()[0])
         assert status > 0
