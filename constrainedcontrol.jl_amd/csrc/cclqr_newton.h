@@ -74,14 +74,36 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// The LDS layout is 26 offsets that are all functions of nb.  Held as scalars through the kernel they cost 26 SGPRs for its whole
+// lifetime (the tree kernels spilled 74-80 scalars); recomputed where a phase is called -- a few scalar multiply-adds on a value the
+// optimiser cannot see through -- they live only inside that phase.  (SS, the sibling blocks, does not depend on their number.)
+__device__ __forceinline__ Lay fresh_layout(int nb) {
+    asm volatile("" : "+s"(nb));
+    return make_layout(nb, 0);
+}
+#define FRESH_Y fresh_layout(nb)
+// The same for per-lane predicates (t < nb, t in an elimination front, ...): every phase starts from a lane index the optimiser
+// cannot relate to the one of the previous phase, so its lane masks (64-bit scalars) are formed inside the phase and die with it
+// instead of being hoisted out of the step loop and kept -- or spilled -- for the whole launch.
+__device__ __forceinline__ int fresh_lane(int t) {
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#define FRESH_T fresh_lane(t)
+// ... and for the predicates on the owned link's integers (joint type, parent, child, row kinds) and the addresses of the mechanism's
+// tables (M + constant): re-derived per phase instead of held
+#define FRESH_PHASE(M, r) asm volatile("" : "+s"(M), "+v"((r).parent), "+v"((r).childl), "+v"((r).rotmask), "+v"((r).type))
+
 // residual (+ Jacobians when JAC) at the point s_off with multipliers lambda - alpha dlambda; returns the group's ||f||_2
 template <int G, bool JAC>
-__device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M, double dt,
+__device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt,
                                              int s_off, double alpha, bool active PROF_ARG) {
-    double part = active ? ph_body_eval<JAC>(t, nb, Y, L, r, dt, s_off, alpha) : 0.0;
+    FRESH_PHASE(M, r);
+    double part = active ? ph_body_eval<JAC>(FRESH_T, nb, FRESH_Y, L, r, dt, s_off, alpha) : 0.0;
     __syncthreads();
     STAMP(PF_EVAL_BODY);
-    part += active ? ph_joint_eval<JAC>(t, nb, Y, L, r, dt) : 0.0;
+    FRESH_PHASE(M, r);
+    part += active ? ph_joint_eval<JAC>(FRESH_T, nb, FRESH_Y, L, r, dt) : 0.0;
     __syncthreads();
     STAMP(PF_EVAL_JOINT);
     double nrm = sqrt(group_sum<G>(part));
@@ -97,7 +119,7 @@ __device__ __forceinline__ double eval_point(int t, int nb, const Lay& Y, double
 template <int G, bool TREE = false>
 __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, double dt, bool valid,
                                             bool* converged PROF_ARG) {
-    double normf0 = eval_point<G, true>(t, nb, Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
+    double normf0 = eval_point<G, true>(t, nb, FRESH_Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
     bool done = !valid, failed = false;
     int its = 0;
     const unsigned smask = M->start_mask, emask = M->end_mask;
@@ -109,27 +131,31 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
     for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
         if (!__any(!done)) break;
         PCOUNT(PF_NEWTON_ITERS);
+        FRESH_PHASE(M, r);
         if (TREE) {
             // general tree: sibling-coupled Schur complement, table-driven elimination leaves -> roots, back substitution roots -> leaves
-            if (!done) ph_schur_s_tree(t, G, nb, Y, L, M);
+            if (!done) ph_schur_s_tree(FRESH_T, G, nb, FRESH_Y, L, M);
             __syncthreads();
             STAMP(PF_SCHUR_S);
             for (int l = nb - 1; l >= 0; l--) {
-                if (!done) ph_tree_elim(t, l, Y, L, M);
+                FRESH_PHASE(M, r);
+                if (!done) ph_tree_elim(FRESH_T, l, FRESH_Y, L, M);
                 __syncthreads();
             }
             STAMP(PF_TRI_FWD);
             for (int l = 0; l < nb; l++) {
-                if (!done) ph_tree_back(t, l, Y, L, M);
+                FRESH_PHASE(M, r);
+                if (!done) ph_tree_back(FRESH_T, l, FRESH_Y, L, M);
                 __syncthreads();
             }
             STAMP(PF_TRI_BWD);
-            if (!done) ph_body_solve_tree(t, G, nb, Y, L, M);
+            FRESH_PHASE(M, r);
+            if (!done) ph_body_solve_tree(FRESH_T, G, nb, FRESH_Y, L, M);
             __syncthreads();
             STAMP(PF_BODY_SOLVE);
         } else {
         // Schur complement on the multipliers
-        if (!done) ph_schur_s(t, G, nb, Y, L, smask);
+        if (!done) ph_schur_s(FRESH_T, G, nb, FRESH_Y, L, smask);
         __syncthreads();
         STAMP(PF_SCHUR_S);
         // block-tridiagonal solve along each chain, swept from both ends
@@ -138,21 +164,22 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
             for (int i = 0; i < P.steps; i++) {
                 double lu[5];
                 int l = 0;
-                bool act = !done && ph_tri_elim(t, i, P, Y, L, lu, &l);
+                bool act = !done && ph_tri_elim(FRESH_T, i, P, FRESH_Y, L, lu, &l);
                 // no barrier here: the store overwrites what the same wavefront has already loaded (LDS is in order per wavefront)
-                if (act) ph_tri_store(t, l, Y, L, lu);
+                if (act) ph_tri_store(FRESH_T, l, FRESH_Y, L, lu);
                 __syncthreads();
             }
             STAMP(PF_TRI_FWD);
-            if (!done) ph_tri_mid(t, P, Y, L);
+            if (!done) ph_tri_mid(FRESH_T, P, FRESH_Y, L);
             __syncthreads();
             for (int j = 0; j < P.steps; j++) {
-                if (!done) ph_tri_back(t, j, P, Y, L);
+                if (!done) ph_tri_back(FRESH_T, j, P, FRESH_Y, L);
                 __syncthreads();
             }
             STAMP(PF_TRI_BWD);
         }
-        if (!done) ph_body_solve(t, G, nb, Y, L, emask);
+        FRESH_PHASE(M, r);
+        if (!done) ph_body_solve(FRESH_T, G, nb, FRESH_Y, L, emask);
         __syncthreads();
         STAMP(PF_BODY_SOLVE);
         }
@@ -161,11 +188,11 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         double alpha = 1.0, normf1 = 0.0, nd = 0.0;
         bool ls_done = done, jac_ok = true;
         {   // full step (ls = 0), with the Jacobians
-            double pd = ls_done ? 0.0 : ph_trial(t, G, nb, Y, L, alpha, s_cur, s_try, l_cur, l_try);
+            double pd = ls_done ? 0.0 : ph_trial(FRESH_T, G, nb, FRESH_Y, L, alpha, s_cur, s_try, l_cur, l_try);
             nd = sqrt(group_sum<G>(pd));
             __syncthreads();
             STAMP(PF_TRIAL);
-            double nf = eval_point<G, true>(t, nb, Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS);
+            double nf = eval_point<G, true>(t, nb, FRESH_Y, L, r, M, dt, s_try, alpha, !ls_done PROF_PASS);
             if (!ls_done) {
                 normf1 = nf;
                 if (!(normf1 > normf0)) ls_done = true;
@@ -175,17 +202,18 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         // halvings, NL levels per pass (see level_layout): lane group lg tests alpha = 2^-(lv + lg)
         for (int lv = 1; lv <= LINE_MAXIT; lv += NL) {
             if (!__any(!ls_done)) break;
+            FRESH_PHASE(M, r);
             const int mylv = lv + lg;
             const bool lane_on = !ls_done && lg < NL && mylv <= LINE_MAXIT;
             const double a_l = ldexp(1.0, -mylv);
-            const Lay V = level_layout(Y, nb, lg < NL ? lg : 0);
-            if (lane_on) ph_trial_level(tl, nb, Y, V, L, a_l, s_cur, l_cur);
+            const Lay V = level_layout(FRESH_Y, nb, lg < NL ? lg : 0);
+            if (lane_on) ph_trial_level(fresh_lane(tl), nb, FRESH_Y, V, L, a_l, s_cur, l_cur);
             __syncthreads();
             STAMP(PF_TRIAL);
-            double part = lane_on ? ph_body_eval<false>(tl, nb, V, L, r, dt, V.ST, a_l) : 0.0;
+            double part = lane_on ? ph_body_eval<false>(fresh_lane(tl), nb, V, L, r, dt, V.ST, a_l) : 0.0;
             __syncthreads();
             STAMP(PF_EVAL_BODY);
-            part += lane_on ? ph_joint_eval<false>(tl, nb, V, L, r, dt) : 0.0;
+            part += lane_on ? ph_joint_eval<false>(fresh_lane(tl), nb, V, L, r, dt) : 0.0;
             __syncthreads();
             STAMP(PF_EVAL_JOINT);
             double nfq[LEVEL_SLOTS];
@@ -201,14 +229,15 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
                 if (chosen < 0 && lv + NL > LINE_MAXIT) chosen = -2;   // cannot happen: level LINE_MAXIT always accepts
                 if (chosen >= 0) { ls_done = true; jac_ok = false; }
             }
-            if (chosen >= 0) ph_level_commit(t, nb, Y, level_layout(Y, nb, chosen), L, s_try, l_try);
+            if (chosen >= 0) ph_level_commit(FRESH_T, nb, Y, level_layout(FRESH_Y, nb, chosen), L, s_try, l_try);
             __syncthreads();
         }
         bool need_jac = false;
         // all groups of the wavefront swap together: groups that are already done copy nothing and keep their solution where
         // it is, so the swap is only applied to a group's own view
+        FRESH_PHASE(M, r);
         if (!done) {
-            ph_accept(t, G, nb, Y, L, alpha);
+            ph_accept(FRESH_T, G, nb, FRESH_Y, L, alpha);
             { int q = s_cur; s_cur = s_try; s_try = q; q = l_cur; l_cur = l_try; l_try = q; }
             its = iter;
             if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
@@ -218,9 +247,9 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
         }
         __syncthreads();
         STAMP(PF_ACCEPT);
-        if (__any(need_jac)) eval_point<G, true>(t, nb, Y, L, r, M, dt, s_cur, 0.0, need_jac PROF_PASS);
+        if (__any(need_jac)) eval_point<G, true>(t, nb, FRESH_Y, L, r, M, dt, s_cur, 0.0, need_jac PROF_PASS);
     }
-    ph_copy_solution(t, G, nb, Y, L, s_cur, l_cur);
+    ph_copy_solution(FRESH_T, G, nb, FRESH_Y, L, s_cur, l_cur);
     __syncthreads();
     *converged = done && !failed;
     return its;

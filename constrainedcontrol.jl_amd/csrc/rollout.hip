@@ -16,7 +16,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
     const int64_t inst = (int64_t)blockIdx.x * (64 / G) + grp;
-    const bool valid = inst < a.n_inst;
+    // the instance exists / a step of it did not converge / it is frozen: bits of ONE vector register, re-tested where needed
+    // (a 64-bit lane mask each, kept in scalar registers for the whole launch, otherwise -- see rollout_chain.hip)
+    int fl = inst < a.n_inst ? 1 : 0;
+#define valid ((fl & 1) != 0)
+#define dead ((fl & 2) != 0)
+#define bad ((fl & 4) != 0)
+#define FRESH_FLAGS asm volatile("" : "+v"(fl))
     const MechDev* M = a.M;
     const CtrlDev* C = a.C;
     const int nb = M->nb;
@@ -44,72 +50,97 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     __syncthreads();
 
     int worst = 0;
-    bool bad = false, dead = false;    // dead: a step produced a non-finite residual; the instance is frozen from then on
-    for (int kk = 0; kk < a.steps; kk++) {
-        const int k = a.k0 + kk;
-        if (a.traj && valid)
-            for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.traj[((size_t)inst * a.steps + kk) * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
+    // Launch arguments that are only needed once per step or at the end are read from the kernel-argument segment where they are
+    // used, through a pointer the optimiser cannot see through, instead of sitting in (spilled) scalar registers for the whole launch.
+    typedef const __attribute__((address_space(4))) RolloutArgs* KernArgs;
+    KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int k0 = a.k0;
+    int nsteps = a.steps;
+    for (int kk = 0; kk < nsteps; kk++) {
+        const int k = k0 + kk;
+        asm volatile("" : "+s"(ap));
+        FRESH_PHASE(M, r); FRESH_FLAGS;
+        double* const traj_out = ap->traj;
+        if (traj_out && valid)
+            for (int e = fresh_lane(t); e < nz; e += G) { int l = e / 13, c = e - 13 * l; traj_out[((size_t)inst * ap->steps + kk) * nz + M->perm[l] * 13 + c] = L[FRESH_Y.Z + e]; }
 
         STAMP(PF_IO);
         // ---------------- feedback law (lqr.jl:89-139 / lqr_tracking.jl:46-71)
         const bool gate = (C->N <= 0) || (k < C->N);
         const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
         const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
-        const long long ginst = a.inst0 + inst;     // global instance index: selects the controller table when there is one per instance
-        if (gate && valid) ph_control_error(t, nb, Y, L, r, C, C->zd + ginst * C->zd_stride + (size_t)ksp * nz);
-        else if (t < nb) L[Y.UJ + t] = 0.0;
+        const long long ginst = ap->inst0 + inst;     // global instance index: selects the controller table when there is one per instance
+        if (gate && valid) ph_control_error(FRESH_T, nb, FRESH_Y, L, r, C, C->zd + ginst * C->zd_stride + (size_t)ksp * nz);
+        else if (t < nb) L[FRESH_Y.UJ + t] = 0.0;
         __syncthreads();
         if (gate) {
             for (int i = 0; i < C->mu; i++) {
                 double part = 0.0;
-                if (C->K && valid) part = ph_gain_partial(t, G, nb, Y, L, C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb);
+                if (C->K && valid) part = ph_gain_partial(FRESH_T, G, nb, FRESH_Y, L, C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb);
                 double s = group_sum<G>(part);
-                if (t == 0 && valid) {
+                if (FRESH_T == 0 && valid) {
                     double u = (C->Fd ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
                     // noise: injected by the caller, or generated for this launch by philox_fill_kernel (capi.hip)
-                    if (EXTRA >= 1 && C->noise_scale != 0.0 && a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];
-                    L[Y.UJ + C->cj[i]] += u;
+                    if (EXTRA >= 1 && C->noise_scale != 0.0 && ap->noise) u += C->noise_scale * ap->noise[(size_t)inst * ap->noise_stride + (k - 1)];
+                    L[FRESH_Y.UJ + C->cj[i]] += u;
                 }
                 __syncthreads();
             }
         }
         if (EXTRA >= 2 && C->has_pid) {
-            if (valid) ph_pid(t, nb, Y, L, r, C, dt, k == 1);
+            if (valid) ph_pid(FRESH_T, nb, FRESH_Y, L, r, C, dt, k == 1);
             __syncthreads();
         }
         STAMP(PF_CONTROL);
+        FRESH_PHASE(M, r); FRESH_FLAGS;
         // ---------------- per-step invariants
-        if (lg < NL) ph_forces<TREE>(tl, nb, Y, L, r, M, lg == 0);
-        ph_knot_jac(t, nb, Y, L, r);
+        if (lg < NL) ph_forces<TREE>(fresh_lane(tl), nb, FRESH_Y, L, r, M, lg == 0);
+        ph_knot_jac(FRESH_T, nb, FRESH_Y, L, r);
         __syncthreads();
-        if (TREE) ph_force_map_tree(t, G, nb, Y, L, M);
-        else ph_force_map(t, G, nb, Y, L, M->end_mask);
+        if (TREE) ph_force_map_tree(FRESH_T, G, nb, FRESH_Y, L, M);
+        else ph_force_map(FRESH_T, G, nb, FRESH_Y, L, M->end_mask);
         __syncthreads();
         STAMP(PF_FORCES);
         PCOUNT(PF_STEPS);
 
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
+        FRESH_PHASE(M, r); FRESH_FLAGS;
         bool done = false;
-        int its = newton_solve<G, TREE>(t, nb, Y, L, r, M, dt, valid && !dead, &done PROF_PASS);
+        int its = newton_solve<G, TREE>(t, nb, FRESH_Y, L, r, M, dt, valid && !dead, &done PROF_PASS);
         if (valid && !dead) {
-            if (!done) bad = true;
+            if (!done) fl |= 4;
             if (its > worst) worst = its;
-            if (!done && its < NEWTON_MAXIT) dead = true;   // stopped early on a non-finite residual
-            else ph_update(t, nb, Y, L);
+            if (!done && its < NEWTON_MAXIT) fl |= 2;   // stopped early on a non-finite residual: the instance is frozen from then on
+            else ph_update(FRESH_T, nb, FRESH_Y, L);
         }
         __syncthreads();
+        asm volatile("" : "+s"(ap));
+        nsteps = ap->steps;      // read again rather than kept in a scalar register through the step
     }
+    asm volatile("" : "+s"(ap));
+    FRESH_PHASE(M, r); FRESH_FLAGS;
     if (valid) {
-        for (int e = t; e < nz; e += G) { int l = e / 13, c = e - 13 * l; a.zT[inst * nz + M->perm[l] * 13 + c] = L[Y.Z + e]; }
-        if (a.lam) for (int e = t; e < 5 * nb; e += G) a.lam[inst * 5 * nb + e] = L[Y.LAM + e];
-        if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
-        if (EXTRA >= 2 && a.pid_state && t < nb) { a.pid_state[(inst * nb + t) * 2] = r.pid_int; a.pid_state[(inst * nb + t) * 2 + 1] = r.pid_last; }
+        double* const zT = ap->zT;
+        double* const lam = ap->lam;
+        int* const status = ap->status;
+        const MechDev* const MT = ap->M;
+        const int nbT = MT->nb, nzT = 13 * nbT;      // read again here rather than kept in scalar registers through the launch
+        const Lay YT = make_layout(nbT, 0);
+        for (int e = t; e < nzT; e += G) { int l = e / 13, c = e - 13 * l; zT[inst * nzT + MT->perm[l] * 13 + c] = L[YT.Z + e]; }
+        if (lam) for (int e = t; e < 5 * nbT; e += G) lam[inst * 5 * nbT + e] = L[YT.LAM + e];
+        if (status && t == 0) status[inst] = bad ? -worst : worst;
+        if (EXTRA >= 2 && ap->pid_state && t < nbT) { double* const ps = ap->pid_state; ps[(inst * nbT + t) * 2] = r.pid_int; ps[(inst * nbT + t) * 2 + 1] = r.pid_last; }
     }
 #ifdef CCLQR_PROFILE
     prof.stamp(PF_IO);
     prof.flush();
 #endif
 }
+
+#undef valid
+#undef dead
+#undef bad
+#undef FRESH_FLAGS
 
 #ifdef CCLQR_PROFILE
 extern "C" int cclqr_prof_read(unsigned long long* out, int reset) {

@@ -279,11 +279,15 @@ def test_loop_rollout_kernel_resources(tmp_path):
 
 def test_rollout_kernel_resources(tmp_path):
     """every instantiation of the general-tree rollout kernel cross-compiles for gfx950 within one wavefront's register file
-    (512 VGPR + AGPR per lane) without scratch memory"""
+    (512 VGPR + AGPR per lane) without scratch memory; the plain-LQR and friction/noise instantiations spill NO scalar register
+    (layout offsets, lane predicates, table addresses and launch arguments are re-derived per phase instead of
+    held for the launch -- cclqr_newton.h fresh_layout / fresh_lane / FRESH_PHASE), the PID ones a few (atan2 constants)"""
     kernels = _kernel_resources(tmp_path, "rollout.hip", "rollout_kernel")
     assert len(kernels) == 9, sorted(kernels)          # G in {16, 32, 64} x control variant, trees (chains run rollout_chain.hip)
     for name, k in kernels.items():
         assert k["vgpr"] <= 512 and k["lds"] == 0, (name, k)      # all LDS is dynamic (one instance layout per lane group)
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
-        if "ELi0EEEv" in name:                                     # plain LQR: clear of the register file's limit
-            assert k["vgpr"] <= 420 and k["sgpr_spill"] <= 80, (name, k)
+        if "ELi2EEEv" in name:
+            assert k["sgpr_spill"] <= 24, (name, k)
+        else:                                                       # plain LQR, friction/noise: clear of the register file's limits
+            assert k["vgpr"] <= 340 and k["sgpr_spill"] == 0, (name, k)
