@@ -279,16 +279,83 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T):
     torch.cuda.synchronize()
     dt16 = (time.perf_counter() - t0) / 3
     ok16 = bool((st16_d > 0).all().item())
+    more = {}
+    try:
+        more.update(other_configs(pkg, capi, torch, dev))
+    except Exception as e:        # the extra lines never take the headline line down with them
+        more["other_configs_error"] = repr(e)
     m = mu + ml
     f_ric = 4 * mx ** 3 + 4 * mx ** 2 * m + 2 * mx * (ml ** 2 + m ** 2) + 2 / 3 * m ** 3 + 2 / 3 * ml ** 3
     nsteps = T - max(int(lqr.kbreak), 1)
     return {"cartpole_cfg2": {"instances": n, "sim_steps": 1000, "value": n * 1000 / dt2, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt2,
                               "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak),
                               "device_filled": {"instances": n16, "record": False, "value": (n16 * 1000 / dt16) if ok16 else None, "ms_per_rollout": 1e3 * dt16}},
+            **more,
             "riccati_setup": {"mx": mx, "backward_steps": nsteps, "flops_per_step": f_ric,
                               "note": "LQR construction of the headline workload = linearize + %d-step recursion (projected form, tiled over the device, fp64 MFMA); "
                                       "wall time incl. host<->device copies" % nsteps,
                               "gflops_lower_bound": f_ric * nsteps / setup_s / 1e9, "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}}
+
+
+def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3):
+    n, nb = z0.shape[0], z0.shape[1]
+    z0_d = torch.from_numpy(np.ascontiguousarray(z0)).to(dev)
+    zT_d = torch.empty_like(z0_d)
+    st_d = torch.zeros(n, dtype=torch.int32, device=dev)
+    traj_d = torch.empty((n, steps, nb, 13), dtype=torch.float64, device=dev) if record else None
+    stream = torch.cuda.current_stream().cuda_stream
+    run = lambda: capi.rollout_dev(mh, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(), st_d.data_ptr(), stream)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    bad = int((st_d <= 0).sum().item())
+    return {"instances": n, "sim_steps": steps, "record": bool(record), "value": (n * steps / dt) if bad == 0 else None, "unit": "instance-steps/s",
+            "ms_per_rollout": 1e3 * dt, "failed_instances": bad}
+
+
+def other_configs(pkg, capi, torch, dev):
+    """BASELINE configs[3] and configs[4] at their full sizes through the same C-ABI (not the headline; one line each):
+    lqr_sawyer.jl -- 8192 seven-joint arms, horizon 20 s, joint angles ~ U(-0.002, 0.002) about the zero pose (the range in which every
+    start stays inside the script controller's region of attraction); trackingLQR_triple_cartpole.jl -- 16384 instances,
+    TrackingLQR about the swing-up of the script's own input U, friction + Philox cart noise (the script's uncontrol!/owncontrol law)"""
+    out = {}
+    gold = os.path.join(ROOT, "tests", "golden")
+    tab = json.load(open(os.path.join(gold, "sawyer_arm_tables.json")))
+    ex = pkg.examples.sawyer(tab)
+    mech = ex["mech"]
+    t0 = time.time()
+    lq = pkg.LQR(mech, [pkg.getid(b) for b in mech.bodies], [pkg.getid(e) for e in mech.eqconstraints], ex["Q"], ex["R"], 20.0, xd=ex["xd"], qd=ex["qd"])
+    setup = time.time() - t0
+    rng = np.random.default_rng(4)
+    base = []
+    for _ in range(64):
+        for e in mech.eqconstraints:
+            pkg.setJointPosition(mech, e, rng.uniform(-0.002, 0.002))
+        base.append(mech.state())
+    z0 = np.tile(np.stack(base), (128, 1, 1))
+    mh = mech._cclqr_handle
+    ctrl = lq._ctrl_handle(mh)
+    out["sawyer_cfg4"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, 2000, False), lqr_construct_s=setup, riccati_kbreak=int(lq.kbreak))
+    ctrl.close()
+    U = np.load(os.path.join(gold, "triple_cartpole_U.npy"))
+    ex = pkg.examples.triple_cartpole()
+    mech = ex["mech"]
+    j1 = ex["ctrl"][0]
+    z00 = mech.state()
+    t0 = time.time()
+    s0 = pkg.simulate(mech, pkg.Storage(1000, 4), pkg.OpenLoop(mech, [j1.id], U.reshape(1000, 1)))
+    tl = pkg.TrackingLQR(mech, s0, [[[U[k]]] for k in range(1000)], [j1.id], ex["Q"], ex["R"])
+    setup = time.time() - t0
+    mh = mech._cclqr_handle
+    ctrl = tl._ctrl_handle(mh, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+    out["triple_cartpole_tracking_cfg5"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z00, (16384, 1, 1)), 1000, True),
+                                                swingup_plus_trackinglqr_construct_s=setup)
+    ctrl.close()
+    return out
 
 
 def build_native_oracle():
