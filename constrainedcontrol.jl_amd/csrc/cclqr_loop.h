@@ -20,14 +20,15 @@ namespace cclqr {
 
 // LDS image of one instance.  Body-indexed arrays keep the names (and meaning) of the tree kernels' layout so that their body phases
 // (ph_body_eval, ph_control_error, ph_gain_partial, ph_accept, ph_update) run unchanged; joint-indexed arrays have nj entries.
-// SS = the dense system [S | r], row stride 5 nj + 1 (+1 if that is even: odd stride, conflict-free column walks).
-HD int loop_row_stride(int nj) { const int w = 5 * nj + 1; return (w & 1) ? w : w + 1; }
+// SS = the dense system, one row per lane: [r | S row (5 nj columns) | 8 doubles of padding that stay zero], odd stride.  The padding
+// lets the solve move through a row eight columns at a time without a bounds test per element.
+HD int loop_row_stride(int nj) { return (5 * nj + 9) | 1; }
 HD Lay make_loop_layout(int nb, int nj) {
     Lay L; int o = 0;
     L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;   L.DS = o; o += 6 * nb;
     L.LAM = o; o += 5 * nj;  L.LT = o; o += 5 * nj;  L.DL = o; o += 5 * nj;
     L.XQ = o; o += 7 * nb;   L.NB = o; o += 9 * nb;  L.DINV = o; o += 9 * nb; L.DTM = o; o += nb;
-    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nj;   L.R = o; o += 5 * nj;      // R: column permutation of the pivoting (as doubles)
+    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nj;   L.R = o; o += 10 * nj;     // R: the solve's column permutation, then its pivot rows (as doubles)
     L.GKA = o; o += BLK * nj; L.GKB = o; o += BLK * nj; L.GVA = o; o += BLK * nj; L.GVB = o; o += BLK * nj;
     L.UJ = o; o += nj;
     L.C = o; o += 6 * nb;    L.CD = o; o += 6 * nb;
@@ -152,66 +153,99 @@ HD void lp_schur_row(int row, const Lay& Y, double* L, const MechDev* M) {
     for (int j = 0; j < nj; j++) {
         const int ja = M->parent[j], jb = M->jchild[j];
         const bool bb = ib == jb, ba = ib == ja, ab = ia >= 0 && ia == jb, aa = ia >= 0 && ia == ja;
-        for (int rj = 0; rj < 5; rj++) {
-            const double* ka = L + Y.GKA + BLK * j + 6 * rj;
-            const double* kb = L + Y.GKB + BLK * j + 6 * rj;
-            double s = 0.0;
-            if (bb) s += dot6(wb, kb);
-            if (ba) s += dot6(wb, ka);
-            if (ab) s += dot6(wa, kb);
-            if (aa) s += dot6(wa, ka);
-            out[5 * j + rj] = s;
+        // the products of one joint are formed in registers and stored together: a store into the same LDS array between the loads
+        // would serialise them (the compiler cannot tell the row of S from the Jacobian blocks)
+        double sj[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (bb || ba || ab || aa) {
+            double ka[30], kb[30];
+            for (int e = 0; e < 30; e++) { ka[e] = L[Y.GKA + BLK * j + e]; kb[e] = L[Y.GKB + BLK * j + e]; }
+            for (int rj = 0; rj < 5; rj++) {
+                double acc = 0.0;
+                if (bb) acc += dot6(wb, kb + 6 * rj);
+                if (ba) acc += dot6(wb, ka + 6 * rj);
+                if (ab) acc += dot6(wa, kb + 6 * rj);
+                if (aa) acc += dot6(wa, ka + 6 * rj);
+                sj[rj] = acc;
+            }
         }
+        for (int rj = 0; rj < 5; rj++) out[1 + 5 * j + rj] = sj[rj];
     }
     double rr = L[Y.G + 5 * i + ri] - dot6(wb, L + Y.D + 6 * ib);
     if (ia >= 0) rr -= dot6(wa, L + Y.D + 6 * ia);
-    out[mr] = rr;
+    out[0] = rr;
 }
 
-// ---- dense solve with complete pivoting, one pivot step at a time (the caller separates the sub-steps by wave barriers).
-// Lane = row.  `perm` (L[Y.R + c], stored as doubles) maps the working column c to the multiplier it stands for.
-// search: this lane's largest |a| over the remaining columns (value, column); the caller takes the wavefront's maximum
-HD void lp_pivot_search(int row, int k, int mr, int stride, const Lay& Y, const double* L, double* best, int* bcol) {
-    *best = -1.0; *bcol = k;
-    if (row < k || row >= mr) return;
-    const double* a = L + Y.SS + row * stride;
-    for (int c = k; c < mr; c++) { const double v = fabs(a[c]); if (v > *best) { *best = v; *bcol = c; } }
+// ---- dense solve with complete pivoting up to the numerical rank.  Lane = row for the whole solve (rows never move); columns are
+// swapped physically (every row swaps its own two entries) so that the columns still in play are contiguous, k .. mr-1 in step k.
+// Pivot choice: every remaining row carries its candidate as ONE 64-bit key -- the magnitude's bit pattern with the 12 lowest
+// mantissa bits replaced by 63 - row, 63 - column -- and the wavefront's largest key is the pivot: ties go to the smaller indices and
+// every lane ends with the same pivot.  A row finds its next candidate while it eliminates (the entries it has just updated are
+// the candidates of the next step), eight columns per pass: loads, arithmetic, stores -- no bounds test and no store between loads.
+// One wave barrier per step: after the column swap, before the pivot row is read.
+struct LoopRow {
+    int step;                     // pivot step this lane's row was used in (-1: not yet / never)
+    unsigned long long key;       // candidate of this row for the next step
+};
+HD unsigned long long lp_bits(double v) { union { double d; unsigned long long u; } x; x.d = v; return x.u; }
+HD unsigned long long lp_cand(double v, int col) { return (lp_bits(fabs(v)) & ~0x3Full) | (unsigned long long)(63 - col); }     // within a row: 6 bits of column
+HD unsigned long long lp_row_key(unsigned long long cand, int row) { return (cand & ~0xFC0ull) | ((unsigned long long)(63 - row) << 6); }
+HD double lp_key_value(unsigned long long key) { union { double d; unsigned long long u; } x; x.u = key & ~0xFFFull; return x.d; }
+HD int lp_key_row(unsigned long long key) { return 63 - (int)((key >> 6) & 63); }
+HD int lp_key_col(unsigned long long key) { return 63 - (int)(key & 63); }
+// first candidate of row `row`: its largest entry
+HD void lp_row_init(LoopRow& R, int row, int mr, int stride, const Lay& Y, const double* L) {
+    R.step = -1; R.key = 0ull;
+    if (row >= mr) return;
+    const double* a = L + Y.SS + row * stride + 1;
+    unsigned long long best = 0ull;
+    for (int c0 = 0; c0 < mr; c0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = a[c0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const unsigned long long cu = lp_cand(v[u], c0 + u); if (c0 + u < mr && cu > best) best = cu; }
+    }
+    R.key = lp_row_key(best, row);
 }
-// swap rows k <-> pr (lanes = columns here) and columns k <-> pc (lanes = rows); two calls, a barrier between them
-HD void lp_swap_rows(int t, int k, int pr, int mr, int stride, const Lay& Y, double* L) {
-    if (pr == k || t > mr) return;
-    double* a = L + Y.SS + k * stride + t; double* b = L + Y.SS + pr * stride + t;
-    const double x = *a; *a = *b; *b = x;
+// step k, first half: column pcol trades places with column k in EVERY row (retired pivot rows included: back substitution
+// addresses them by step index)
+HD void lp_col_swap(int row, int k, int pcol, int mr, int stride, const Lay& Y, double* L) {
+    if (pcol == k) return;
+    if (row < mr) { double* a = L + Y.SS + row * stride + 1; const double x = a[k]; a[k] = a[pcol]; a[pcol] = x; }
+    if (row == mr) { const double x = L[Y.R + k]; L[Y.R + k] = L[Y.R + pcol]; L[Y.R + pcol] = x; }
 }
-HD void lp_swap_cols(int t, int k, int pc, int mr, int stride, const Lay& Y, double* L) {
-    if (pc == k) return;
-    if (t < mr) { double* a = L + Y.SS + t * stride; const double x = a[k]; a[k] = a[pc]; a[pc] = x; }
-    if (t == mr) { const double x = L[Y.R + k]; L[Y.R + k] = L[Y.R + pc]; L[Y.R + pc] = x; }
-}
-// eliminate column k below the pivot (lane = row > k)
-HD void lp_eliminate(int row, int k, int mr, int stride, const Lay& Y, double* L) {
-    if (row <= k || row >= mr) return;
-    const double* p = L + Y.SS + k * stride;
+// step k, second half: the pivot row's lane retires; every other remaining row eliminates column k and finds its next candidate
+HD void lp_elim_search(LoopRow& R, int row, int k, int prow, int mr, int stride, const Lay& Y, double* L) {
+    if (row >= mr || R.step >= 0) return;
+    if (row == prow) { R.step = k; R.key = 0ull; L[Y.R + mr + k] = (double)prow; return; }
+    const double* p = L + Y.SS + prow * stride;
     double* a = L + Y.SS + row * stride;
-    const double f = a[k] / p[k];
-    if (f == 0.0) return;
-    for (int c = k + 1; c <= mr; c++) a[c] -= f * p[c];
-    a[k] = 0.0;
+    const double f = a[1 + k] / p[1 + k];
+    a[0] -= f * p[0];
+    unsigned long long best = 0ull;
+    for (int c0 = k + 1; c0 < mr; c0 += 8) {
+        double av[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { av[u] = a[1 + c0 + u]; pv[u] = p[1 + c0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            av[u] -= f * pv[u];           // beyond column mr-1 this is padding: 0 - f 0
+            const unsigned long long cu = lp_cand(av[u], c0 + u);
+            if (c0 + u < mr && cu > best) best = cu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[1 + c0 + u] = av[u];
+    }
+    R.key = lp_row_key(best, row);
 }
-// back substitution step k (rank-1 .. 0): x_k = r_k / a_kk ; rows above subtract a_ik x_k from their right-hand side
-HD void lp_back_step(int row, int k, int mr, int stride, const Lay& Y, double* L) {
-    if (row > k || row >= mr) return;
-    const double* p = L + Y.SS + k * stride;
-    const double xk = p[mr] / p[k];
+// back substitution, pivot k (rank-1 .. 0) in row prow: x = r / a_kk ; the rows of EARLIER pivots take a_ik x out of their right-hand side
+HD void lp_back_step(const LoopRow& R, int row, int k, int prow, int mr, int stride, const Lay& Y, double* L) {
+    if (row >= mr || R.step < 0 || R.step > k) return;
+    const double* p = L + Y.SS + prow * stride;
+    const double xk = p[0] / p[1 + k];
+    if (R.step == k) { L[Y.DL + (int)L[Y.R + k]] = xk; return; }
     double* a = L + Y.SS + row * stride;
-    if (row < k) a[mr] -= a[k] * xk;
-}
-// scatter: dl[perm[c]] = x_c for c < rank (x_c = r_c / a_cc after the back substitution), 0 beyond
-HD void lp_scatter(int c, int rank, int mr, int stride, const Lay& Y, double* L) {
-    if (c >= mr) return;
-    const double* a = L + Y.SS + c * stride;
-    const int dst = (int)L[Y.R + c];
-    L[Y.DL + dst] = c < rank ? a[mr] / a[c] : 0.0;
+    a[0] -= a[1 + k] * xk;
 }
 
 // body solve: cd = sum G_k' dl ; ds = D^-1 (d + cd)

@@ -12,46 +12,67 @@ namespace cclqr {
 
 // residual (+ Jacobians) at the point s_off with multipliers lambda - alpha dlambda already folded into C - alpha CD
 template <bool JAC>
-__device__ __forceinline__ double loop_eval(int t, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M, int s_off, double alpha) {
+__device__ __forceinline__ double loop_eval(int t, const Lay& Y, double* L, const LaneRegs& r, const MechDev* M, int s_off, double alpha PROF_ARG) {
     double part = ph_body_eval<JAC>(t, M->nb, Y, L, r, M->dt, s_off, alpha);
     __syncthreads();
+    STAMP(PF_EVAL_BODY);
     part += lp_joint_eval<JAC>(t, Y, L, r, M);
     __syncthreads();
+    STAMP(PF_EVAL_JOINT);
+    PCOUNT(PF_EVALS);
     return sqrt(group_sum<64>(part));
 }
 
+// maximum of one 64-bit key per lane over the wavefront, through the DPP crossbar (no LDS round trips): running maximum along
+// each 16-lane row, row 0 -> 1 and 2 -> 3, rows {0,1} -> {2,3}; lane 63 holds the result, read back as a wavefront-uniform value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long key_dpp_max(unsigned long long v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+    v = key_dpp_max<0x111, 0xf>(v);      // row_shr:1
+    v = key_dpp_max<0x112, 0xf>(v);      // row_shr:2
+    v = key_dpp_max<0x114, 0xf>(v);      // row_shr:4
+    v = key_dpp_max<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of each row holds the row's maximum
+    v = key_dpp_max<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = key_dpp_max<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's maximum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // S dl = r by elimination with complete pivoting up to the numerical rank; dl of the free (redundant) directions is 0
-__device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const MechDev* M) {
+__device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const MechDev* M PROF_ARG) {
     const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
     lp_schur_row(t, Y, L, M);
-    if (t < mr) L[Y.R + t] = (double)t;
+    if (t < mr) { L[Y.R + t] = (double)t; L[Y.DL + t] = 0.0; }
     __syncthreads();
-    int rank = mr;
+    STAMP(PF_SCHUR_S);
+    LoopRow R;
+    lp_row_init(R, t, mr, stride, Y, L);
+    int rank = 0;
     double first = 0.0;
     for (int k = 0; k < mr; k++) {
-        double best; int bcol, brow = t;
-        lp_pivot_search(t, k, mr, stride, Y, L, &best, &bcol);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {      // wavefront arg-max, ties to the smaller (row, column): every lane ends with the same triple
-            const double ov = __shfl_xor(best, o, 64);
-            const int orow = __shfl_xor(brow, o, 64), ocol = __shfl_xor(bcol, o, 64);
-            if (ov > best || (ov == best && (orow < brow || (orow == brow && ocol < bcol)))) { best = ov; brow = orow; bcol = ocol; }
-        }
+        const unsigned long long key = wave_max_key(R.key);            // uniform: every lane holds the same pivot
+        const double best = lp_key_value(key);
         if (k == 0) first = best;
-        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) { rank = k; break; }      // uniform: every lane holds the same pivot
-        lp_swap_rows(t, k, brow, mr, stride, Y, L);
+        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) break;
+        const int prow = lp_key_row(key), pcol = lp_key_col(key);
+        lp_col_swap(t, k, pcol, mr, stride, Y, L);
         __syncthreads();
-        lp_swap_cols(t, k, bcol, mr, stride, Y, L);
-        __syncthreads();
-        lp_eliminate(t, k, mr, stride, Y, L);
-        __syncthreads();
+        lp_elim_search(R, t, k, prow, mr, stride, Y, L);
+        rank = k + 1;
     }
-    for (int k = rank - 1; k >= 0; k--) {
-        lp_back_step(t, k, mr, stride, Y, L);
-        __syncthreads();
-    }
-    lp_scatter(t, rank, mr, stride, Y, L);
     __syncthreads();
+    STAMP(PF_TRI_FWD);
+    for (int k = rank - 1; k >= 0; k--) {
+        lp_back_step(R, t, k, (int)L[Y.R + mr + k], mr, stride, Y, L);
+        __syncthreads();
+    }
+    STAMP(PF_TRI_BWD);
 }
 
 __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
@@ -72,6 +93,10 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
         for (int e = t; e < 5 * nj; e += 64) L[Y.LAM + e] = a.lam[inst * 5 * nj + e];
     __syncthreads();
 
+#ifdef CCLQR_PROFILE
+    Prof prof;
+    prof.start();
+#endif
     int worst = 0;
     bool bad = false, dead = false;
     const long long ginst = a.inst0 + inst;
@@ -79,6 +104,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
         const int k = a.k0 + kk;
         if (a.traj)
             for (int e = t; e < nz; e += 64) a.traj[((size_t)inst * a.steps + kk) * nz + e] = L[Y.Z + e];
+        STAMP(PF_IO);
         // ---------------- feedback law (lqr.jl:89-139)
         const bool gate = (C->N <= 0) || (k < C->N);
         const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
@@ -97,25 +123,31 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
                 __syncthreads();
             }
         }
+        STAMP(PF_CONTROL);
         // ---------------- per-step invariants
         lp_forces(t, Y, L, r, M);
         lp_knot_jac(t, Y, L, r, M);
         __syncthreads();
         lp_force_map(t, Y, L, M);
         __syncthreads();
+        STAMP(PF_FORCES);
+        PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool done = dead, failed = false;
         int its = 0;
-        double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0);
+        double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);
         for (int iter = 1; iter <= NEWTON_MAXIT && !done; iter++) {
-            loop_solve(t, Y, L, M);
+            PCOUNT(PF_NEWTON_ITERS);
+            loop_solve(t, Y, L, M PROF_PASS);
             lp_body_solve(t, Y, L, M);
             __syncthreads();
+            STAMP(PF_BODY_SOLVE);
             double alpha = 1.0, normf1 = 0.0;
             const double nd = sqrt(group_sum<64>(lp_trial(t, Y, L, M, alpha)));
             __syncthreads();
+            STAMP(PF_TRIAL);
             for (int ls = 0; ls <= LINE_MAXIT; ls++) {     // halve while ||f|| grows; level LINE_MAXIT is taken as it is
-                normf1 = loop_eval<false>(t, Y, L, r, M, Y.ST, alpha);
+                normf1 = loop_eval<false>(t, Y, L, r, M, Y.ST, alpha PROF_PASS);
                 if (!(normf1 > normf0) || ls == LINE_MAXIT) break;
                 alpha *= 0.5;
                 lp_trial(t, Y, L, M, alpha);
@@ -123,10 +155,11 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
             }
             lp_accept(t, Y, L, M, alpha);
             __syncthreads();
+            STAMP(PF_ACCEPT);
             its = iter;
             if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
             if (!(normf1 < 1e300)) { done = true; failed = true; }
-            if (!done) normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0);     // Jacobians at the accepted point
+            if (!done) normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);     // Jacobians at the accepted point
         }
         if (!dead) {
             const bool conv = done && !failed;
@@ -145,7 +178,19 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
     for (int e = t; e < nz; e += 64) a.zT[inst * nz + e] = L[Y.Z + e];
     if (a.lam) for (int e = t; e < 5 * nj; e += 64) a.lam[inst * 5 * nj + e] = L[Y.LAM + e];
     if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
+#ifdef CCLQR_PROFILE
+    prof.stamp(PF_IO);
+    prof.flush();
+#endif
 }
+
+#ifdef CCLQR_PROFILE
+extern "C" int cclqr_prof_read_loop(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PF_N);
+    if (e == hipSuccess && reset) { unsigned long long z[PF_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return e == hipSuccess ? PF_N : -1;
+}
+#endif
 
 size_t loop_lds_bytes(int nb, int nj) { return (size_t)make_loop_layout(nb, nj).total * sizeof(double); }
 

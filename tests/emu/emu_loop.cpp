@@ -35,28 +35,25 @@ void loop_solve(LoopInst& I) {
     double* L = I.L;
     const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
     for (int t = 0; t < 64; t++) lp_schur_row(t, Y, L, M);
-    for (int t = 0; t < mr; t++) L[Y.R + t] = (double)t;
-    int rank = mr;
+    for (int t = 0; t < mr; t++) { L[Y.R + t] = (double)t; L[Y.DL + t] = 0.0; }
+    LoopRow R[64];
+    for (int t = 0; t < 64; t++) lp_row_init(R[t], t, mr, stride, Y, L);
+    int rank = 0;
     double first = 0.0;
     for (int k = 0; k < mr; k++) {
-        double best = -1.0; int brow = 0, bcol = 0;
-        for (int t = 0; t < 64; t++) {     // the wavefront arg-max: ties to the smaller (row, column)
-            double v; int c;
-            lp_pivot_search(t, k, mr, stride, Y, L, &v, &c);
-            if (v > best) { best = v; brow = t; bcol = c; }
-        }
+        unsigned long long key = 0ull;
+        for (int t = 0; t < 64; t++) if (R[t].key > key) key = R[t].key;       // the wavefront's maximum key
+        const double best = lp_key_value(key);
         if (k == 0) first = best;
-        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) { rank = k; break; }
-        for (int t = 0; t < 64; t++) lp_swap_rows(t, k, brow, mr, stride, Y, L);
-        for (int t = 0; t < 64; t++) lp_swap_cols(t, k, bcol, mr, stride, Y, L);
-        for (int t = 0; t < 64; t++) lp_eliminate(t, k, mr, stride, Y, L);
+        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) break;
+        const int prow = lp_key_row(key), pcol = lp_key_col(key);
+        for (int t = 0; t < 64; t++) lp_col_swap(t, k, pcol, mr, stride, Y, L);
+        // lanes run in lock step on the GPU; the pivot row's lane only retires here and nobody writes that row, so a serial sweep is equivalent
+        for (int t = 0; t < 64; t++) lp_elim_search(R[t], t, k, prow, mr, stride, Y, L);
+        rank = k + 1;
     }
-    for (int k = rank - 1; k >= 0; k--) {
-        // lanes run in lock step on the GPU (every lane reads the pivot row's right-hand side before row k itself is left alone): row
-        // k is not written in step k, so a serial sweep is equivalent
-        for (int t = 0; t < 64; t++) lp_back_step(t, k, mr, stride, Y, L);
-    }
-    for (int t = 0; t < 64; t++) lp_scatter(t, rank, mr, stride, Y, L);
+    for (int k = rank - 1; k >= 0; k--)
+        for (int t = 0; t < 64; t++) lp_back_step(R[t], t, k, (int)L[Y.R + mr + k], mr, stride, Y, L);
 }
 }  // namespace
 
