@@ -64,3 +64,11 @@ def upright_setpoint(n):
     for i in range(1, n + 1):
         zd[i, 2] = i - 0.5
     return zd
+
+
+def free_port():
+    """a TCP port nobody is listening on right now (rendezvous of the two-rank tests): a fixed port can still be held by an earlier run"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -371,7 +371,8 @@ def test_two_ranks_chunked_rollout_and_trajectory_collection(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(_SHARDED_WORKER % {"root": root})
-    port = 29700 + os.getpid() % 200
+    from conftest import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=170)

@@ -140,7 +140,8 @@ def test_gloo_world2_shard_and_gather(tmp_path):
     bit for bit) and the final states on rank 0"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER % {"root": ROOT})
-    port = 29600 + os.getpid() % 300
+    from conftest import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
