@@ -72,3 +72,32 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def long_and_short_chain_forest(cclqr):
+    """a 13-link cartpole chain and a 3-link one hanging off the same origin, bodies interleaved in the caller's numbering; returns
+    (tables, z0 [1][nb][13], zd [nb][13], K [20][2][12 nb], controlled joints)"""
+    ea, eb = cclqr.examples.cartpole_n(12), cclqr.examples.cartpole_n(2)
+    ta, tb = ea["mech"].tables(), eb["mech"].tables()
+    nb = ta.nb + tb.nb
+    order = list(np.random.default_rng(5).permutation(nb))
+    ia, ib = order[:ta.nb], order[ta.nb:]
+    mass, inertia = np.zeros(nb), np.zeros((nb, 9))
+    parent, child, typ = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+    p1, p2, axis, qoff = np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 4))
+    for ids, tt in ((ia, ta), (ib, tb)):
+        for k in range(tt.nb):
+            j = ids[k]
+            mass[j], inertia[j] = tt.mass[k], tt.inertia[k]
+            parent[j] = -1 if tt.parent[k] < 0 else ids[tt.parent[k]]
+            child[j], typ[j], p1[j], p2[j], axis[j], qoff[j] = ids[k], tt.type[k], tt.p1[k], tt.p2[k], tt.axis[k], tt.qoff[k]
+    t2 = cclqr.MechTables(nb, nb, ta.dt, ta.g, mass, inertia, parent, child, typ, p1, p2, axis, qoff)
+    rng = np.random.default_rng(11)
+    phi = rng.uniform(-0.2, 0.2, (1, 12)); phi[:, 0] += np.pi
+    za = cclqr.examples.cartpole_states(12, [0.1], phi)[0]
+    zb = cclqr.examples.cartpole_states(2, [-0.3], [[-0.15, 0.05]])[0]
+    z0 = np.zeros((1, nb, 13))
+    z0[0, ia], z0[0, ib] = za, zb
+    zd = z0[0].copy(); zd[:, 7:] = 0
+    K = rng.normal(size=(20, 2, 12 * nb)) * 0.05
+    return t2, z0, zd, K, [int(ia[0]), int(ib[0])]

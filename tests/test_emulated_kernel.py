@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import scipy.linalg as sl
 
-from conftest import hanging_setpoint, upright_setpoint
+from conftest import hanging_setpoint, long_and_short_chain_forest, upright_setpoint
 
 dp = C.POINTER(C.c_double)
 
@@ -198,6 +198,17 @@ def test_emulated_two_chains(cclqr, orc, emu):
     _, traj, st = emu_rollout(emu, orc, t2, c, z0, 30)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-10
+
+
+def test_emulated_forest_long_and_short_chain(cclqr, orc, emu):
+    """a 13-link chain (takes the odd-even reduction level: 32 lanes, 16-link layout) next to a 3-link chain (plain two-front sweep) in
+    one mechanism, bodies interleaved in the caller's numbering: the level's lane map must leave the second chain alone"""
+    t2, z0, zd, K, cj = long_and_short_chain_forest(cclqr)
+    c = orc.ctrl_desc(t2.nb, cj, K=K, N=21, zd=zd)
+    _, traj_o, st_o = orc.rollout(t2, c, z0, 20, record=True)
+    _, traj, st = emu_rollout(emu, orc, t2, c, z0, 20)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-9
 
 
 def test_emulated_pid(cclqr, orc, emu):

@@ -276,6 +276,23 @@ def test_per_instance_controller_tables(cclqr, orc):
             capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=20)
 
 
+def test_forest_with_a_long_and_a_short_chain(cclqr, orc):
+    """one mechanism, two chains: 13 links (odd-even reduction level ahead of the sweep) and 3 links (plain sweep), interleaved body
+    numbering, one controlled joint each"""
+    from conftest import long_and_short_chain_forest
+    capi = cclqr._capi
+    t2, z0, zd, K, cj = long_and_short_chain_forest(cclqr)
+    z0 = np.repeat(z0, 3, 0)
+    z0[1, :, 7:10] += 0.01
+    oc = orc.ctrl_desc(t2.nb, cj, K=K, N=21, zd=zd)
+    zT_o, traj_o, st_o = orc.rollout(t2, oc, z0[:1], 20, record=True)
+    mech = capi.MechHandle(t2)
+    ctrl = capi.CtrlHandle(mech, cj, K=K, N=21, zd=zd)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, 20, record=True)
+    assert (st_o > 0).all() and (st > 0).all() and mech.geometry()[0] == 32
+    assert np.abs(traj[0] - traj_o[0]).max() < TOL and np.array_equal(traj[0], traj[2])
+
+
 def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     """examples/lqr_deltabot.jl:25-53 through the C-ABI (`rollout_loop_kernel`, csrc/rollout_loop.hip): 33 constraint rows on 30 body
     coordinates.  (i) the reference's own number: Fτd = +-6.7879484 on the platform joints holds the script's pose at rest; (ii) with
