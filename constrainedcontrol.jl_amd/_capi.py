@@ -14,7 +14,7 @@ OK, EINVAL, ESINGULAR, ENOCONV, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQR_ENOCONV", EHIP: "CCLQR_EHIP", EUNSUPPORTED: "CCLQR_EUNSUPPORTED"}
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
-           "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
+           "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex", "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
@@ -242,6 +242,20 @@ def linearize(mech, zd, ctrl_joint, Fd=None):
     A, Bu, Bl, G = np.zeros((nk, mx, mx)), np.zeros((nk, mx, mu)), np.zeros((nk, mx, ml)), np.zeros((nk, ml, mx))
     check(lib().cclqr_linearize(mech.ptr, C.c_int32(nk), _d(zd), C.c_int32(mu), _i(cj), _d(Fd), _d(A), _d(Bu), _d(Bl), _d(G)))
     return A, Bu, Bl, G
+
+
+def linearize_projected(mech, zd, ctrl_joint, Fd=None, h=0.0):
+    """projected linear model (A', D) of the device's constrained step map by central differences: zd [nk][nb][13] -> A' [nk][mx][mx],
+    D [nk][mx][mu] (cclqr_linearize_projected; any topology, the only linearisation of closed-loop mechanisms)"""
+    t = mech.tables
+    zd = f64(zd).reshape(-1, t.nb, 13)
+    nk = zd.shape[0]
+    cj = i32(ctrl_joint).reshape(-1)
+    mu, mx = len(cj), 12 * t.nb
+    Fd = f64(np.zeros((nk, mu)) if Fd is None else Fd).reshape(nk, mu)
+    Ap, D = np.zeros((nk, mx, mx)), np.zeros((nk, mx, mu))
+    check(lib().cclqr_linearize_projected(mech.ptr, C.c_int32(nk), _d(zd), C.c_int32(mu), _i(cj), _d(Fd), C.c_double(float(h)), _d(Ap), _d(D)))
+    return Ap, D
 
 
 def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0):

@@ -264,6 +264,90 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     return CCLQR_OK;
 }
 
+// ---- projected linear model by central differences of the DEVICE step map (any topology; the only linearisation of closed loops)
+static inline void h_qmul(const double* a, const double* b, double* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+// error coordinates of state z about z0, per body x, v, q~ = vec(q0^-1 q), w  (lqr.jl:92-103)
+static inline void h_state_error(int nb, const double* z, const double* z0, double* e) {
+    for (int b = 0; b < nb; b++) {
+        const double* p = z + 13 * b; const double* r = z0 + 13 * b;
+        const double qc[4] = {r[3], -r[4], -r[5], -r[6]};
+        double qe[4];
+        h_qmul(qc, p + 3, qe);
+        for (int i = 0; i < 3; i++) { e[12 * b + i] = p[i] - r[i]; e[12 * b + 3 + i] = p[7 + i] - r[7 + i]; e[12 * b + 6 + i] = qe[1 + i]; e[12 * b + 9 + i] = p[10 + i] - r[10 + i]; }
+    }
+}
+extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
+                                         double h, double* Ap, double* D) {
+    if (!m || !zd || !Ap || (mu > 0 && (!ctrl_joint || !D))) return fail(CCLQR_EINVAL, "null argument");
+    if (nk < 0 || mu < 0 || mu > m->nj) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
+    if (nk == 0) return CCLQR_OK;
+    if (!(h > 0.0)) h = 1e-6;
+    const int nb = m->nb, mx = 12 * nb;
+    const size_t nz = 13 * (size_t)nb;
+    const int per = 1 + 2 * mx + 2 * mu;            // nominal, +-h in every state error coordinate, +-h in every input
+    const size_t n = (size_t)nk * per;
+    std::vector<double> z0(n * nz), fd(n * (size_t)(mu > 0 ? mu : 1), 0.0), zdum(n * nz, 0.0), zT(n * nz);
+    std::vector<int32_t> st(n);
+    for (size_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) zdum[i * nz + 13 * b + 3] = 1.0;
+    for (int k = 0; k < nk; k++) {
+        const double* zk = zd + (size_t)k * nz;
+        for (int q = 0; q < per; q++) {
+            double* z = &z0[((size_t)k * per + q) * nz];
+            memcpy(z, zk, nz * sizeof(double));
+            for (int i = 0; i < mu; i++) fd[((size_t)k * per + q) * mu + i] = Fd ? Fd[(size_t)k * mu + i] : 0.0;
+            if (q >= 1 && q <= 2 * mx) {
+                const int col = (q - 1) >> 1, b = col / 12, e = col % 12;
+                const double s = ((q - 1) & 1) ? -h : h;
+                double* p = z + 13 * b;
+                if (e < 3) p[e] += s;
+                else if (e < 6) p[7 + e - 3] += s;
+                else if (e < 9) {                       // q = qd (sqrt(1 - s^2), s e_i): vec(qd^-1 q) = s e_i exactly
+                    double dq[4] = {sqrt(1.0 - s * s), 0.0, 0.0, 0.0}, qn[4];
+                    dq[1 + e - 6] = s;
+                    h_qmul(zk + 13 * b + 3, dq, qn);
+                    for (int i = 0; i < 4; i++) p[3 + i] = qn[i];
+                } else p[10 + e - 9] += s;
+            } else if (q > 2 * mx) {
+                const int i = (q - 1 - 2 * mx) >> 1;
+                fd[((size_t)k * per + q) * mu + i] += ((q - 1) & 1) ? -h : h;
+            }
+        }
+    }
+    cclqr_ctrl_desc cd;
+    memset(&cd, 0, sizeof(cd));
+    cd.mu = mu; cd.ctrl_joint = ctrl_joint; cd.nK = 0; cd.N = 0; cd.K = nullptr; cd.nsp = 1; cd.zd = zdum.data(); cd.Fd = mu > 0 ? fd.data() : nullptr;
+    cd.n_ctrl = (int32_t)n;
+    cclqr_ctrl* c = nullptr;
+    int rc = cclqr_ctrl_create(m, &cd, &c);
+    if (rc != CCLQR_OK) return rc;
+    rc = cclqr_rollout(m, c, (int64_t)n, 1, 1, z0.data(), nullptr, nullptr, zT.data(), st.data());
+    cclqr_ctrl_destroy(c);
+    if (rc != CCLQR_OK) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (st[i] <= 0) return fail(CCLQR_ENOCONV, "Newton did not converge at a perturbed setpoint of knot " + std::to_string(i / per));
+    std::vector<double> ep(mx), em(mx);
+    for (int k = 0; k < nk; k++) {
+        const double* znom = &zT[((size_t)k * per) * nz];
+        for (int col = 0; col < mx + mu; col++) {
+            const size_t qp = (size_t)k * per + 1 + 2 * col, qm = qp + 1;
+            h_state_error(nb, &zT[qp * nz], znom, ep.data());
+            h_state_error(nb, &zT[qm * nz], znom, em.data());
+            for (int r = 0; r < mx; r++) {
+                const double v = (ep[r] - em[r]) / (2.0 * h);
+                if (col < mx) Ap[((size_t)k * mx + r) * mx + col] = v;
+                else D[((size_t)k * mx + r) * mu + (col - mx)] = v;
+            }
+        }
+    }
+    return CCLQR_OK;
+}
+
 // shared tail of the two dlqr entry points: run the recursion on device-resident (A,Bu,Bl,G), download K and kbreak
 static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varying, double tol, const double* dA, const double* dBu,
                        const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak,

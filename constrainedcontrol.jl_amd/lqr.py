@@ -108,9 +108,18 @@ class LQR(Controller):
         self.zd = _pack_setpoint(nb, xd, vd, qd, ωd)[None]
         self.Fd = np.array([f[0] for f in self.Fτd]).reshape(1, -1)
         dev = _device_mech(mechanism)
-        # linearize (lqr.jl:63)
-        A, Bu, Bl, G = _capi.linearize(dev, self.zd, self.ctrl_joints, self.Fd)
-        self.A, self.Bu, self.Bλ, self.G = A[0], Bu[0], Bl[0], G[0]
+        self.projected = bool(getattr(mechanism, "has_loops", False))
+        if self.projected:
+            # closed loops (examples/lqr_deltabot.jl:47-53): G Bλ of lqr.jl:151 is singular (redundant constraint rows), but the pair the
+            # recursion works with -- A' = A - Bλ (G Bλ)^-1 G A, D = Bu - Bλ (G Bλ)^-1 G Bu -- is unique: it is the Jacobian of the
+            # constrained one-step map, taken from the device by central differences, and the recursion runs on it with no multipliers
+            mx = 12 * nb
+            Ap, D = _capi.linearize_projected(dev, self.zd, self.ctrl_joints, self.Fd)
+            self.A, self.Bu, self.Bλ, self.G = Ap[0], D[0], np.zeros((mx, 0)), np.zeros((0, mx))
+        else:
+            # linearize (lqr.jl:63)
+            A, Bu, Bl, G = _capi.linearize(dev, self.zd, self.ctrl_joints, self.Fd)
+            self.A, self.Bu, self.Bλ, self.G = A[0], Bu[0], Bl[0], G[0]
         self._finish(self.A, self.Bu, self.Bλ, self.G, Q, [np.asarray(r, dtype=np.float64) for r in R], horizon, mechanism.Δt)
 
     def _finish(self, A, Bu, Bl, G, Q, R, horizon, Δt):
@@ -123,7 +132,7 @@ class LQR(Controller):
             Ntemp = N
         else:
             Ntemp = int(math.ceil(10 / Δt))                 # lqr.jl:26: 10 s as maximal horizon for Inf
-        if G.shape[0] == 0 and N == math.inf:
+        if G.shape[0] == 0 and N == math.inf and not getattr(self, "projected", False):
             # lqr.jl:33 calls dlqr(A,Bu,Q,R,N) which binds N=Inf to the Δt method of util.jl:50 — a defect, not reproduced
             raise ValueError("unconstrained infinite-horizon LQR is not reachable in the reference (lqr.jl:33)")
         K, kbreak = _capi.riccati(A, Bu, Bl, G, self.Q, self.R, Ntemp)   # lqr.jl:36 / :39

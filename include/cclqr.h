@@ -103,6 +103,14 @@ int cclqr_ctrl_destroy(cclqr_ctrl *c);
 int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
                     double *A, double *Bu, double *Bl, double *G);
 
+/* The same linear model with the multipliers eliminated -- A' = A - Bλ (G Bλ)^-1 G A and D = Bu - Bλ (G Bλ)^-1 G Bu, the projected pair the
+ * recursion of lqr.jl:151-170 works with -- obtained as central differences (step h in every error coordinate x, v, q~, ω of lqr.jl:92-103
+ * and every input; h <= 0: 1e-6) of the DEVICE's own constrained one-step map, one launch of nk (1 + 24 nb + 2 mu) single-step rollouts.
+ * Defined for every topology cclqr_mech_create takes, and the only linearisation of closed-loop mechanisms (examples/lqr_deltabot.jl:47-53),
+ * where G Bλ is singular but A', D are still unique; feed them to cclqr_riccati with ml = 0.  Ap [nk][mx][mx], D [nk][mx][mu]. Host pointers. */
+int cclqr_linearize_projected(const cclqr_mech *m, int32_t nk, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
+                              double h, double *Ap, double *D);
+
 /* dlqr(A, Bu, Bλ, G, Q, R, N) -- lqr.jl:141-184, batched over nprob independent problems (nprob = 1 in the reference).
  * Q [mx][mx] and R [mu][mu] are the already Δt-scaled block-diagonal weights (lqr.jl:18-19).
  * K [nprob][N-1][mu][mx]; kbreak [nprob] = value of the loop index k after the loop (lqr.jl:172-181). Host pointers. */

@@ -45,6 +45,16 @@ const REVOLUTE = Int32(0)
 const PRISMATIC = Int32(1)
 const FIXED_ORIENTATION = Int32(2)     # FixedOrientation(a, b; qoffset): one Rotational3 constraint (examples/lqr_deltabot.jl:25)
 
+# Closed-loop mechanisms (examples/lqr_deltabot.jl): `linearize_projected` returns A' = A - Bλ (G Bλ)^-1 G A and D = Bu - Bλ (G Bλ)^-1 G Bu
+# (lqr.jl:151) from cclqr_linearize_projected; pass them to `riccati` with empty Bλ (mx x 0) and G (0 x mx).
+function linearize_projected(mech::Ptr{Cvoid}, zd::Vector{Float64}, nb::Int, ctrl_joint::Vector{Int32}, Fd::Vector{Float64}; h = 0.0)
+    mx, mu = 12nb, length(ctrl_joint)
+    Ap, D = zeros(mx * mx), zeros(mx * mu)
+    check(ccall((:cclqr_linearize_projected, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+                mech, Int32(1), zd, Int32(mu), ctrl_joint, Fd, h, Ap, D))
+    return permutedims(reshape(Ap, mx, mx)), permutedims(reshape(D, mu, mx))      # row-major on the C side
+end
+
 lasterror() = unsafe_string(ccall((:cclqr_last_error, lib), Cstring, ()))
 function check(rc::Integer)
     rc == 0 && return nothing

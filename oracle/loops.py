@@ -149,6 +149,50 @@ class LoopMechanism:
         raise RuntimeError("dense-KKT Newton did not converge: |f| = %g" % np.linalg.norm(f(x)))
 
 
+def state_error(z, z0):
+    """error coordinates per body x, v, q~ = vec(q0^-1 q), w (lqr.jl:92-103) of z [nb][13] about z0"""
+    e = np.zeros((len(z), 12))
+    for b in range(len(z)):
+        qe = qmul(np.concatenate([[z0[b, 3]], -z0[b, 4:7]]), z[b, 3:7])
+        e[b] = np.concatenate([z[b, 0:3] - z0[b, 0:3], z[b, 7:10] - z0[b, 7:10], qe[1:], z[b, 10:13] - z0[b, 10:13]])
+    return e.ravel()
+
+
+def projected_linear_model(lm, z, u, ctrl, h=1e-6):
+    """A' [mx][mx], D [mx][mu]: Jacobians of the constrained one-step map of `lm` about (z, u) in the error coordinates of lqr.jl:92-103, by
+    central differences (the quantity the recursion of lqr.jl:151-170 works with once the multipliers are eliminated; for a tree it equals
+    A - Bl (G Bl)^-1 G A, Bu - Bl (G Bl)^-1 G Bu of the reference's linearsystem).  ctrl: indices of the controlled joints."""
+    nb, mx = lm.nb, 12 * lm.nb
+    lam0 = np.zeros(lm.nrows)
+    step = lambda zz, uu: lm.step(zz, lam0, uu, tol=1e-13)[0]
+    znom = step(z, u)
+    Ap, D = np.zeros((mx, mx)), np.zeros((mx, len(ctrl)))
+    for col in range(mx + len(ctrl)):
+        out = []
+        for sgn in (+1.0, -1.0):
+            zz, uu = z.copy(), u.copy()
+            if col < mx:
+                b, e = divmod(col, 12)
+                if e < 3:
+                    zz[b, e] += sgn * h
+                elif e < 6:
+                    zz[b, 7 + e - 3] += sgn * h
+                elif e < 9:
+                    dq = np.array([np.sqrt(1 - h * h), 0.0, 0.0, 0.0]); dq[1 + e - 6] = sgn * h
+                    zz[b, 3:7] = qmul(z[b, 3:7], dq)
+                else:
+                    zz[b, 10 + e - 9] += sgn * h
+            else:
+                uu[ctrl[col - mx]] += sgn * h
+            out.append(state_error(step(zz, uu), znom))
+        v = (out[0] - out[1]) / (2 * h)
+        if col < mx:
+            Ap[:, col] = v
+        else:
+            D[:, col - mx] = v
+    return Ap, D
+
+
 def place(z, a, b, p1, p2, dq):
     """setPosition!(a, b; p1, p2, Δq) (examples/lqr_deltabot.jl:37-41): q_b = q_a Δq ; x_b = x_a + R(q_a) p1 - R(q_b) p2"""
     xa = z[a, 0:3] if a >= 0 else np.zeros(3)

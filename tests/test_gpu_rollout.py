@@ -333,7 +333,7 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     zT1, traj1, _ = capi.rollout(mech, one, z0[None], steps, record=True)
     assert np.array_equal(zT1[0], zT[3]) and np.array_equal(traj1[0], traj[3])
     with pytest.raises(capi.CclqrError) as e:
-        capi.linearize(mech, zd, cj)
+        capi.linearize(mech, zd, cj)          # Bλ and G separately: not for redundant constraint rows (cclqr_linearize_projected is)
     assert e.value.code == -5
 
 

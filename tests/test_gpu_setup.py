@@ -246,6 +246,49 @@ def test_sawyer_config4_pipeline(cclqr, orc):
     assert np.abs(st.z - traj).max() < 1e-9
 
 
+def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
+    """examples/lqr_deltabot.jl:47-53 end to end.  The redundant constraint rows of a closed loop make G Bλ (lqr.jl:151) singular, but the
+    pair the recursion works with -- A' = A - Bλ (G Bλ)^-1 G A, D = Bu - Bλ (G Bλ)^-1 G Bu -- is the Jacobian of the constrained one-step
+    map and stays unique; `cclqr_linearize_projected` takes it from the device by central differences.
+    (i) on a TREE it equals the projection of the analytic `cclqr_linearize` output to 1e-7 (relative 1e-9);
+    (ii) on the deltabot it equals the same differences of the ORACLE's dense-KKT step (oracle/loops.py) to 1e-6, and the gains of the
+    recursion (lqr.jl:141-184 with no multipliers left) equal the oracle's to 1e-6 relative;
+    (iii) the LQR holds the mechanism: from a state 0.13 off the setpoint the closed loop returns to it, the open loop falls."""
+    from oracle import loops
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(3)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, 3)
+    mh = capi.MechHandle(t)
+    A, Bu, Bl, G = (M[0] for M in capi.linearize(mh, zd[None], [0], np.zeros((1, 1))))
+    AD = np.hstack([A, Bu]) - Bl @ np.linalg.solve(G @ Bl, G @ np.hstack([A, Bu]))
+    Ap, D = capi.linearize_projected(mh, zd[None], [0], np.zeros((1, 1)))
+    assert np.abs(Ap[0] - AD[:, :48]).max() < 1e-7 and np.abs(D[0] - AD[:, 48:]).max() < 1e-9 and np.abs(AD).max() > 100
+    # deltabot
+    ex = cclqr.examples.deltabot()
+    mech = ex["mech"]
+    z0 = mech.state()
+    ids = [cclqr.getid(b) for b in mech.bodies]
+    Q, R = [np.eye(12) for _ in ids], [np.eye(1) * 0.1 for _ in ex["eqcids"]]
+    lq = cclqr.LQR(mech, ids, ex["eqcids"], Q, R, 10.0, xd=[z0[i, 0:3] for i in range(5)], qd=[z0[i, 3:7] for i in range(5)],
+                   Fτd=[[ex["Fd"][0]], [ex["Fd"][1]]])
+    assert lq.projected and lq.K.shape == (999, 2, 60) and lq.G.shape == (0, 60)
+    lm, z, u = loops.deltabot()
+    Ao, Do = loops.projected_linear_model(lm, z, u, [0, 1])
+    assert np.abs(lq.A - Ao).max() < 1e-6 and np.abs(lq.Bu - Do).max() < 1e-6 and np.abs(Ao).max() > 1
+    Ko, kbo = orc.riccati(Ao, Do, np.zeros((60, 0)), np.zeros((0, 60)), lq.Q, lq.R, 1000)
+    assert int(lq.kbreak) == kbo and np.abs(lq.K - Ko).max() < 1e-6 * np.abs(Ko).max()
+    # closed loop vs open loop from a consistent perturbed state (eight steps with 90 % of the holding torque)
+    weak = capi.CtrlHandle(mech._cclqr_handle, lq.ctrl_joints, K=None, N=0, zd=z0[None], Fd=0.9 * ex["Fd"].reshape(1, 2))
+    zp, _, st = capi.rollout(mech._cclqr_handle, weak, z0[None], 8)
+    assert st[0] > 0 and 0.05 < np.abs(zp[0] - z0).max() < 0.3
+    res = cclqr.simulate(mech, 3.0, lq, record=False, z0=zp)
+    assert res.status[0] > 0 and np.abs(res.zT[0] - z0).max() < 5e-3
+    hold = cclqr.OpenLoop(mech, ex["eqcids"], np.tile(ex["Fd"], (300, 1)))
+    free = cclqr.simulate(mech, cclqr.Storage(300, 5), hold, record=False, z0=zp)
+    assert free.status[0] < 0 or np.abs(free.zT[0] - z0).max() > 20 * np.abs(res.zT[0] - z0).max()      # the holding inputs alone do not bring it back
+
+
 def test_minimal_coordinate_lqr_prismatic(cclqr, orc):
     """examples/lqr_prismatic.jl: LQR(mech, getid.(constraints), getid.(constraints), Q::Vector, R::Vector, 10.)  (lqr.jl:68-86)"""
     ex = cclqr.examples.prismatic_slider()

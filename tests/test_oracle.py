@@ -504,6 +504,22 @@ def test_dense_kkt_stepper_reproduces_the_tree_oracle(cclqr, orc):
     assert np.abs(z - zl).max() < 1e-11 and np.abs(lam - laml).max() < 1e-8
 
 
+def test_projected_linear_model_by_differences_equals_the_analytic_projection_on_a_tree(cclqr, orc):
+    """oracle/loops.py::projected_linear_model (central differences of the dense-KKT step in the error coordinates of lqr.jl:92-103) against
+    the projection A - Bl (G Bl)^-1 G A, Bu - Bl (G Bl)^-1 G Bu of the oracle's ANALYTIC linearsystem restatement, on the double-pole
+    cartpole about its hanging equilibrium: the quantity that stays defined when a closed loop makes G Bl singular (lqr_deltabot.jl)"""
+    from oracle import loops
+    ex = cclqr.examples.cartpole_n(2)
+    t = ex["mech"].tables()
+    joints = [loops.Joint(int(t.type[j]), int(t.parent[j]), int(t.child[j]), t.axis[j], t.p1[j], t.p2[j], t.qoff[j]) for j in range(t.ne)]
+    lm = loops.LoopMechanism(t.mass, t.inertia.reshape(-1, 3, 3), joints, dt=t.dt, g=t.g)
+    zd = cclqr.examples.cartpole_states(2, [0.0], np.array([[np.pi, 0.0]]))[0]
+    A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
+    AD = np.hstack([A, Bu]) - Bl @ np.linalg.solve(G @ Bl, G @ np.hstack([A, Bu]))
+    Ap, D = loops.projected_linear_model(lm, zd.copy(), np.zeros(t.ne), [0])
+    assert np.abs(Ap - AD[:, :36]).max() < 1e-6 and np.abs(D - AD[:, 36:]).max() < 1e-8 and np.abs(AD).max() > 100
+
+
 def test_deltabot_holding_torque_is_the_references_number():
     """The one number the reference holds for the dynamics (examples/lqr_deltabot.jl:53): `Fτd = [[[6.7879484]];[[-6.7879484]]]`, the
     feed-forward torques at the two platform joints that hold the closed-loop delta mechanism at the pose of :37-41 against gravity.
