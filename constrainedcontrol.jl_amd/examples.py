@@ -234,4 +234,56 @@ def deltabot():
     setPosition(lowerlegl, upperlegl, p1=pll, p2=-pul, Δq=RotX(-np.pi / 2))                                      # :39
     setPosition(lowerlegr, upperlegr, p1=pll, p2=-pul, Δq=RotX(np.pi / 2))                                       # :40
     setPosition(upperlegl, platform, p1=pul, p2=pp, Δq=RotX(3 * np.pi / 4))                                      # :41
-    return {"mech": mech, "eqcids": [getid(platl), getid(platr)], "Fd": np.array([6.7879484, -6.7879484])}      # :53
+    Q = [np.zeros((12, 12)) for _ in range(5)]                                                                 # :46-50: only the platform's y, z
+    Q[4][1, 1] = Q[4][2, 2] = 10.0                                                                             # position and velocity are weighted
+    Q[4][4, 4] = Q[4][5, 5] = 1.0
+    R = [np.ones((1, 1)) * 0.1 for _ in range(2)]                                                              # :51
+    return {"mech": mech, "eqcids": [getid(platl), getid(platr)], "Fd": np.array([6.7879484, -6.7879484]),     # :53
+            "Q": Q, "R": R, "links": links, "origin": origin, "L": L}
+
+
+def deltabot_initial_states(ex, stride=1):
+    """the valid initial conditions of examples/lqr_deltabot.jl:56-136: platform positions (y, z) on the script's 101 x 101 grid over
+    [-1.5 L, 1.5 L]^2 with z >= 0 whose two hip points lie between 0.5 L and 1.5 L from the floor joints, the leg angles from the two
+    triangles (floor joint, knee, hip), placed with the script's setPosition! sequence (:139-143).  The script simulates ONE of them
+    (i = 97); here they are a batch.  Returns (z0 [nc][5][13], yz [nc][2]); stride > 1 keeps every stride-th condition."""
+    L = ex["L"]
+    mech, origin = ex["mech"], ex["origin"]
+    lowerlegl, lowerlegr, upperlegl, upperlegr, platform = ex["links"]
+    pll, pul, p3 = np.array([0, 0, L / 2]), np.array([0, 0, L / 4]), L / 4 * np.sqrt(2)
+    grid = -1.5 * L + 3 * L * np.arange(101) / 100.0
+    yz = [(y, z) for z in grid if z >= 0 for y in grid
+          if 0.5 * L <= np.hypot(y + p3, z) <= 1.5 * L and 0.5 * L <= np.hypot(y - p3, z) <= 1.5 * L]
+    yz = np.array(yz)[::stride]
+    a, b = L, L / 2
+
+    def triangle(py, pz):
+        c = np.hypot(py, pz)
+        beta = np.arccos((a * a + c * c - b * b) / (2 * a * c))
+        gamma = np.arccos((a * a + b * b - c * c) / (2 * a * b))
+        with np.errstate(divide="ignore"):
+            delta = abs(np.arctan(np.float64(py) / np.float64(pz)))
+        return beta, gamma, delta
+
+    saved = mech.state()
+    out = []
+    for y, z in yz:
+        ly, ry = y - p3, y + p3
+        bl, gl, dl = triangle(ly, z)
+        br, gr, dr = triangle(ry, z)
+        if ly <= 0 and z >= 0:   al = (dl + bl, -np.pi + gl)                                                   # :117-125
+        elif ly >= 0 and z >= 0: al = (-dl + bl, -np.pi + gl)
+        elif ly >= 0 and z <= 0: al = (-np.pi + dl - bl, np.pi - gl)
+        else:                    al = (-np.pi - dl - bl, np.pi - gl)
+        if ry <= 0 and z >= 0:   ar = (dr - br, np.pi - gr)                                                    # :127-135
+        elif ry >= 0 and z >= 0: ar = (-dr - br, np.pi - gr)
+        elif ry >= 0 and z <= 0: ar = (-np.pi + dr + br, -np.pi + gr)
+        else:                    ar = (-np.pi - dr + br, -np.pi + gr)
+        setPosition(origin, lowerlegl, p2=-pll, Δq=RotX(al[0]))                                                # :139-143
+        setPosition(origin, lowerlegr, p2=-pll, Δq=RotX(ar[0]))
+        setPosition(lowerlegl, upperlegl, p1=pll, p2=-pul, Δq=RotX(al[1]))
+        setPosition(lowerlegr, upperlegr, p1=pll, p2=-pul, Δq=RotX(ar[1]))
+        setPosition(origin, platform, p1=np.array([0.0, y, z]), Δq=RotX(np.pi / 2))
+        out.append(mech.state())
+    mech.set_state(saved)
+    return np.array(out), yz

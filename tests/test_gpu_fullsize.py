@@ -287,3 +287,38 @@ def test_cfg4_distinct_setpoints_batched_lqr_drives_batched_rollout(cclqr, orc):
     oc = orc.ctrl_desc(7, cj, K=Kinf[sel], N=0, zd=zd[sel][:, None], n_ctrl=len(sel))
     zo, _, sto = orc.rollout(t, oc, z0[sel], steps)
     assert (sto > 0).all() and np.abs(zo - zT[sel]).max() < 1e-9
+
+
+def test_deltabot_script_as_a_batch(cclqr, orc):
+    """examples/lqr_deltabot.jl end to end on the device: the script's LQR (its Q and R, infinite horizon, the holding inputs
+    +-6.7879484; projected linear model, lqr.py) and ALL 1973 valid initial conditions of its grid (:56-136; the script simulates one,
+    i = 97) for 10 s on the closed-loop rollout kernel.  The controller of the script works: its own case and 99 % of the grid are brought
+    back to the setpoint; the first steps of the script's case equal the oracle's dense-KKT stepper under the same feedback law."""
+    import math
+    from oracle import loops
+    from test_emulated_kernel import loop_feedback_reference
+    ex = cclqr.examples.deltabot()
+    mech = ex["mech"]
+    z00 = mech.state()
+    ids = [cclqr.getid(b) for b in mech.bodies]
+    lq = cclqr.LQR(mech, ids, ex["eqcids"], ex["Q"], ex["R"], math.inf, xd=[z00[i, 0:3] for i in range(5)], qd=[z00[i, 3:7] for i in range(5)],
+                   Fτd=[[ex["Fd"][0]], [ex["Fd"][1]]])
+    assert lq.converged and lq.K.shape == (1, 2, 60) and lq.N == 0
+    z0, yz = cclqr.examples.deltabot_initial_states(ex)
+    assert z0.shape == (1973, 5, 13)
+    lm, z, u = loops.deltabot()
+    assert max(np.abs(lm.constraints(zz)).max() for zz in z0[::97]) < 1e-14          # the script's inverse kinematics closes the loops
+    st = cclqr.simulate(mech, 10.0, lq, record=False, z0=z0)
+    dev = np.abs(st.zT[:, 4, 1:3] - z00[4, 1:3]).max(axis=1)
+    home = (st.status > 0) & (dev < 1e-2)
+    assert home[96] and dev[96] < 1e-6                                                # the script's i = 97
+    assert home.mean() > 0.98 and (st.status > 0).sum() == home.sum()                 # whoever keeps converging comes home
+    near = np.hypot(yz[:, 0] - z00[4, 1], yz[:, 1] - z00[4, 2]) < 0.8
+    assert home[near].all()
+    st2 = cclqr.simulate(mech, 10.0, lq, record=False, z0=z0[::-1].copy())
+    assert np.array_equal(st2.zT[::-1], st.zT) and np.array_equal(st2.status[::-1], st.status)      # batch-order invariant, bit for bit
+    # the script's case against the oracle under the same law, first steps
+    steps = 12
+    rec = cclqr.simulate(mech, cclqr.Storage(steps, 5), lq, z0=z0[96:97])
+    ref, _ = loop_feedback_reference(lm, z0[96].copy(), ex["Fd"], lq.K[0], z00, steps)
+    assert np.abs(rec.z[0] - ref).max() < 1e-9
