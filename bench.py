@@ -27,6 +27,9 @@ import time
 
 import numpy as np
 
+# RCCL shares device buffers between the ranks' processes through dmabuf IPC on this driver; the legacy IPC mode fails with
+# `hipIpcGetMemHandle: invalid argument` (already exported on the pool's images: kept here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
