@@ -271,14 +271,29 @@ static inline void h_qmul(const double* a, const double* b, double* o) {
     o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
     o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
 }
-// error coordinates of state z about z0, per body x, v, q~ = vec(q0^-1 q), w  (lqr.jl:92-103)
-static inline void h_state_error(int nb, const double* z, const double* z0, double* e) {
-    for (int b = 0; b < nb; b++) {
-        const double* p = z + 13 * b; const double* r = z0 + 13 * b;
-        const double qc[4] = {r[3], -r[4], -r[5], -r[6]};
-        double qe[4];
-        h_qmul(qc, p + 3, qe);
-        for (int i = 0; i < 3; i++) { e[12 * b + i] = p[i] - r[i]; e[12 * b + 3 + i] = p[7 + i] - r[7 + i]; e[12 * b + 6 + i] = qe[1 + i]; e[12 * b + 9 + i] = p[10 + i] - r[10 + i]; }
+// difference quotients of the perturbed single-step results, on the device: thread = (knot, column, body).  Error coordinates of a
+// state about the nominal next state, per body x, v, q~ = vec(q0^-1 q), w  (lqr.jl:92-103)
+__global__ void fd_quotient_kernel(const double* zT, int nk, int per, int nb, int mu, double h, double* Ap, double* D) {
+    const int mx = 12 * nb, ncol = mx + mu;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)nk * ncol * nb) return;
+    const int b = (int)(id % nb), col = (int)((id / nb) % ncol), k = (int)(id / ((long long)nb * ncol));
+    const size_t nz = 13 * (size_t)nb;
+    const double* z0 = zT + ((size_t)k * per) * nz + 13 * b;
+    const double* zp = zT + ((size_t)k * per + 1 + 2 * col) * nz + 13 * b;
+    const double* zm = zp + nz;
+    const double qc[4] = {z0[3], -z0[4], -z0[5], -z0[6]};
+    double qp[4], qm[4], e[12];
+    qmul(qc, zp + 3, qp);
+    qmul(qc, zm + 3, qm);
+    for (int i = 0; i < 3; i++) {
+        e[i] = zp[i] - zm[i]; e[3 + i] = zp[7 + i] - zm[7 + i]; e[6 + i] = qp[1 + i] - qm[1 + i]; e[9 + i] = zp[10 + i] - zm[10 + i];
+    }
+    for (int i = 0; i < 12; i++) {
+        const double v = e[i] / (2.0 * h);
+        const int r = 12 * b + i;
+        if (col < mx) Ap[((size_t)k * mx + r) * mx + col] = v;
+        else D[((size_t)k * mx + r) * mu + (col - mx)] = v;
     }
 }
 extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
@@ -291,7 +306,7 @@ extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const 
     const size_t nz = 13 * (size_t)nb;
     const int per = 1 + 2 * mx + 2 * mu;            // nominal, +-h in every state error coordinate, +-h in every input
     const size_t n = (size_t)nk * per;
-    std::vector<double> z0(n * nz), fd(n * (size_t)(mu > 0 ? mu : 1), 0.0), zdum(n * nz, 0.0), zT(n * nz);
+    std::vector<double> z0(n * nz), fd(n * (size_t)(mu > 0 ? mu : 1), 0.0), zdum(n * nz, 0.0);
     std::vector<int32_t> st(n);
     for (size_t i = 0; i < n; i++)
         for (int b = 0; b < nb; b++) zdum[i * nz + 13 * b + 3] = 1.0;
@@ -326,25 +341,34 @@ extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const 
     cclqr_ctrl* c = nullptr;
     int rc = cclqr_ctrl_create(m, &cd, &c);
     if (rc != CCLQR_OK) return rc;
-    rc = cclqr_rollout(m, c, (int64_t)n, 1, 1, z0.data(), nullptr, nullptr, zT.data(), st.data());
+    double *dz0 = nullptr, *dzT = nullptr, *dAp = nullptr, *dD = nullptr;
+    int32_t* dst = nullptr;
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dz0, n * nz * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dzT, n * nz * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dst, n * sizeof(int32_t));
+    if (e == hipSuccess) e = ws_get((void**)&dAp, (size_t)nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dD, (size_t)nk * mx * (size_t)(mu > 0 ? mu : 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dz0, z0.data(), n * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        cclqr_rollout_opts o;
+        o.first_instance = 0; o.pid_state_dev = nullptr; o.pid_state_len = 0;
+        rc = cclqr_rollout_ex(m, c, (int64_t)n, 1, 1, dz0, nullptr, nullptr, 0, nullptr, dzT, dst, &o, nullptr);
+    }
+    if (rc == CCLQR_OK && e == hipSuccess) {
+        const long long work = (long long)nk * (mx + mu) * nb;
+        hipLaunchKernelGGL(fd_quotient_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, nullptr, dzT, nk, per, nb, mu, h, dAp, dD);
+        e = hipGetLastError();
+    }
+    if (rc == CCLQR_OK && e == hipSuccess) e = hipDeviceSynchronize();
+    if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(st.data(), dst, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(Ap, dAp, (size_t)nk * mx * mx * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == CCLQR_OK && e == hipSuccess && mu > 0) e = hipMemcpy(D, dD, (size_t)nk * mx * mu * sizeof(double), hipMemcpyDeviceToHost);
     cclqr_ctrl_destroy(c);
     if (rc != CCLQR_OK) return rc;
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("linearize_projected: ") + hipGetErrorString(e));
     for (size_t i = 0; i < n; i++)
         if (st[i] <= 0) return fail(CCLQR_ENOCONV, "Newton did not converge at a perturbed setpoint of knot " + std::to_string(i / per));
-    std::vector<double> ep(mx), em(mx);
-    for (int k = 0; k < nk; k++) {
-        const double* znom = &zT[((size_t)k * per) * nz];
-        for (int col = 0; col < mx + mu; col++) {
-            const size_t qp = (size_t)k * per + 1 + 2 * col, qm = qp + 1;
-            h_state_error(nb, &zT[qp * nz], znom, ep.data());
-            h_state_error(nb, &zT[qm * nz], znom, em.data());
-            for (int r = 0; r < mx; r++) {
-                const double v = (ep[r] - em[r]) / (2.0 * h);
-                if (col < mx) Ap[((size_t)k * mx + r) * mx + col] = v;
-                else D[((size_t)k * mx + r) * mu + (col - mx)] = v;
-            }
-        }
-    }
     return CCLQR_OK;
 }
 
