@@ -276,6 +276,34 @@ def test_per_instance_controller_tables(cclqr, orc):
             capi.rollout_dev(mech, ctrl, 12, N, 1, zs.data_ptr(), 0, 0, 0, 0, out.data_ptr(), sts.data_ptr(), first_instance=20)
 
 
+def test_closed_loop_free_fall_energy_error_is_first_order(cclqr):
+    """a physics pin for the closed-loop kernel that needs no oracle: the deltabot released with no joint inputs falls for 0.3 s (a large
+    motion: velocities of several m/s); the total mechanical energy of the recorded states stays within 1.2 % at dt = 0.01 and the
+    error halves with the step (0.27, 0.135, 0.068 J at dt, dt/2, dt/4: the first-order scheme of SURVEY 8a-bis), i.e. the constraint
+    forces of the loops do no net work"""
+    capi = cclqr._capi
+
+    def drift(dt, steps):
+        ex = cclqr.examples.deltabot()
+        mech = ex["mech"]
+        mech.Δt = dt
+        t = mech.tables()
+        z0 = mech.state()
+        mh = capi.MechHandle(t)
+        c = capi.CtrlHandle(mh, [0, 1], K=None, N=0, zd=z0[None], Fd=np.zeros((1, 2)))
+        zT, traj, st = capi.rollout(mh, c, z0[None], steps, record=True)
+        assert st[0] > 0
+        E = np.array([sum(0.5 * t.mass[b] * z[b, 7:10] @ z[b, 7:10] + 0.5 * z[b, 10:13] @ t.inertia[b].reshape(3, 3) @ z[b, 10:13] + t.mass[b] * 9.81 * z[b, 2]
+                          for b in range(t.nb)) for z in traj[0]])
+        assert np.abs(traj[0, -1, :, 7:10]).max() > 2.0          # it really falls
+        return np.abs(E - E[0]).max(), E[0]
+
+    d1, E0 = drift(0.01, 30)
+    d2, _ = drift(0.005, 60)
+    d3, _ = drift(0.0025, 120)
+    assert d1 < 0.015 * E0 and 1.8 < d1 / d2 < 2.2 and 1.8 < d2 / d3 < 2.2
+
+
 def test_forest_with_a_long_and_a_short_chain(cclqr, orc):
     """one mechanism, two chains: 13 links (odd-even reduction level ahead of the sweep) and 3 links (plain sweep), interleaved body
     numbering, one controlled joint each"""
