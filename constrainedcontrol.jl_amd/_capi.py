@@ -14,7 +14,7 @@ OK, EINVAL, ESINGULAR, ENOCONV, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQR_ENOCONV", EHIP: "CCLQR_EHIP", EUNSUPPORTED: "CCLQR_EUNSUPPORTED"}
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
-           "cclqr_ctrl_create", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
+           "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex", "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
@@ -175,6 +175,36 @@ class CtrlHandle:
                              0 if noise_seed is None else 1, 0 if noise_seed is None else int(noise_seed), int(n_ctrl))
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
+
+    def close(self):
+        if self.ptr:
+            lib().cclqr_ctrl_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchLqrHandle:
+    """cclqr_ctrl* built by cclqr_ctrl_create_lqr_batch: one LQR per setpoint (linearsystem + dlqr + controller tables), gains device-resident"""
+
+    def __init__(self, mech, zd, ctrl_joint, Q, R, N, Fd=None, tol=1e-5):
+        nb = mech.tables.nb
+        zd = f64(zd).reshape(-1, nb, 13)
+        n = zd.shape[0]
+        cj = i32(ctrl_joint).reshape(-1)
+        mu = len(cj)
+        Fd = None if Fd is None else f64(Fd).reshape(n, mu)
+        Q, R = f64(Q).reshape(12 * nb, 12 * nb), f64(R).reshape(mu, mu)
+        self.kbreak = np.zeros(n, dtype=np.int32)
+        self.mu, self.N, self.nsp, self.n_ctrl = mu, int(N), 1, n
+        self._arrs = [zd, cj, Fd, Q, R]
+        self.ptr = C.c_void_p()
+        check(lib().cclqr_ctrl_create_lqr_batch(mech.ptr, C.c_int32(n), _d(zd), C.c_int32(mu), _i(cj), _d(Fd), _d(Q), _d(R), C.c_int32(int(N)),
+                                                C.c_double(float(tol)), _i(self.kbreak), C.byref(self.ptr)))
 
     def close(self):
         if self.ptr:

@@ -111,6 +111,106 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     return CCLQR_OK;
 }
 
+// in-place permutation of the 12-column body blocks of every gain row from the caller's body order to the kernels' link order
+// (one workgroup per row, the row staged in LDS); what build_ctrl_tables does on the host for caller-supplied gains
+__global__ void k_rows_to_link_order_kernel(double* K, long long nrows, int nb, const MechDev* M) {
+    extern __shared__ double row[];
+    const long long r = blockIdx.x;
+    if (r >= nrows) return;
+    double* p = K + r * 12 * nb;
+    for (int e = threadIdx.x; e < 12 * nb; e += blockDim.x) row[e] = p[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 12 * nb; e += blockDim.x) { const int l = e / 12; p[e] = row[12 * M->perm[l] + (e - 12 * l)]; }
+}
+
+extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, const double* zd, int32_t mu, const int32_t* ctrl_joint,
+                                           const double* Fd, const double* Q, const double* R, int32_t N, double tol, int32_t* kbreak,
+                                           cclqr_ctrl** out) {
+    if (!m || !zd || !Q || !out || (mu > 0 && (!ctrl_joint || !R))) return fail(CCLQR_EINVAL, "null argument");
+    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "batched LQR construction is for tree mechanisms (closed loops: cclqr_linearize_projected)");
+    if (n_ctrl < 1 || N < 2 || mu < 1 || mu > m->nb) return fail(CCLQR_EINVAL, "bad sizes");
+    const int nb = m->nb;
+    const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb, np = (size_t)n_ctrl;
+    if (linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    LinArgs la;
+    memset(&la, 0, sizeof(la));
+    la.M = m->dev; la.nk = n_ctrl; la.mu = mu;
+    cclqr_ctrl* c = new cclqr_ctrl();
+    memset(c, 0, sizeof(*c));
+    c->nb = nb;
+    CtrlDev& H = c->host;
+    H.mu = mu; H.nK = N - 1; H.N = N; H.nsp = 1; H.n_ctrl = n_ctrl;
+    for (int i = 0; i < mu; i++) {
+        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nb) { delete c; return fail(CCLQR_EINVAL, "controlled joint out of range"); }
+        la.cj[i] = m->link_of_joint[ctrl_joint[i]];
+        H.cj[i] = la.cj[i];
+    }
+    H.K_stride = n_ctrl > 1 ? (long long)(N - 1) * mu * (long long)mx : 0;
+    H.zd_stride = n_ctrl > 1 ? (long long)nz : 0;
+    H.Fd_stride = (n_ctrl > 1 && Fd) ? mu : 0;
+    // setpoints in link order for the rollout's control law
+    std::vector<double> zl(np * nz);
+    for (size_t s = 0; s < np; s++)
+        for (int l = 0; l < nb; l++) memcpy(&zl[(s * nb + l) * 13], zd + (s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
+    const size_t nK = np * (size_t)(N - 1) * mu * mx;
+    double *dzd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr, *dQ = nullptr, *dR = nullptr, *dwork = nullptr;
+    int *dlst = nullptr, *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
+    std::vector<int> lst(np), kb(np), st(np);
+    WsScope scope;
+    hipError_t e = hipMalloc((void**)&c->zd_dev, np * nz * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(c->zd_dev, zl.data(), np * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->K_dev, nK * sizeof(double));
+    if (e == hipSuccess && Fd) {
+        e = hipMalloc((void**)&c->Fd_dev, np * mu * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(c->Fd_dev, Fd, np * mu * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = ws_get((void**)&dzd, np * nz * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dA, np * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, np * mx * mu * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, np * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, np * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dlst, np * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dzd, zd, np * nz * sizeof(double), hipMemcpyHostToDevice);
+    // linearsystem at every setpoint (lqr.jl:63), one launch; the matrices stay on the device
+    la.zd = dzd; la.Fd = c->Fd_dev; la.A = dA; la.Bu = dBu; la.Bl = dBl; la.G = dG; la.status = dlst;
+    if (e == hipSuccess) e = launch_linearize(la, nb, m->host.tree, m->host.npairs, nullptr);
+    // dlqr for every setpoint (lqr.jl:141-184), gains written straight into the controller's table
+    RicArgs ra;
+    ra.nprob = n_ctrl; ra.mx = (int)mx; ra.mu = mu; ra.ml = (int)ml; ra.N = N; ra.time_varying = 0; ra.tol = tol; ra.path = 0; ra.bf16_terms = 0;
+    const size_t wd = ric_total_work_doubles(ra);
+    if (e == hipSuccess) e = ws_get((void**)&dQ, mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dwork, wd * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dstop, np * sizeof(int));
+    if (e == hipSuccess) e = ws_get((void**)&dkb, np * sizeof(int));
+    if (e == hipSuccess) e = ws_get((void**)&dst, np * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dQ, Q, mx * mx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dR, R, (size_t)mu * mu * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c->K_dev, 0, nK * sizeof(double));
+    ra.stop = dstop; ra.A = dA; ra.Bu = dBu; ra.Bl = dBl; ra.G = dG; ra.Q = dQ; ra.R = dR; ra.K = c->K_dev; ra.kbreak = dkb; ra.status = dst; ra.work = dwork;
+    if (e == hipSuccess) e = launch_riccati(ra, nullptr);
+    if (e == hipSuccess) {
+        const long long nrows = (long long)np * (N - 1) * mu;
+        hipLaunchKernelGGL(k_rows_to_link_order_kernel, dim3((unsigned)nrows), dim3(128), mx * sizeof(double), nullptr, c->K_dev, nrows, nb, m->dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(lst.data(), dlst, np * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(kb.data(), dkb, np * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dst, np * sizeof(int), hipMemcpyDeviceToHost);
+    H.K = c->K_dev; H.zd = c->zd_dev; H.Fd = c->Fd_dev;
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dev, sizeof(CtrlDev));
+    if (e == hipSuccess) e = hipMemcpy(c->dev, &c->host, sizeof(CtrlDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cclqr_ctrl_destroy(c); return fail(CCLQR_EHIP, std::string("batched LQR construction: ") + hipGetErrorString(e)); }
+    for (size_t p = 0; p < np; p++) {
+        if (kbreak) kbreak[p] = kb[p];
+        if (lst[p] <= 0) { cclqr_ctrl_destroy(c); return fail(CCLQR_ENOCONV, "Newton did not converge at setpoint " + std::to_string(p)); }
+        if (st[p] != 0) { cclqr_ctrl_destroy(c); return fail(CCLQR_ESINGULAR, "G*Bl or M is singular at setpoint " + std::to_string(p)); }
+    }
+    *out = c;
+    return CCLQR_OK;
+}
+
 extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
     if (!c) return CCLQR_OK;
     if (c->K_dev) (void)hipFree(c->K_dev);

@@ -97,6 +97,14 @@ int cclqr_mech_destroy(cclqr_mech *m);
 int cclqr_ctrl_create(const cclqr_mech *m, const cclqr_ctrl_desc *desc, cclqr_ctrl **out);
 int cclqr_ctrl_destroy(cclqr_ctrl *c);
 
+/* LQR(mechanism, bodyids, eqcids, Q, R, horizon; xd, vd, qd, ωd, Fτd) (lqr.jl:50-66) for n_ctrl setpoints at once, entirely on the device
+ * (SURVEY 8d configs[3]: "Riccati run per instance on distinct setpoints"): linearsystem at every zd[i] (lqr.jl:63), dlqr (lqr.jl:141-184)
+ * and the per-instance controller tables of cclqr_ctrl_create (instance n of a rollout reads table first_instance + n) without the gains
+ * -- n_ctrl (N-1) mu 12 nb doubles: 1 GB for 1024 seven-joint arms at N = 200 -- ever visiting the host.  Q [mx][mx], R [mu][mu] already Δt-scaled
+ * (lqr.jl:18-19), N = horizon in steps, zd [n_ctrl][nb][13], Fd [n_ctrl][mu] or NULL, kbreak [n_ctrl] or NULL.  Tree mechanisms. */
+int cclqr_ctrl_create_lqr_batch(const cclqr_mech *m, int32_t n_ctrl, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
+                                const double *Q, const double *R, int32_t N, double tol, int32_t *kbreak, cclqr_ctrl **out);
+
 /* linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) -- call sites lqr.jl:63, lqr_tracking.jl:88.
  * Batched over nk knots (nk = 1 for LQR, N-1 for TrackingLQR).  Host pointers.
  * zd [nk][nb][13], Fd [nk][mu]; outputs A [nk][mx][mx], Bu [nk][mx][mu], Bl [nk][mx][ml], G [nk][ml][mx]. */

@@ -55,6 +55,16 @@ function linearize_projected(mech::Ptr{Cvoid}, zd::Vector{Float64}, nb::Int, ctr
     return permutedims(reshape(Ap, mx, mx)), permutedims(reshape(D, mu, mx))      # row-major on the C side
 end
 
+# One LQR per setpoint, built and kept on the device (cclqr_ctrl_create_lqr_batch): zd is nb*13*n doubles, Q / R the Δt-scaled weights
+# (lqr.jl:18-19) row-major; returns the controller handle for rollout!(...) and the break indices.
+function lqr_batch(mech::Ptr{Cvoid}, n::Int, zd::Vector{Float64}, ctrl_joint::Vector{Int32}, Q::Vector{Float64}, R::Vector{Float64}, N::Int; tol = 1e-5)
+    h = Ref{Ptr{Cvoid}}(C_NULL); kb = zeros(Int32, n)
+    check(ccall((:cclqr_ctrl_create_lqr_batch, lib), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                mech, Int32(n), zd, Int32(length(ctrl_joint)), ctrl_joint, C_NULL, Q, R, Int32(N), tol, kb, h))
+    return h[], kb
+end
+
 lasterror() = unsafe_string(ccall((:cclqr_last_error, lib), Cstring, ()))
 function check(rc::Integer)
     rc == 0 && return nothing

@@ -289,6 +289,52 @@ def test_cfg4_distinct_setpoints_batched_lqr_drives_batched_rollout(cclqr, orc):
     assert (sto > 0).all() and np.abs(zo - zT[sel]).max() < 1e-9
 
 
+def test_batched_lqr_constructor_keeps_the_gains_on_the_device(cclqr, orc):
+    """cclqr_ctrl_create_lqr_batch (SURVEY 8d configs[3] with a setpoint per instance): linearsystem, dlqr and the per-instance controller
+    tables in one call, the gains never leaving the device.  256 Sawyer poses, N = 200: the rollout it drives is bit-identical to the one
+    driven by the same gains taken through the host (cclqr_linearize -> cclqr_riccati -> cclqr_ctrl_create), break indices included."""
+    import json
+    import os
+    import time
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    n, N = 256, 200
+    rng = np.random.default_rng(45)
+    ang = rng.uniform(-0.8, 0.8, (n, 7))
+    off = rng.uniform(-0.002, 0.002, (n, 7))
+    zd, z0 = [], []
+    for p in range(n):
+        for e, a in zip(mech.eqconstraints, ang[p]):
+            cclqr.setJointPosition(mech, e, a)
+        zd.append(mech.state())
+        for e, a in zip(mech.eqconstraints, ang[p] + off[p]):
+            cclqr.setJointPosition(mech, e, a)
+        z0.append(mech.state())
+    zd, z0 = np.stack(zd), np.stack(z0)
+    mh = capi.MechHandle(t)
+    cj = list(range(7))
+    Q, R = np.eye(84) * 1000.0 * t.dt, np.eye(7) * t.dt
+    t0 = time.time()
+    A, Bu, Bl, G = capi.linearize(mh, zd, cj, np.zeros((n, 7)))
+    K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N)
+    host = capi.CtrlHandle(mh, cj, K=K, N=N, zd=zd[:, None], n_ctrl=n)
+    t_host = time.time() - t0
+    t0 = time.time()
+    dev = capi.BatchLqrHandle(mh, zd, cj, Q, R, N)
+    t_dev = time.time() - t0
+    assert np.array_equal(dev.kbreak, np.atleast_1d(kb))
+    zT_h, tr_h, st_h = capi.rollout(mh, host, z0, N - 1, record=True)
+    zT_d, tr_d, st_d = capi.rollout(mh, dev, z0, N - 1, record=True)
+    assert (st_h > 0).all() and np.array_equal(st_h, st_d)
+    assert np.array_equal(tr_h, tr_d) and np.array_equal(zT_h, zT_d)
+    assert np.abs(zT_d[:, :, 0:3] - zd[:, :, 0:3]).max() < np.abs(z0[:, :, 0:3] - zd[:, :, 0:3]).max()
+    print("batched LQR for %d setpoints, N = %d: through the host %.3f s, on the device %.3f s" % (n, N, t_host, t_dev))
+    assert dev.n_ctrl == n and t_dev < t_host
+
+
 def test_deltabot_script_as_a_batch(cclqr, orc):
     """examples/lqr_deltabot.jl end to end on the device: the script's LQR (its Q and R, infinite horizon, the holding inputs
     +-6.7879484; projected linear model, lqr.py) and ALL 1973 valid initial conditions of its grid (:56-136; the script simulates one,
