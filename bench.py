@@ -344,6 +344,27 @@ def other_configs(pkg, capi, torch, dev):
     ctrl = lq._ctrl_handle(mh)
     out["sawyer_cfg4"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, 2000, False), lqr_construct_s=setup, riccati_kbreak=int(lq.kbreak))
     ctrl.close()
+    # the same arm with a setpoint PER INSTANCE (SURVEY 8d configs[3]: "Riccati run per instance on distinct setpoints"): 1024 poses, one
+    # batched LQR construction on the device (linearsystem + 1999-step dlqr + per-instance tables; 9.6 GB of gains stay in HBM), one rollout
+    n = 1024
+    rng = np.random.default_rng(44)
+    ang, off = rng.uniform(-0.8, 0.8, (n, 7)), rng.uniform(-0.002, 0.002, (n, 7))
+    zdb, z0b = [], []
+    for p in range(n):
+        for e, a in zip(mech.eqconstraints, ang[p]):
+            pkg.setJointPosition(mech, e, a)
+        zdb.append(mech.state())
+        for e, a in zip(mech.eqconstraints, ang[p] + off[p]):
+            pkg.setJointPosition(mech, e, a)
+        z0b.append(mech.state())
+    zdb, z0b = np.stack(zdb), np.stack(z0b)
+    t0 = time.time()
+    bl = capi.BatchLqrHandle(mh, zdb, list(range(7)), lq.Q, lq.R, 2000)
+    setup_b = time.time() - t0
+    out["sawyer_cfg4_setpoint_per_instance"] = dict(_timed_rollout(capi, torch, dev, mh, bl, z0b, 1999, False), batched_lqr_construct_s=setup_b,
+                                                    gain_table_bytes_in_hbm=int(n) * 1999 * 7 * 84 * 8,
+                                                    riccati_kbreak_min_max=[int(bl.kbreak.min()), int(bl.kbreak.max())])
+    bl.close()
     U = np.load(os.path.join(gold, "triple_cartpole_U.npy"))
     ex = pkg.examples.triple_cartpole()
     mech = ex["mech"]
