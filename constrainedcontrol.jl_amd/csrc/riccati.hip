@@ -632,11 +632,24 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         __syncthreads();
         RSTAMP(RP_PA);
         // TS = D' W = [D' Pk A' | D' Pk D] ; S = R + D' Pk D
-        for (int e = tid; e < mu * na; e += RIC_THREADS) {
-            const int q = e / na, j = e - q * na;
-            double sacc = 0.0;
-            for (int i = 0; i < mx; i++) sacc += Dl[i * mu + q] * W[i * na + j];
-            TS[e] = sacc;
+        if (mu <= 16) {            // on the matrix core: D' (mu rows of a 16-row tile) against the column tiles of W
+            for (int tile = wave; tile < t16n; tile += RIC_WAVES) {
+                const int j0 = tile << 4;
+                const bool iok = li < mu, jok = j0 + li < na;
+                const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? Dl[kk * mu + li] : 0.0; },
+                                            [&](int kk) { return jok ? W[kk * na + j0 + li] : 0.0; });
+                if (jok) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int row = lk + 4 * r; if (row < mu) TS[row * na + j0 + li] = acc[r]; }
+                }
+            }
+        } else {
+            for (int e = tid; e < mu * na; e += RIC_THREADS) {
+                const int q = e / na, j = e - q * na;
+                double sacc = 0.0;
+                for (int i = 0; i < mx; i++) sacc += Dl[i * mu + q] * W[i * na + j];
+                TS[e] = sacc;
+            }
         }
         __syncthreads();
         for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];
