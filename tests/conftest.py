@@ -74,7 +74,7 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def long_and_short_chain_forest(cclqr):
+def long_and_short_chain_forest(cclqr, short_first=False):
     """a 13-link cartpole chain and a 3-link one hanging off the same origin, bodies interleaved in the caller's numbering; returns
     (tables, z0 [1][nb][13], zd [nb][13], K [20][2][12 nb], controlled joints)"""
     ea, eb = cclqr.examples.cartpole_n(12), cclqr.examples.cartpole_n(2)
@@ -82,6 +82,11 @@ def long_and_short_chain_forest(cclqr):
     nb = ta.nb + tb.nb
     order = list(np.random.default_rng(5).permutation(nb))
     ia, ib = order[:ta.nb], order[ta.nb:]
+    # the chain whose root joint has the smaller index comes first in the kernels' link order
+    if (min(ia[0], ib[0]) == ib[0]) != short_first:
+        j0, j1 = ia[0], ib[0]
+        ia = [j1 if x == j0 else x for x in ia]
+        ib = [j0 if x == j1 else x for x in ib]
     mass, inertia = np.zeros(nb), np.zeros((nb, 9))
     parent, child, typ = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
     p1, p2, axis, qoff = np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 4))

@@ -200,10 +200,11 @@ def test_emulated_two_chains(cclqr, orc, emu):
     assert np.abs(traj - traj_o).max() < 1e-10
 
 
-def test_emulated_forest_long_and_short_chain(cclqr, orc, emu):
+@pytest.mark.parametrize("short_first", [False, True])
+def test_emulated_forest_long_and_short_chain(cclqr, orc, emu, short_first):
     """a 13-link chain (takes the odd-even reduction level: 32 lanes, 16-link layout) next to a 3-link chain (plain two-front sweep) in
     one mechanism, bodies interleaved in the caller's numbering: the level's lane map must leave the second chain alone"""
-    t2, z0, zd, K, cj = long_and_short_chain_forest(cclqr)
+    t2, z0, zd, K, cj = long_and_short_chain_forest(cclqr, short_first)
     c = orc.ctrl_desc(t2.nb, cj, K=K, N=21, zd=zd)
     _, traj_o, st_o = orc.rollout(t2, c, z0, 20, record=True)
     _, traj, st = emu_rollout(emu, orc, t2, c, z0, 20)
