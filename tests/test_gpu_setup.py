@@ -412,3 +412,28 @@ def test_riccati_bf16_split_mode_error_is_measured(cclqr, orc):
     assert err[3] < 1e-4 and err[3] < err[2] < 1e-2 and err[1] > 1e-2, err
     with pytest.raises(capi.CclqrError):
         capi.riccati(A, Bu, Bl, G, Q, R, N, bf16_terms=4)
+
+
+def test_bench_line_contract(tmp_path):
+    """`python bench.py` prints ONE JSON line with the fields the driver reads: metric/value/unit, n_gpus, steps, warmup, ms_per_step,
+    scaling, dtype, config.workload, roofline {bound, achieved, peak, unit, frac, traffic}, cpu_baseline {value, unit, cores, kind, sample}"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--instances", "512", "--sim-steps", "40",
+                        "--cpu-sample", "64"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] in ("port", "reference")
+    assert abs(d["value"] - 512 * 40 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
