@@ -49,6 +49,8 @@ struct LinkC {
     HD bool valid() const { return (flags & 16) != 0; }
     HD bool live() const { return (flags & 32) != 0; }
     static const int DEAD = 64, BAD = 128;     // set by the rollout loop (see there)
+    static const int FRIC = 256;               // the own joint has viscous friction (friction/noise variant)
+    HD bool has_fric() const { return (flags & FRIC) != 0; }
     HD bool dead() const { return (flags & DEAD) != 0; }
     HD bool bad() const { return (flags & BAD) != 0; }
     HD void set_valid(bool v) { flags |= v ? (16 | ((flags & 1) << 5)) : 0; }

@@ -255,7 +255,7 @@ def test_chain_rollout_kernel_resources(tmp_path):
     {(8, 4), (16, 8), (32, 16), (32, 17), (32, 32)} x control variant {plain LQR, + friction/noise, + PID}.  The plain-LQR instantiations
     -- every BASELINE config but the friction/noise law of config 5 -- must not spill a single scalar register and must not touch
     scratch memory (VERDICT r1 item 2: the kernel must not live in the regime where a spilled pointer or mask can go wrong);
-    the other two variants may spill a few scalars (atan2 / friction code) but no vector register to scratch either."""
+    nor does the friction/noise variant; the PID variant may spill a few scalars (atan2 constants) but no vector register to scratch either."""
     kernels = _kernel_resources(tmp_path, "rollout_chain.hip", "rollout_chain_kernel")
     assert len(kernels) == 15, sorted(kernels)
     for name, k in kernels.items():
@@ -266,8 +266,10 @@ def test_chain_rollout_kernel_resources(tmp_path):
             assert k["vgpr_spill"] == 0, (name, k)
             # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
             assert k["vgpr"] <= (496 if "ILi32ELi1" in name else 440), (name, k)
+        elif variant == 1:
+            assert k["sgpr_spill"] == 0, (name, k)
         else:
-            assert k["sgpr_spill"] <= 16, (name, k)
+            assert k["sgpr_spill"] <= 8, (name, k)
 
 
 def test_loop_rollout_kernel_resources(tmp_path):
