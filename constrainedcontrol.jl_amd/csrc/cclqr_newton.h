@@ -137,16 +137,24 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
             if (!done) ph_schur_s_tree(FRESH_T, G, nb, FRESH_Y, L, M);
             __syncthreads();
             STAMP(PF_SCHUR_S);
-            for (int l = nb - 1; l >= 0; l--) {
-                FRESH_PHASE(M, r);
-                if (!done) ph_tree_elim(FRESH_T, l, FRESH_Y, L, M);
-                __syncthreads();
+            FRESH_PHASE(M, r);
+            {   // offsets and lane index re-derived once for the whole sweep (not per link)
+                const Lay Ye = FRESH_Y;
+                const int te = FRESH_T;
+                for (int l = nb - 1; l >= 0; l--) {
+                    if (!done) ph_tree_elim(te, l, Ye, L, M);
+                    __syncthreads();
+                }
             }
             STAMP(PF_TRI_FWD);
-            for (int l = 0; l < nb; l++) {
-                FRESH_PHASE(M, r);
-                if (!done) ph_tree_back(FRESH_T, l, FRESH_Y, L, M);
-                __syncthreads();
+            FRESH_PHASE(M, r);
+            {
+                const Lay Yb = FRESH_Y;
+                const int tb = FRESH_T;
+                for (int l = 0; l < nb; l++) {
+                    if (!done) ph_tree_back(tb, l, Yb, L, M);
+                    __syncthreads();
+                }
             }
             STAMP(PF_TRI_BWD);
             FRESH_PHASE(M, r);
