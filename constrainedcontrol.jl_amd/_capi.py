@@ -14,7 +14,7 @@ OK, EINVAL, ESINGULAR, ENOCONV, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQR_ENOCONV", EHIP: "CCLQR_EHIP", EUNSUPPORTED: "CCLQR_EUNSUPPORTED"}
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
-           "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tracking", "cclqr_rollout",
+           "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex", "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
 
 
@@ -308,6 +308,23 @@ def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0):
     check(lib().cclqr_riccati_ex(C.c_int32(nprob), C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl), _d(G), _d(Q), _d(R),
                                  C.c_int32(N), C.c_double(tol), _d(K), _i(kb), C.byref(o)))
     return (K[0], int(kb[0])) if single else (K, kb)
+
+
+def riccati_tv(A, Bu, Bl, G, Q, R, N, tol=1e-5):
+    """time-varying dlqr on caller-supplied per-knot models: A [N-1][mx][mx], Bu [N-1][mx][mu], Bl [N-1][mx][ml], G [N-1][ml][mx] -> K [N-1][mu][mx], kbreak"""
+    A = f64(A)
+    nk, mx = A.shape[0], A.shape[1]
+    assert nk == N - 1
+    Bu = f64(Bu).reshape(nk, mx, -1)
+    mu = Bu.shape[2]
+    Bl = f64(Bl).reshape(nk, mx, -1)
+    ml = Bl.shape[2]
+    G = f64(G).reshape(nk, ml, mx)
+    K = np.zeros((nk, mu, mx))
+    kb = np.zeros(1, dtype=np.int32)
+    check(lib().cclqr_riccati_tv(C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl) if ml else None, _d(G) if ml else None,
+                                 _d(f64(Q)), _d(f64(R)), C.c_int32(int(N)), C.c_double(float(tol)), _d(K), _i(kb)))
+    return K, int(kb[0])
 
 
 def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5, path=0, bf16_terms=0):

@@ -544,6 +544,27 @@ extern "C" int cclqr_riccati_ex(int32_t nprob, int32_t mx, int32_t mu, int32_t m
     return rc;
 }
 
+extern "C" int cclqr_riccati_tv(int32_t mx, int32_t mu, int32_t ml, const double* A, const double* Bu, const double* Bl, const double* G,
+                                const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
+    if (!A || !Q || (mu > 0 && (!Bu || !R)) || (ml > 0 && (!Bl || !G)) || !K) return fail(CCLQR_EINVAL, "null argument");
+    if (mx < 1 || mu < 0 || ml < 0 || N < 2) return fail(CCLQR_EINVAL, "bad sizes");
+    double *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
+    const size_t nk = (size_t)N - 1;
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dA, nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, (nk * mx * mu + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, (nk * mx * ml + 1) * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, (nk * ml * mx + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dA, A, nk * mx * mx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && mu > 0) e = hipMemcpy(dBu, Bu, nk * mx * mu * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ml > 0) e = hipMemcpy(dBl, Bl, nk * mx * ml * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ml > 0) e = hipMemcpy(dG, G, nk * ml * mx * sizeof(double), hipMemcpyHostToDevice);
+    int rc = CCLQR_OK;
+    if (e == hipSuccess) rc = run_riccati(1, mx, mu, ml, N, 1, tol, dA, dBu, dBl, dG, Q, R, K, kbreak, nullptr);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("riccati upload: ") + hipGetErrorString(e));
+    return rc;
+}
+
 extern "C" int cclqr_riccati_tracking(const cclqr_mech* m, int32_t mu, const int32_t* ctrl_joint, const double* zd, const double* Fd,
                                       const double* Q, const double* R, int32_t N, double tol, double* K, int32_t* kbreak) {
     return cclqr_riccati_tracking_ex(m, mu, ctrl_joint, zd, Fd, Q, R, N, tol, K, kbreak, nullptr);

@@ -212,7 +212,15 @@ class TrackingLQR(Controller):
         mu = len(self.eqcids)
         self.Fd = np.array([[np.asarray(Fτ[k][i], dtype=np.float64).reshape(-1)[0] for i in range(mu)] for k in range(N)]).reshape(N, mu)
         dev = _device_mech(mechanism)
-        self.K, self.kbreak = _capi.riccati_tracking(dev, self.ctrl_joints, self.zd, self.Fd, self.Q, self.R, N)   # lqr_tracking.jl:40
+        self.projected = bool(getattr(mechanism, "has_loops", False))
+        if self.projected:
+            # closed loops: the projected pair (A'_k, D_k) of every knot from the device's constrained step map (see LQR), recursion with
+            # no multipliers left
+            mx = 12 * nb
+            Ap, D = _capi.linearize_projected(dev, self.zd[:N - 1], self.ctrl_joints, self.Fd[:N - 1])
+            self.K, self.kbreak = _capi.riccati_tv(Ap, D, np.zeros((N - 1, mx, 0)), np.zeros((N - 1, 0, mx)), self.Q, self.R, N)
+        else:
+            self.K, self.kbreak = _capi.riccati_tracking(dev, self.ctrl_joints, self.zd, self.Fd, self.Q, self.R, N)   # lqr_tracking.jl:40
         self.N = N
         self.NK = 12 * nb
 

@@ -152,6 +152,12 @@ int cclqr_release_workspaces(void);
  * Same results either way. */
 int cclqr_riccati_path(int32_t path);
 
+/* The recursion of lqr_tracking.jl:73-122 on per-knot linear models the caller brings: A [N-1][mx][mx], Bu [N-1][mx][mu], Bl [N-1][mx][ml],
+ * G [N-1][ml][mx] (knot k = 1 .. N-1 at index k-1, as cclqr_riccati_tracking linearises them itself); ml = 0 with the projected pairs of
+ * cclqr_linearize_projected gives the TrackingLQR of a closed-loop mechanism.  K [N-1][mu][mx], kbreak [1]. Host pointers. */
+int cclqr_riccati_tv(int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
+                     const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
+
 /* dlqr(mechanism, xd, vd, qd, ωd, Fτd, eqcids, Q, R, N) -- lqr_tracking.jl:73-122: re-linearises at every knot (:88).
  * zd [N][nb][13], Fd [N][mu], K [N-1][mu][mx]. Host pointers. */
 int cclqr_riccati_tracking(const cclqr_mech *m, int32_t mu, const int32_t *ctrl_joint, const double *zd, const double *Fd, const double *Q,

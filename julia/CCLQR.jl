@@ -65,6 +65,17 @@ function lqr_batch(mech::Ptr{Cvoid}, n::Int, zd::Vector{Float64}, ctrl_joint::Ve
     return h[], kb
 end
 
+# Time-varying recursion (lqr_tracking.jl:73-122) on per-knot models the caller brings (row-major [N-1][..][..] flattened), e.g. the
+# projected pairs of a closed-loop mechanism with ml = 0
+function dlqr_tv(mx::Int, mu::Int, ml::Int, A::Vector{Float64}, Bu::Vector{Float64}, Bl::Vector{Float64}, G::Vector{Float64},
+                 Q::Vector{Float64}, R::Vector{Float64}, N::Int; tol = 1e-5)
+    K = zeros((N - 1) * mu * mx); kb = zeros(Int32, 1)
+    check(ccall((:cclqr_riccati_tv, lib), Cint,
+                (Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Int32}),
+                Int32(mx), Int32(mu), Int32(ml), A, Bu, ml > 0 ? pointer(Bl) : C_NULL, ml > 0 ? pointer(G) : C_NULL, Q, R, Int32(N), tol, K, kb))
+    return K, Int(kb[1])
+end
+
 lasterror() = unsafe_string(ccall((:cclqr_last_error, lib), Cstring, ()))
 function check(rc::Integer)
     rc == 0 && return nothing

@@ -289,6 +289,58 @@ def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
     assert free.status[0] < 0 or np.abs(free.zT[0] - z0).max() > 20 * np.abs(res.zT[0] - z0).max()      # the holding inputs alone do not bring it back
 
 
+def test_tracking_lqr_on_the_deltabot(cclqr, orc):
+    """TrackingLQR (lqr_tracking.jl:17-43) on a closed-loop mechanism: per-knot projected models from the device (cclqr_linearize_projected,
+    119 knots x 125 single-step rollouts in one launch), the time-varying recursion on them (cclqr_riccati_tv, no multipliers left).
+    The model of a mid-trajectory knot equals the oracle's dense-KKT differences about the same (state, input); the gains equal a numpy
+    restatement of the recursion (lqr_tracking.jl:73-122) on the same models; and the controller pulls a perturbed start back onto the
+    recorded trajectory where the replayed inputs alone drift away."""
+    from oracle import loops
+    capi = cclqr._capi
+    ex = cclqr.examples.deltabot()
+    mech = ex["mech"]
+    z00 = mech.state()
+    N = 120
+    U = ex["Fd"][None, :] * (1.0 + 0.03 * np.sin(2 * np.pi * np.arange(N) / 60.0))[:, None]
+    s0 = cclqr.simulate(mech, cclqr.Storage(N, 5), cclqr.OpenLoop(mech, ex["eqcids"], U))
+    assert s0.status[0] > 0 and np.abs(s0.z[0, -1] - z00).max() > 1e-3                     # the platform is driven around
+    mech.set_state(z00)
+    Q, R = [np.eye(12) for _ in range(5)], [np.eye(1) * 0.1 for _ in range(2)]
+    tl = cclqr.TrackingLQR(mech, s0, [[[U[k, 0]], [U[k, 1]]] for k in range(N)], ex["eqcids"], Q, R)
+    assert tl.projected and tl.K.shape == (N - 1, 2, 60)
+    # one knot's model against the oracle
+    lm, z, u = loops.deltabot()
+    k = 40
+    uk = np.zeros(7); uk[:2] = U[k]
+    Ao, Do = loops.projected_linear_model(lm, s0.z[0, k].copy(), uk, [0, 1])
+    Ap, D = capi.linearize_projected(mech._cclqr_handle, s0.z[0, k:k + 1], tl.ctrl_joints, U[k:k + 1])
+    assert np.abs(Ap[0] - Ao).max() < 1e-6 and np.abs(D[0] - Do).max() < 1e-6
+    # the recursion on the device's models, restated in numpy (ml = 0: D = Bu, lqr.jl:151-176 with the knot's matrices)
+    Aall, Dall = capi.linearize_projected(mech._cclqr_handle, s0.z[0, :N - 1], tl.ctrl_joints, U[:N - 1])
+    P, Kref = tl.Q.copy(), np.zeros_like(tl.K)
+    kb = 0
+    for kk in range(N - 1, 0, -1):
+        A, B = Aall[kk - 1], Dall[kk - 1]
+        Kk = np.linalg.solve(tl.R + B.T @ P @ B, B.T @ P @ A)
+        Kref[kk - 1] = Kk
+        Abar = A - B @ Kk
+        Pn = tl.Q + Kk.T @ tl.R @ Kk + Abar.T @ P @ Abar
+        kb = kk
+        if np.linalg.norm(P - Pn) < 1e-5:
+            break
+        P = Pn
+    for k2 in range(kb - 1, 0, -1):
+        Kref[k2 - 1] = Kref[k2]
+    assert int(tl.kbreak) == kb and np.abs(tl.K - Kref).max() < 1e-7 * np.abs(Kref).max()
+    # tracking: start two steps ahead on the same motion (a consistent perturbed state), follow the recorded trajectory
+    zp = s0.z[0, 2:3].copy()
+    track = cclqr.simulate(mech, cclqr.Storage(N - 1, 5), tl, z0=zp)
+    replay = cclqr.simulate(mech, cclqr.Storage(N - 1, 5), cclqr.OpenLoop(mech, ex["eqcids"], U), z0=zp)
+    e_track = np.abs(track.z[0, -1] - s0.z[0, N - 2]).max()
+    e_replay = np.abs(replay.z[0, -1] - s0.z[0, N - 2]).max()
+    assert track.status[0] > 0 and e_track < 0.2 * e_replay and e_track < 5e-3, (e_track, e_replay)
+
+
 def test_minimal_coordinate_lqr_prismatic(cclqr, orc):
     """examples/lqr_prismatic.jl: LQR(mech, getid.(constraints), getid.(constraints), Q::Vector, R::Vector, 10.)  (lqr.jl:68-86)"""
     ex = cclqr.examples.prismatic_slider()
