@@ -62,12 +62,10 @@ __device__ __forceinline__ double group_sum(double v) {
     v += dpp_row_ror<4>(v);
     v += dpp_row_ror<2>(v);
     v += dpp_row_ror<1>(v);
-    if (G == 32) {      // rows 0+1 and 2+3: gfx950's row swap (two VALU instructions per half) instead of a round trip through the LDS crossbar
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);     // [0]: even rows everywhere, [1]: odd rows everywhere
-        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
-    }
+    // rows 0+1 and 2+3 through the LDS crossbar (ds_bpermute).  gfx950's v_permlane16_swap does the same exchange in the vector
+    // ALU, but its two result pairs cost the 17-link instantiations 4 vector registers they do not have (VGPR spills; round 2,
+    // 6ef5c0b) for no measured gain
+    if (G == 32) v += __shfl_xor(v, 16, 64);
     if (G == 64) {
         int lo = __double2loint(v), hi = __double2hiint(v);
         double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));

@@ -272,6 +272,26 @@ def test_chain_rollout_kernel_resources(tmp_path):
             assert k["sgpr_spill"] <= 8, (name, k)
 
 
+def test_linearize_and_riccati_kernel_resources(tmp_path):
+    """csrc/linearize.hip and csrc/riccati.hip: no scratch memory and no vector-register spill in any kernel; the scalar spills the
+    compiler makes today (to VGPR lanes, never to memory) are recorded as upper bounds so that an edit that pushes a kernel further
+    into the spilling regime fails here, on the CPU, before it reaches a GPU"""
+    lin = _kernel_resources(tmp_path, "linearize.hip", "linearize_kernel")
+    assert len(lin) == 2, sorted(lin)
+    for name, k in lin.items():
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
+        assert k["sgpr_spill"] <= (23 if "ILb1E" in name else 6), (name, k)
+    ric = _kernel_resources(tmp_path, "riccati.hip", "ric")
+    assert len(ric) >= 7, sorted(ric)
+    bound = {"riccati_resident_kernel": 58, "ric_gain_update_kernel": 42}
+    for name, k in ric.items():
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
+        # every riccati kernel runs >= 2 wavefronts per SIMD (512-thread workgroups / tiles): <= 256 registers per lane
+        assert k["vgpr"] <= 256, (name, k)
+        lim = max([v for key, v in bound.items() if key in name] + [0])
+        assert k["sgpr_spill"] <= lim, (name, k)
+
+
 def test_loop_rollout_kernel_resources(tmp_path):
     """the closed-loop rollout kernel (csrc/rollout_loop.hip) cross-compiles for gfx950 without scratch memory"""
     kernels = _kernel_resources(tmp_path, "rollout_loop.hip", "rollout_loop_kernel")

@@ -5,6 +5,11 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-prof_r02}
 mkdir -p $OUT
+# Rule: the CPU suite -- which holds the register/spill guards of every kernel -- runs before anything is
+# profiled or committed; a red suite aborts the round's profile.
+if [ "${SKIP_CPU_SUITE:-0}" != "1" ]; then
+  (cd $R && python3 -m pytest tests -x -q -m "not gpu" > $OUT/cpu_suite.log 2>&1) || { echo "CPU suite red: see $OUT/cpu_suite.log"; tail -5 $OUT/cpu_suite.log; exit 1; }
+fi
 cd /tmp && export TMPDIR=/tmp
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1
