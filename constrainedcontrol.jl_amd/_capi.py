@@ -15,7 +15,9 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
-           "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex", "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_set_instance_offset", "cclqr_riccati_path", "cclqr_set_pid_state"]
+           "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_host_ex", "cclqr_ctrl_reserve_noise", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex",
+           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links"]
+ABI_VERSION = 200     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header
 
 
 class CclqrError(RuntimeError):
@@ -38,11 +40,12 @@ class CtrlDesc(C.Structure):
 
 
 class RiccatiOpts(C.Structure):
-    _fields_ = [("path", C.c_int32), ("bf16_terms", C.c_int32)]
+    _fields_ = [("path", C.c_int32), ("bf16_terms", C.c_int32), ("keep_last", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RolloutOpts(C.Structure):
-    _fields_ = [("first_instance", C.c_int64), ("pid_state_dev", C.c_void_p), ("pid_state_len", C.c_int64)]
+    _fields_ = [("first_instance", C.c_int64), ("pid_state_dev", C.c_void_p), ("pid_state_len", C.c_int64),
+                ("noise_ws_dev", C.c_void_p), ("noise_ws_len", C.c_int64), ("newton_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -79,6 +82,8 @@ def lib():
         L.cclqr_last_error.restype = C.c_char_p
         for name in EXPORTS[1:]:
             getattr(L, name).restype = C.c_int   # a missing export raises here: the library must implement all of include/cclqr.h
+        if L.cclqr_version() != ABI_VERSION:
+            raise ImportError("libcclqr.so has ABI version %d, this binding was written for %d: rebuild the library" % (L.cclqr_version(), ABI_VERSION))
         _lib = L
     return _lib
 
@@ -110,11 +115,6 @@ def device_count():
     return n.value
 
 
-def chain_layout_links(nb):
-    """links the chain kernel's LDS image is laid out for (= csrc/rollout_chain.hip chain_layout_links): names the instantiation"""
-    return 8 if nb <= 8 else (16 if nb <= 16 else (17 if nb == 17 else 32))
-
-
 def set_device(dev):
     check(lib().cclqr_set_device(C.c_int32(dev)))
 
@@ -135,6 +135,12 @@ class MechHandle:
         lanes, ldsb = C.c_int32(0), C.c_int32(0)
         check(lib().cclqr_rollout_geometry(self.ptr, C.byref(lanes), C.byref(ldsb)))
         return lanes.value, ldsb.value
+
+    def layout_links(self):
+        """links the chain kernel's LDS image is laid out for (names the instantiation); 0 for tree / closed-loop mechanisms"""
+        n = C.c_int32(0)
+        check(lib().cclqr_rollout_layout_links(self.ptr, C.byref(n)))
+        return n.value
 
     def close(self):
         if self.ptr:
@@ -176,6 +182,10 @@ class CtrlHandle:
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create(mech.ptr, C.byref(self.desc), C.byref(self.ptr)))
 
+    def reserve_noise(self, n_inst, steps):
+        """size the handle's Philox workspace (needed before a noise_philox launch is captured into a hipGraph)"""
+        check(lib().cclqr_ctrl_reserve_noise(self.ptr, C.c_int64(int(n_inst)), C.c_int32(int(steps))))
+
     def close(self):
         if self.ptr:
             lib().cclqr_ctrl_destroy(self.ptr)
@@ -191,7 +201,8 @@ class CtrlHandle:
 class BatchLqrHandle:
     """cclqr_ctrl* built by cclqr_ctrl_create_lqr_batch: one LQR per setpoint (linearsystem + dlqr + controller tables), gains device-resident"""
 
-    def __init__(self, mech, zd, ctrl_joint, Q, R, N, Fd=None, tol=1e-5):
+    def __init__(self, mech, zd, ctrl_joint, Q, R, N, Fd=None, tol=1e-5, infinite_horizon=False):
+        """infinite_horizon: LQR{T,Inf} -- N = Ntemp = ceil(10/Δt) (lqr.jl:26), only Ku[1] per setpoint is kept"""
         nb = mech.tables.nb
         zd = f64(zd).reshape(-1, nb, 13)
         n = zd.shape[0]
@@ -200,11 +211,11 @@ class BatchLqrHandle:
         Fd = None if Fd is None else f64(Fd).reshape(n, mu)
         Q, R = f64(Q).reshape(12 * nb, 12 * nb), f64(R).reshape(mu, mu)
         self.kbreak = np.zeros(n, dtype=np.int32)
-        self.mu, self.N, self.nsp, self.n_ctrl = mu, int(N), 1, n
+        self.mu, self.N, self.nsp, self.n_ctrl = mu, (0 if infinite_horizon else int(N)), 1, n
         self._arrs = [zd, cj, Fd, Q, R]
         self.ptr = C.c_void_p()
         check(lib().cclqr_ctrl_create_lqr_batch(mech.ptr, C.c_int32(n), _d(zd), C.c_int32(mu), _i(cj), _d(Fd), _d(Q), _d(R), C.c_int32(int(N)),
-                                                C.c_double(float(tol)), _i(self.kbreak), C.byref(self.ptr)))
+                                                C.c_int32(1 if infinite_horizon else 0), C.c_double(float(tol)), _i(self.kbreak), C.byref(self.ptr)))
 
     def close(self):
         if self.ptr:
@@ -218,7 +229,7 @@ class BatchLqrHandle:
             pass
 
 
-def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
+def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instance=0, newton_mode=0):
     """host-pointer rollout: returns (zT, traj or None, status)"""
     nb = mech.tables.nb
     z0 = f64(z0).reshape(-1, nb, 13)
@@ -227,36 +238,24 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False):
     zT = np.zeros_like(z0)
     status = np.zeros(n, dtype=np.int32)
     noise = None if noise is None else f64(noise).reshape(n, steps)
-    check(lib().cclqr_rollout(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
-                              _i(status)))
+    o = RolloutOpts(int(first_instance), None, 0, None, 0, int(newton_mode), 0)
+    check(lib().cclqr_rollout_host_ex(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
+                                      _i(status), C.byref(o)))
     return zT, traj, status
 
 
-def riccati_path(path):
-    """0 auto, 1 persistent workgroup per problem, 2 tiled over the device"""
-    check(lib().cclqr_riccati_path(C.c_int32(int(path))))
-
-
-def set_pid_state(ptr):
-    """device address of a [n_inst][nb][2] fp64 buffer carrying the PID integrators across rollout_dev launches (0: none)"""
-    check(lib().cclqr_set_pid_state(C.c_void_p(int(ptr)) if ptr else None))
-
-
-def set_instance_offset(first_instance):
-    check(lib().cclqr_set_instance_offset(C.c_int64(int(first_instance))))
-
-
 def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0,
-                first_instance=None, pid_state=None):
+                first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0):
     """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
-    first_instance / pid_state given: cclqr_rollout_ex with explicit options (pid_state = device address of [n_inst][nb][2] doubles);
-    neither given: the legacy entry point cclqr_rollout_dev (thread-local setters)"""
+    Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][nb][2] doubles, noise_ws / noise_ws_len = caller's
+    Philox workspace, newton_mode; none given: cclqr_rollout_dev (= NULL options)"""
     vp = lambda p: C.c_void_p(int(p)) if p else None
-    if first_instance is None and pid_state is None:
+    if first_instance is None and pid_state is None and noise_ws is None and not newton_mode:
         check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                       vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
         return
-    o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.nb * 2 if pid_state else 0)
+    o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.nb * 2 if pid_state else 0,
+                    int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), 0)
     check(lib().cclqr_rollout_ex(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), C.byref(o), vp(stream)))
 
@@ -288,9 +287,10 @@ def linearize_projected(mech, zd, ctrl_joint, Fd=None, h=0.0):
     return Ap, D
 
 
-def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0):
+def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0, keep_last=False):
     """batched dlqr: A [nprob][mx][mx] (or [mx][mx]) -> K [nprob][N-1][mu][mx], kbreak [nprob].
-    path: 0 auto / 1 resident / 2 tiled; bf16_terms: 0 = fp64 MFMA (parity), 1..3 = split-bf16 measured-error mode (cclqr_riccati_opts)"""
+    path: 0 auto / 1 resident / 2 tiled; bf16_terms: 0 = fp64 MFMA (parity), 1..3 = split-bf16 measured-error mode (cclqr_riccati_opts);
+    keep_last: K [nprob][1][mu][mx] = Ku[1] only (LQR{T,Inf})"""
     A = f64(A)
     single = A.ndim == 2
     mx = A.shape[-1]
@@ -302,9 +302,9 @@ def riccati(A, Bu, Bl, G, Q, R, N, tol=1e-5, path=0, bf16_terms=0):
     ml = Bl.shape[2]
     G = f64(G).reshape(nprob, ml, mx)
     Q, R = f64(Q).reshape(mx, mx), f64(R).reshape(mu, mu)
-    K = np.zeros((nprob, max(N - 1, 0), mu, mx))
+    K = np.zeros((nprob, (1 if keep_last else N - 1) if N > 1 else 0, mu, mx))
     kb = np.zeros(nprob, dtype=np.int32)
-    o = RiccatiOpts(int(path), int(bf16_terms))
+    o = RiccatiOpts(int(path), int(bf16_terms), 1 if keep_last else 0, 0)
     check(lib().cclqr_riccati_ex(C.c_int32(nprob), C.c_int32(mx), C.c_int32(mu), C.c_int32(ml), _d(A), _d(Bu), _d(Bl), _d(G), _d(Q), _d(R),
                                  C.c_int32(N), C.c_double(tol), _d(K), _i(kb), C.byref(o)))
     return (K[0], int(kb[0])) if single else (K, kb)
@@ -335,7 +335,7 @@ def riccati_tracking(mech, ctrl_joint, zd, Fd, Q, R, N, tol=1e-5, path=0, bf16_t
     Fd = f64(Fd).reshape(N, mu)
     K = np.zeros((N - 1, mu, mx))
     kb = C.c_int32(0)
-    o = RiccatiOpts(int(path), int(bf16_terms))
+    o = RiccatiOpts(int(path), int(bf16_terms), 0, 0)
     check(lib().cclqr_riccati_tracking_ex(mech.ptr, C.c_int32(mu), _i(cj), _d(zd), _d(Fd), _d(f64(Q).reshape(mx, mx)), _d(f64(R).reshape(mu, mu)),
                                           C.c_int32(N), C.c_double(tol), _d(K), C.byref(kb), C.byref(o)))
     return K, kb.value

@@ -4,6 +4,7 @@
 #include "../../include/cclqr.h"
 #include "cclqr_internal.h"
 #include "cclqr_tables.h"
+#include "cclqr_wscache.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -22,35 +23,60 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* cclqr_last_error(void) { return g_err.c_str(); }
 
+#include <mutex>
+namespace cclqr {
+hipError_t set_max_dynamic_lds_once(const void* fn, size_t lds) {
+    struct Entry { int dev; const void* fn; size_t lds; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& s : seen)
+        if (s.dev == dev && s.fn == fn) {
+            if (s.lds >= lds) return hipSuccess;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) s.lds = lds;
+            return e;
+        }
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) seen.push_back({dev, fn, lds});
+    return e;
+}
+}  // namespace cclqr
+
 // Device workspaces of the host-pointer entry points (linearize / riccati / rollout staging) are kept per thread and reused by the
 // next call instead of a hipMalloc + hipFree (both synchronise the device) per call; cclqr_release_workspaces() returns them.
-struct WsCache {
-    std::vector<std::pair<void*, size_t>> blocks;
-    size_t used = 0;
-};
 static thread_local WsCache g_ws;
 static hipError_t ws_get(void** p, size_t bytes) {
-    WsCache& w = g_ws;
-    if (bytes == 0) bytes = 8;
-    if (w.used == w.blocks.size()) w.blocks.push_back({nullptr, 0});
-    auto& b = w.blocks[w.used];
-    if (b.second < bytes) {
-        if (b.first) { hipError_t e = hipFree(b.first); b.first = nullptr; b.second = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&b.first, bytes);
-        if (e != hipSuccess) { b.first = nullptr; return e; }
-        b.second = bytes;
-    }
-    *p = b.first;
-    w.used++;
-    return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const int rc = ws_get_on(g_ws, dev, p, bytes, [](void** q, size_t n) { return (int)hipMalloc(q, n); }, [](void* q) { return (int)hipFree(q); },
+                             [](int d) { (void)hipSetDevice(d); });
+    return rc < 0 ? hipErrorInvalidDevice : (hipError_t)rc;
 }
 struct WsScope { ~WsScope() { g_ws.used = 0; } };     // every block is free again when the entry point returns
+// blocks of a thread that exits without calling this stay allocated until the process ends (thread_local destructors must not call
+// into a HIP runtime that may already be shutting down)
 extern "C" int cclqr_release_workspaces(void) {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (have && g_ws.device >= 0 && g_ws.device != cur) (void)hipSetDevice(g_ws.device);
     for (auto& b : g_ws.blocks) if (b.first) (void)hipFree(b.first);
-    g_ws.blocks.clear(); g_ws.used = 0;
+    if (have && g_ws.device >= 0 && g_ws.device != cur) (void)hipSetDevice(cur);
+    g_ws.blocks.clear(); g_ws.used = 0; g_ws.device = -1;
     return CCLQR_OK;
 }
-extern "C" int cclqr_version(void) { return 100; }
+// every entry point that takes a handle runs on the device the handle's tables live on
+static int check_device(const cclqr_mech* m) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(CCLQR_EHIP, "hipGetDevice failed");
+    if (m && m->device != dev) return fail(CCLQR_EINVAL, "the mechanism was created on device " + std::to_string(m->device) + ", the calling thread is on device " + std::to_string(dev));
+    return CCLQR_OK;
+}
+extern "C" int cclqr_version(void) { return CCLQR_ABI_VERSION; }
 extern "C" int cclqr_device_count(int32_t* n) {
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -83,6 +109,7 @@ extern "C" int cclqr_mech_destroy(cclqr_mech* m) {
 
 extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, cclqr_ctrl** out) {
     if (!m || !d || !out) return fail(CCLQR_EINVAL, "null argument");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     CtrlHostTables T;
     std::string err;
     int rc = build_ctrl_tables(m, d, T, err);
@@ -124,9 +151,11 @@ __global__ void k_rows_to_link_order_kernel(double* K, long long nrows, int nb, 
 }
 
 extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, const double* zd, int32_t mu, const int32_t* ctrl_joint,
-                                           const double* Fd, const double* Q, const double* R, int32_t N, double tol, int32_t* kbreak,
-                                           cclqr_ctrl** out) {
+                                           const double* Fd, const double* Q, const double* R, int32_t N, int32_t infinite_horizon, double tol,
+                                           int32_t* kbreak, cclqr_ctrl** out) {
+    const bool inf = infinite_horizon != 0;
     if (!m || !zd || !Q || !out || (mu > 0 && (!ctrl_joint || !R))) return fail(CCLQR_EINVAL, "null argument");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "batched LQR construction is for tree mechanisms (closed loops: cclqr_linearize_projected)");
     if (n_ctrl < 1 || N < 2 || mu < 1 || mu > m->nb) return fail(CCLQR_EINVAL, "bad sizes");
     const int nb = m->nb;
@@ -139,20 +168,22 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     memset(c, 0, sizeof(*c));
     c->nb = nb;
     CtrlDev& H = c->host;
-    H.mu = mu; H.nK = N - 1; H.N = N; H.nsp = 1; H.n_ctrl = n_ctrl;
+    // LQR{T,Inf} (lqr.jl:25-27, 40-43): the recursion runs its N = Ntemp steps, only Ku[1] is kept and the feedback is never gated
+    const size_t nKtab = inf ? 1 : (size_t)(N - 1);
+    H.mu = mu; H.nK = (int)nKtab; H.N = inf ? 0 : N; H.nsp = 1; H.n_ctrl = n_ctrl;
     for (int i = 0; i < mu; i++) {
         if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nb) { delete c; return fail(CCLQR_EINVAL, "controlled joint out of range"); }
         la.cj[i] = m->link_of_joint[ctrl_joint[i]];
         H.cj[i] = la.cj[i];
     }
-    H.K_stride = n_ctrl > 1 ? (long long)(N - 1) * mu * (long long)mx : 0;
+    H.K_stride = n_ctrl > 1 ? (long long)nKtab * mu * (long long)mx : 0;
     H.zd_stride = n_ctrl > 1 ? (long long)nz : 0;
     H.Fd_stride = (n_ctrl > 1 && Fd) ? mu : 0;
     // setpoints in link order for the rollout's control law
     std::vector<double> zl(np * nz);
     for (size_t s = 0; s < np; s++)
         for (int l = 0; l < nb; l++) memcpy(&zl[(s * nb + l) * 13], zd + (s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
-    const size_t nK = np * (size_t)(N - 1) * mu * mx;
+    const size_t nK = np * nKtab * mu * mx;
     double *dzd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr, *dQ = nullptr, *dR = nullptr, *dwork = nullptr;
     int *dlst = nullptr, *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
     std::vector<int> lst(np), kb(np), st(np);
@@ -176,7 +207,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     if (e == hipSuccess) e = launch_linearize(la, nb, m->host.tree, m->host.npairs, nullptr);
     // dlqr for every setpoint (lqr.jl:141-184), gains written straight into the controller's table
     RicArgs ra;
-    ra.nprob = n_ctrl; ra.mx = (int)mx; ra.mu = mu; ra.ml = (int)ml; ra.N = N; ra.time_varying = 0; ra.tol = tol; ra.path = 0; ra.bf16_terms = 0;
+    ra.nprob = n_ctrl; ra.mx = (int)mx; ra.mu = mu; ra.ml = (int)ml; ra.N = N; ra.time_varying = 0; ra.tol = tol; ra.path = 0; ra.bf16_terms = 0; ra.keep_last = inf ? 1 : 0;
     const size_t wd = ric_total_work_doubles(ra);
     if (e == hipSuccess) e = ws_get((void**)&dQ, mx * mx * sizeof(double));
     if (e == hipSuccess) e = ws_get((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
@@ -190,7 +221,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     ra.stop = dstop; ra.A = dA; ra.Bu = dBu; ra.Bl = dBl; ra.G = dG; ra.Q = dQ; ra.R = dR; ra.K = c->K_dev; ra.kbreak = dkb; ra.status = dst; ra.work = dwork;
     if (e == hipSuccess) e = launch_riccati(ra, nullptr);
     if (e == hipSuccess) {
-        const long long nrows = (long long)np * (N - 1) * mu;
+        const long long nrows = (long long)np * (long long)nKtab * mu;
         hipLaunchKernelGGL(k_rows_to_link_order_kernel, dim3((unsigned)nrows), dim3(128), mx * sizeof(double), nullptr, c->K_dev, nrows, nb, m->dev);
         e = hipGetLastError();
     }
@@ -222,12 +253,11 @@ extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
     return CCLQR_OK;
 }
 
-// Deprecated thread-local defaults of cclqr_rollout_opts (kept one round; cclqr_rollout_ex takes them as arguments).
-static thread_local int64_t g_inst0 = 0;
-extern "C" int cclqr_set_instance_offset(int64_t first_instance) { g_inst0 = first_instance; return CCLQR_OK; }
-// forwarded to cclqr_rollout_dev launches of this thread with a PID controller only (never to the host-pointer cclqr_rollout)
-static thread_local double* g_pid_state = nullptr;
-extern "C" int cclqr_set_pid_state(double* pid_state_dev) { g_pid_state = pid_state_dev; return CCLQR_OK; }
+extern "C" int cclqr_rollout_layout_links(const cclqr_mech* m, int32_t* links) {
+    if (!m || !links) return fail(CCLQR_EINVAL, "null argument");
+    *links = (m->host.loop || m->host.tree) ? 0 : chain_layout_links(m->nb);      // 0: not a chain-kernel mechanism
+    return CCLQR_OK;
+}
 
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
@@ -244,6 +274,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     if (!m->host.loop && rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     const int64_t first = opts ? opts->first_instance : 0;
     if (first < 0) return fail(CCLQR_EINVAL, "negative first_instance");
@@ -251,48 +282,76 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     const CtrlDev& H = c->host;
     double* pid_state = (opts && H.has_pid) ? opts->pid_state_dev : nullptr;      // never forwarded to a controller without a PID law
     if (pid_state && opts->pid_state_len != n_inst * (int64_t)m->nb * 2) return fail(CCLQR_EINVAL, "pid_state_len must be n_inst * nb * 2");
-    // counter-based noise: generated for this launch into the handle's workspace, read by the rollout like an injected array
+    // counter-based noise: generated for this launch into a workspace, read by the rollout like an injected array.  The workspace is the
+    // caller's (opts->noise_ws_dev: required for launches that share one controller on different streams or threads) or the handle's,
+    // which only ever grows OUTSIDE stream capture: hipMalloc / hipFree are illegal while a stream is being captured, so a captured
+    // launch needs the workspace sized beforehand (cclqr_ctrl_reserve_noise) or passed in.
     const bool use_noise = H.noise_scale != 0.0 && H.mu > 0;
     if (use_noise && !noise && H.noise_philox && steps > 0) {
-        cclqr_ctrl* cm = const_cast<cclqr_ctrl*>(c);
         const size_t need = (size_t)n_inst * steps;
-        if (cm->noise_ws_cap < need) {
-            if (cm->noise_ws) HIPCHK(hipFree(cm->noise_ws));
-            cm->noise_ws = nullptr; cm->noise_ws_cap = 0;
-            HIPCHK(hipMalloc((void**)&cm->noise_ws, need * sizeof(double)));
-            cm->noise_ws_cap = need;
+        double* ws = nullptr;
+        if (opts && opts->noise_ws_dev) {
+            if (opts->noise_ws_len < (int64_t)need) return fail(CCLQR_EINVAL, "noise_ws_len must be at least n_inst * steps");
+            ws = opts->noise_ws_dev;
+        } else {
+            cclqr_ctrl* cm = const_cast<cclqr_ctrl*>(c);
+            if (cm->noise_ws_cap < need) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (stream) HIPCHK(hipStreamIsCapturing((hipStream_t)stream, &cap));
+                if (cap != hipStreamCaptureStatusNone)
+                    return fail(CCLQR_EINVAL, "the Philox noise workspace cannot grow during stream capture: call cclqr_ctrl_reserve_noise(ctrl, n_inst, steps) "
+                                              "before the capture or pass cclqr_rollout_opts.noise_ws_dev");
+                int rc = cclqr_ctrl_reserve_noise(cm, n_inst, steps);
+                if (rc != CCLQR_OK) return rc;
+            }
+            ws = cm->noise_ws;
         }
-        HIPCHK(launch_philox_fill(cm->noise_ws, H.noise_key0, first, n_inst, k0, steps, (hipStream_t)stream));
-        noise = cm->noise_ws - (k0 - 1);      // indexed by the absolute step k-1
+        HIPCHK(launch_philox_fill(ws, H.noise_key0, first, n_inst, k0, steps, (hipStream_t)stream));
+        noise = ws - (k0 - 1);      // indexed by the absolute step k-1
         noise_stride = steps;
     }
     const int extra = H.has_pid ? 2 : ((H.has_fric || (use_noise && noise)) ? 1 : 0);
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
+    const int newton_mode = opts ? opts->newton_mode : 0;
+    if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");
+    if (newton_mode != 0 && (m->host.loop || m->host.tree || extra != 0))
+        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists for forests of chains under the plain LQR / TrackingLQR law only");
     if (m->host.loop) {      // closed loops: plain LQR law only (build_ctrl_tables refuses the others)
         if (extra != 0 || noise) return fail(CCLQR_EUNSUPPORTED, "closed-loop mechanisms take the plain LQR law only");
         HIPCHK(launch_rollout_loop(a, m->nb, m->nj, (hipStream_t)stream));
         return CCLQR_OK;
     }
-    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, (hipStream_t)stream));
+    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, newton_mode, (hipStream_t)stream));
     return CCLQR_OK;
 }
 
 extern "C" int cclqr_rollout_dev(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
                                  double* lam, const double* noise, int64_t noise_stride, double* traj, double* zT, int32_t* status,
                                  void* stream) {
-    cclqr_rollout_opts o;
-    o.first_instance = g_inst0;
-    o.pid_state_dev = g_pid_state;
-    o.pid_state_len = (m && n_inst > 0) ? n_inst * (int64_t)m->nb * 2 : 0;     // the legacy setter carries no length
-    return cclqr_rollout_ex(m, c, n_inst, steps, k0, z0, lam, noise, noise_stride, traj, zT, status, &o, stream);
+    return cclqr_rollout_ex(m, c, n_inst, steps, k0, z0, lam, noise, noise_stride, traj, zT, status, nullptr, stream);
 }
 
-extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
-                             const double* noise, double* traj, double* zT, int32_t* status) {
+extern "C" int cclqr_ctrl_reserve_noise(cclqr_ctrl* c, int64_t n_inst, int32_t steps) {
+    if (!c || n_inst < 0 || steps < 0) return fail(CCLQR_EINVAL, "bad argument");
+    const size_t need = (size_t)n_inst * steps;
+    if (c->noise_ws_cap >= need) return CCLQR_OK;
+    // a launch that still reads the old block may be in flight on some stream: the device is drained before the block is replaced
+    HIPCHK(hipDeviceSynchronize());
+    if (c->noise_ws) HIPCHK(hipFree(c->noise_ws));
+    c->noise_ws = nullptr; c->noise_ws_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->noise_ws, (need ? need : 1) * sizeof(double)));
+    c->noise_ws_cap = need;
+    return CCLQR_OK;
+}
+
+extern "C" int cclqr_rollout_host_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                                     const double* noise, double* traj, double* zT, int32_t* status, const cclqr_rollout_opts* opts) {
     if (m && c && n_inst == 0) return CCLQR_OK;   // empty batch
     if (!m || !c || !z0 || !zT) return fail(CCLQR_EINVAL, "null argument");
+    if (opts && (opts->pid_state_dev || opts->noise_ws_dev)) return fail(CCLQR_EINVAL, "the host-pointer rollout takes no device buffers in its options");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     const size_t nz = (size_t)13 * m->nb;
     double *dz0 = nullptr, *dzT = nullptr, *dtraj = nullptr, *dnoise = nullptr;
     int32_t* dst = nullptr;
@@ -308,9 +367,7 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
     if (e == hipSuccess) {
         // noise is indexed by the absolute step k-1: shift the base so that k0 maps to column 0 of the caller's array
         const double* nbase = dnoise ? dnoise - (k0 - 1) : nullptr;
-        cclqr_rollout_opts o;
-        o.first_instance = g_inst0; o.pid_state_dev = nullptr; o.pid_state_len = 0;
-        rc = cclqr_rollout_ex(m, c, n_inst, steps, k0, dz0, nullptr, nbase, steps, dtraj, dzT, dst, &o, nullptr);
+        rc = cclqr_rollout_ex(m, c, n_inst, steps, k0, dz0, nullptr, nbase, steps, dtraj, dzT, dst, opts, nullptr);
         if (rc == CCLQR_OK) e = hipDeviceSynchronize();
     }
     if (rc == CCLQR_OK && e == hipSuccess) e = hipMemcpy(zT, dzT, n_inst * nz * sizeof(double), hipMemcpyDeviceToHost);
@@ -321,10 +378,16 @@ extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n
     return CCLQR_OK;
 }
 
+extern "C" int cclqr_rollout(const cclqr_mech* m, const cclqr_ctrl* c, int64_t n_inst, int32_t steps, int32_t k0, const double* z0,
+                             const double* noise, double* traj, double* zT, int32_t* status) {
+    return cclqr_rollout_host_ex(m, c, n_inst, steps, k0, z0, noise, traj, zT, status, nullptr);
+}
+
 extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
                                double* A, double* Bu, double* Bl, double* G) {
     if (!m || !zd || !A || !Bl || !G || (mu > 0 && (!ctrl_joint || !Bu))) return fail(CCLQR_EINVAL, "null argument");
-    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "linearsystem of a closed-loop mechanism (redundant constraint rows) is outside this build's scope");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
+    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "linearsystem of a closed-loop mechanism divides by the singular G*Bl (lqr.jl:151): use cclqr_linearize_projected");
     if (nk < 0 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
     const int nb = m->nb;
@@ -399,6 +462,7 @@ __global__ void fd_quotient_kernel(const double* zT, int nk, int per, int nb, in
 extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
                                          double h, double* Ap, double* D) {
     if (!m || !zd || !Ap || (mu > 0 && (!ctrl_joint || !D))) return fail(CCLQR_EINVAL, "null argument");
+    { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     if (nk < 0 || mu < 0 || mu > m->nj) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
     if (!(h > 0.0)) h = 1e-6;
@@ -476,7 +540,8 @@ extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const 
 static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varying, double tol, const double* dA, const double* dBu,
                        const double* dBl, const double* dG, const double* Q, const double* R, double* K, int32_t* kbreak,
                        const cclqr_riccati_opts* opts) {
-    const size_t nK = (size_t)nprob * (N > 1 ? N - 1 : 0) * mu * mx;
+    const int keep_last = (opts && opts->keep_last) ? 1 : 0;
+    const size_t nK = (size_t)nprob * (N > 1 ? (keep_last ? 1 : N - 1) : 0) * mu * mx;
     double *dQ = nullptr, *dR = nullptr, *dK = nullptr, *dwork = nullptr;
     int *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
     std::vector<int> st(nprob), kb(nprob);
@@ -484,6 +549,7 @@ static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varyin
     a.nprob = nprob; a.mx = mx; a.mu = mu; a.ml = ml; a.N = N; a.time_varying = time_varying; a.tol = tol;
     a.path = opts ? opts->path : 0;
     a.bf16_terms = opts ? opts->bf16_terms : 0;
+    a.keep_last = keep_last;
     if (a.path < 0 || a.path > 2 || a.bf16_terms < 0 || a.bf16_terms > 3) return fail(CCLQR_EINVAL, "riccati options: path in 0..2, bf16_terms in 0..3");
     const size_t wd = ric_total_work_doubles(a);
     hipError_t e = ws_get((void**)&dQ, (size_t)mx * mx * sizeof(double));
@@ -508,12 +574,6 @@ static int run_riccati(int nprob, int mx, int mu, int ml, int N, int time_varyin
         if (kbreak) kbreak[p] = kb[p];
         if (st[p] != 0) return fail(CCLQR_ESINGULAR, "G*Bl or M is singular in problem " + std::to_string(p));
     }
-    return CCLQR_OK;
-}
-
-extern "C" int cclqr_riccati_path(int32_t path) {
-    if (path < 0 || path > 2) return fail(CCLQR_EINVAL, "riccati path must be 0 (auto), 1 (persistent) or 2 (tiled)");
-    set_riccati_path(path);
     return CCLQR_OK;
 }
 

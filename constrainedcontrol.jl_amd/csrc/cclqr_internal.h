@@ -25,15 +25,19 @@ struct RolloutArgs {
     int* status;          // [n_inst] or null
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) instead of once per launch: remembers the largest size set so
+// far and only calls the runtime when a launch needs more (capi.hip)
+hipError_t set_max_dynamic_lds_once(const void* fn, size_t lds);
+
 int rollout_lanes_per_instance(int nb, int tree);
 size_t rollout_lds_bytes(int nb, int tree, int npairs);
-hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, hipStream_t stream);
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, int newton_mode, hipStream_t stream);
 hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long long n_inst, int k0, int steps, hipStream_t stream);
 // forests of chains (rollout_chain.hip)
 int chain_lanes_per_instance(int nb);
 int chain_layout_links(int nb);
 size_t chain_lds_bytes(int nb);
-hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, hipStream_t stream);
+hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream);
 // closed-loop mechanisms (rollout_loop.hip)
 size_t loop_lds_bytes(int nb, int nj);
 hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, hipStream_t stream);
@@ -55,16 +59,16 @@ struct RicArgs {
     int time_varying;        // 1: A,Bu,Bl,G are [N-1][...] per problem (knot k uses index k-1)
     double tol;
     const double *A, *Bu, *Bl, *G, *Q, *R;
-    double* K;               // [nprob][N-1][mu][mx]
+    double* K;               // [nprob][N-1][mu][mx] ([nprob][mu][mx] with keep_last)
     int* kbreak;             // [nprob]
     int* status;             // [nprob]
     double* work;            // ric_total_work_doubles(args) doubles
     int* stop;               // [nprob] scratch flags of the tiled path
-    int path;                // 0: the process default (set_riccati_path), 1 resident, 2 tiled
+    int path;                // 0: chosen by problem size and count, 1 resident, 2 tiled
     int bf16_terms;          // 0: fp64 MFMA; 1..3: split-bf16 products with fp32 accumulation (tiled path)
+    int keep_last;           // 1: K is [nprob][mu][mx], the gain of the last executed backward step (= Ku[1] after the back-fill)
 };
 size_t ric_total_work_doubles(const RicArgs& a);
-void set_riccati_path(int p);   // 0 auto / 1: LDS-resident workgroup per problem whenever it fits; 2: tiled (three launches per backward step)
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream);
 
 }  // namespace cclqr

@@ -68,7 +68,7 @@ hipError_t launch_linearize(const LinArgs& a, int nb, int tree, int npairs, hipS
     if (a.nk <= 0) return hipSuccess;
     const size_t lds = linearize_lds_bytes(nb, tree, npairs);
     const void* fn = tree ? (const void*)linearize_kernel<true> : (const void*)linearize_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds_once(fn, lds);
     if (e != hipSuccess) return e;
     if (tree) hipLaunchKernelGGL(linearize_kernel<true>, dim3(a.nk), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL(linearize_kernel<false>, dim3(a.nk), dim3(64), lds, stream, a);

@@ -202,6 +202,8 @@ struct RicGrid {
     const double *A, *Bu, *Bl, *G, *Q, *R;
     double *AD, *W, *Abar, *P, *Ku, *KRK, *part, *TSp, *scratch, *K;
     int *stop, *kbreak, *status;
+    int keep_last;     // 1: only the gain of the last executed backward step is kept (K [nprob][mu][mx] = Ku[1] after the back-fill of
+                       // lqr.jl:179-181 = the one gain LQR{T,Inf} keeps, lqr.jl:40-43); 0: the whole table K [nprob][N-1][mu][mx]
     int bf16_terms;    // 0: fp64 MFMA (parity mode); 1..3: the two mx^3 products of a backward step on bf16 MFMA with fp32 accumulation,
                        // every fp64 operand split into that many bf16 terms (measured-error mode, BASELINE configs[3]; tiled path only)
 };
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_gain_update_kernel(RicGrid a
     if (sing) { if (lead && tid == 0) { a.status[prob] = CCLQR_ESINGULAR_; a.stop[prob] = 1; a.kbreak[prob] = k; } return; }
     double* Ku = a.Ku + (size_t)prob * mu * mx;
     double* KRK = a.KRK + (size_t)prob * mu * mx;
-    double* Kout = a.K + ((size_t)prob * (a.N - 1) + (k - 1)) * mu * mx;
+    double* Kout = a.K + (a.keep_last ? (size_t)prob : ((size_t)prob * (a.N - 1) + (k - 1))) * mu * mx;
     for (int j = tid; j < mx; j += TILE_THREADS) {
         for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[(size_t)c * na + j]; TS[(size_t)c * na + j] = TS[(size_t)p * na + j]; TS[(size_t)p * na + j] = t; } }
         for (int i = 1; i < mu; i++) { double sacc = TS[(size_t)i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[(size_t)r * na + j]; TS[(size_t)i * na + j] = sacc; }
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
     lds_double* red = Rl + (size_t)mu * mu;
     int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2));
     double* Abar = a.Abar + (size_t)prob * mx * mx;
-    double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
+    double* Kout = a.K + (size_t)prob * (a.keep_last ? 1 : (N > 1 ? N - 1 : 0)) * mu * mx;
     if (tid == 0) sing = 0;
     for (int e = tid; e < mx * mx; e += RIC_THREADS) P[e] = a.Q[e];       // Pk = Q                                  lqr.jl:147
     for (int e = tid; e < mu * mu; e += RIC_THREADS) Rl[e] = a.R[e];
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 for (int r = i + 1; r < mu; r++) sacc -= S[i * mu + r] * TS[r * na + j];
                 TS[i * na + j] = sacc / S[i * mu + i];
             }
-            for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(size_t)(k - 1) * mu * mx + (size_t)q * mx + j] = v; }   // lqr.jl:162-164
+            for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(a.keep_last ? 0 : (size_t)(k - 1) * mu * mx) + (size_t)q * mx + j] = v; }   // lqr.jl:162-164 (keep_last: one slot, the last step's gain stays)
             for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += Rl[q * mu + r] * TS[r * na + j]; KRK[q * mx + j] = sacc; }
         }
         __syncthreads();
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         if (k < 1 && N - 1 >= 1) k = 1;   // Julia: after a completed loop the outer k holds its last value
         if (N - 1 < 1) k = 0;
         __syncthreads();
-        for (int k2 = k - 1; k2 >= 1; k2--) {                             // Ku[k2] = Ku[k2+1]                       lqr.jl:179-181
+        for (int k2 = k - 1; k2 >= 1 && !a.keep_last; k2--) {             // Ku[k2] = Ku[k2+1]                       lqr.jl:179-181
             for (int e = tid; e < mu * mx; e += RIC_THREADS) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
             __syncthreads();
         }
@@ -772,7 +774,7 @@ __global__ void ric_backfill_kernel(RicGrid a) {
         kb = k;
     }
     __syncthreads();
-    if (a.status[prob] != 0) return;
+    if (a.status[prob] != 0 || a.keep_last) return;
     double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
     for (int k2 = kb - 1; k2 >= 1; k2--) {
         for (int e = tid; e < mu * mx; e += blockDim.x) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
@@ -780,8 +782,6 @@ __global__ void ric_backfill_kernel(RicGrid a) {
     }
 }
 
-static int g_ric_path = 0;   // 0 auto, 1 persistent workgroup per problem, 2 tiled
-void set_riccati_path(int p) { g_ric_path = p; }
 
 size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_varying) {
     const size_t nlin = time_varying ? (size_t)(N > 1 ? N - 1 : 1) : 1, na = (size_t)mx + mu, tm = (mx + 31) / 32;
@@ -793,7 +793,7 @@ static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(
 // resident (one workgroup per problem, P and W in LDS) whenever it fits; otherwise the tiled three-launch step
 static bool ric_use_tiled(const RicArgs& a) {
     if (!ric_resident_fits(a) || a.bf16_terms > 0) return true;       // the measured-error mode exists on the tiled path only
-    const int path = a.path != 0 ? a.path : g_ric_path;
+    const int path = a.path;      // 0 auto, 1 LDS-resident workgroup per problem, 2 tiled
     if (path != 0) return path == 2;
     // measured crossover: a single 84..96-state problem is faster spread over the device (41 vs 59 us per step), small problems
     // and large batches are faster resident (mx 48: 14 vs 20 us; 1024 x mx 84: 0.54 vs 0.74 ms per step)
@@ -806,7 +806,7 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
     RicGrid g;
     g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
-    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms;
+    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms; g.keep_last = a.keep_last;
     g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = a.stop;
     const size_t np = a.nprob, nlin = g.nlin, mx = a.mx, na = g.na, mu = a.mu, ml = a.ml;
     double* o = a.work;
@@ -834,7 +834,7 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
         lds = (ml * ml + ml * c) * sizeof(double);        // G Bλ for the pivoted LU + one batch of right-hand-side columns
     }
     if (lds > 0) {
-        e = hipFuncSetAttribute((const void*)ric_project_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds_once((const void*)ric_project_kernel<true>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(ric_project_kernel<true>, dim3(g.nlin, a.nprob), dim3(RIC_THREADS), lds, stream, g, cols);
     } else {
@@ -842,14 +842,14 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     }
     if (!ric_use_tiled(a)) {
         const size_t rl = ric_resident_lds_bytes(a.mx, a.mu);
-        e = hipFuncSetAttribute((const void*)riccati_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+        e = set_max_dynamic_lds_once((const void*)riccati_resident_kernel, rl);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(riccati_resident_kernel, dim3(a.nprob), dim3(RIC_THREADS), rl, stream, g);
         return hipGetLastError();
     }
     const size_t lds_gain = (mu * na + mu * mu + 2 * RU * mu) * sizeof(double) + (mu + 2) * sizeof(int), lds_pn = 2 * mu * 32 * sizeof(double);
     if (lds_gain > 48 * 1024) {
-        e = hipFuncSetAttribute((const void*)ric_gain_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gain);
+        e = set_max_dynamic_lds_once((const void*)ric_gain_update_kernel, lds_gain);
         if (e != hipSuccess) return e;
     }
     for (int k = a.N - 1; k >= 1; k--) {                                 // for outer k=N-1:-1:1                    lqr.jl:150

@@ -166,7 +166,7 @@ size_t rollout_lds_bytes(int nb, int tree, int npairs) {
 template <int G, bool TREE>
 static hipError_t launch_one(const RolloutArgs& a, int extra, unsigned grid, size_t lds, hipStream_t stream) {
     const void* f = extra == 0 ? (const void*)rollout_kernel<G, TREE, 0> : (extra == 1 ? (const void*)rollout_kernel<G, TREE, 1> : (const void*)rollout_kernel<G, TREE, 2>);
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds_once(f, lds);
     if (e != hipSuccess) return e;
     if (extra == 0) hipLaunchKernelGGL((rollout_kernel<G, TREE, 0>), dim3(grid), dim3(64), lds, stream, a);
     else if (extra == 1) hipLaunchKernelGGL((rollout_kernel<G, TREE, 1>), dim3(grid), dim3(64), lds, stream, a);
@@ -174,8 +174,8 @@ static hipError_t launch_one(const RolloutArgs& a, int extra, unsigned grid, siz
     return hipGetLastError();
 }
 
-hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, hipStream_t stream) {
-    if (!tree) return launch_rollout_chain(a, nb, extra, stream);   // forests of chains: the register-resident kernel (rollout_chain.hip)
+hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, int newton_mode, hipStream_t stream) {
+    if (!tree) return launch_rollout_chain(a, nb, extra, newton_mode, stream);   // forests of chains: the register-resident kernel (rollout_chain.hip)
     const int G = rollout_lanes_per_instance(nb, tree);
     const int per_wg = 64 / G;
     const size_t lds = rollout_lds_bytes(nb, tree, npairs);

@@ -197,7 +197,7 @@ size_t loop_lds_bytes(int nb, int nj) { return (size_t)make_loop_layout(nb, nj).
 hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, hipStream_t stream) {
     if (a.n_inst <= 0) return hipSuccess;
     const size_t lds = loop_lds_bytes(nb, nj);
-    hipError_t e = hipFuncSetAttribute((const void*)rollout_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds_once((const void*)rollout_loop_kernel, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rollout_loop_kernel, dim3((unsigned)a.n_inst), dim3(64), lds, stream, a);
     return hipGetLastError();

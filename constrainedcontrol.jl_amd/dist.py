@@ -19,7 +19,7 @@ def shard(array, rank, world):
     return array[lo:hi]
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_init=False):
     """torch.distributed init from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun); returns (rank, world, local_rank).
 
     backend None = "nccl" (RCCL) when a GPU is visible, else "gloo".  There is NO fallback: if RCCL cannot be initialised the
@@ -29,7 +29,7 @@ def init_from_env(backend=None):
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_init) and not dist.is_initialized():      # force_init: a one-rank process group (the RCCL smoke test)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL's cross-process buffer sharing needs dmabuf IPC on this driver
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -46,29 +46,49 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class RootGather:
+    """Fixed-size rooted gather of per-rank blocks [n_local, ...] into [n_total, ...] on rank 0 with every buffer allocated ONCE
+    (the padded send block, the N receive blocks and the assembled result): nothing is allocated or concatenated inside a timed
+    region.  Blocks are padded to the largest shard so that one gather moves everything: each peer sends its block straight to
+    the root over its own link instead of circulating a ring.  `force_collective` makes a single rank call the collective too
+    (the RCCL smoke test: one process, world_size 1)."""
+
+    def __init__(self, n_total, tail_shape, dtype, device, rank, world, dst=0, force_collective=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.dst, self.n_total = rank, world, dst, int(n_total)
+        self.collective = world > 1 or force_collective
+        self.sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+        self.nmax = max(self.sizes) if self.sizes else 0
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.host_staged = self.collective and dist.is_initialized() and dist.get_backend() == "gloo" and self.device.type == "cuda"
+        cdev = torch.device("cpu") if self.host_staged else self.device      # gloo rehearsal of the GPU path: host buffers carry the collective
+        shape = (self.nmax,) + tuple(tail_shape)
+        self.pad = torch.zeros(shape, dtype=dtype, device=cdev) if self.collective else None
+        self.bufs = [torch.empty(shape, dtype=dtype, device=cdev) for _ in range(world)] if (self.collective and rank == dst) else None
+        self.out = torch.empty((self.n_total,) + tuple(tail_shape), dtype=dtype, device=self.device) if (self.collective and rank == dst) else None
+
+    def __call__(self, local):
+        if not self.collective:
+            return local
+        assert local.shape[0] == self.sizes[self.rank], "block size does not match this rank's shard"
+        self.pad[:local.shape[0]].copy_(local)
+        self.dist.gather(self.pad, self.bufs, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        lo = 0
+        for r in range(self.world):
+            self.out[lo:lo + self.sizes[r]].copy_(self.bufs[r][:self.sizes[r]], non_blocking=True)
+            lo += self.sizes[r]
+        return self.out
+
+
 def gather_to_root(local, n_total, rank, world, dst=0):
-    """gather per-rank blocks (torch tensors [n_local, ...]) into [n_total, ...] on `dst` (None elsewhere).
-    Blocks are padded to the largest shard so that ONE fixed-size gather moves everything: each peer sends its block
-    straight to the root over its own link instead of circulating a ring."""
-    import torch
-    import torch.distributed as dist
+    """one-off form of RootGather (numpy helpers, tests): allocates its buffers per call -- timed loops keep a RootGather"""
     if world == 1:
         return local
-    sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
-    nmax = max(sizes)
-    pad = local
-    if local.shape[0] < nmax:
-        pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[:local.shape[0]] = local
-    pad = pad.contiguous()
-    dev = pad.device
-    if dist.get_backend() == "gloo" and pad.is_cuda:
-        pad = pad.cpu()          # gloo rehearsal of the GPU path: the collective itself runs on host buffers
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0).to(dev)
+    return RootGather(n_total, tuple(local.shape[1:]), local.dtype, local.device, rank, world, dst)(local)
 
 
 class TrajectoryGather:
@@ -85,7 +105,7 @@ class TrajectoryGather:
     24 M instance-steps/s and nb = 17 that is 42 GB/s per GPU = 27 % of a link, so the transfer hides behind compute except
     for the last chunk: exposed time ~ (bytes of one chunk) / link rate + the root's copies."""
 
-    def __init__(self, rank, world, n_local, T, nb, chunks, device, dtype=None):
+    def __init__(self, rank, world, n_local, T, nb, chunks, device, dtype=None, force_collective=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -94,11 +114,13 @@ class TrajectoryGather:
         self.device = device
         dtype = dtype or torch.float64
         self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.gloo_on_gpu = self.cuda and world > 1 and dist.get_backend() == "gloo"
+        # force_collective: a single rank (world_size 1, process group initialised) really calls dist.gather -- the RCCL smoke test
+        self.collective = world > 1 or force_collective
+        self.gloo_on_gpu = self.cuda and self.collective and dist.get_backend() == "gloo"
         self.slabs = [torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=device) for _ in range(2)]
         self.out = torch.empty((n_local * world, T, nb, 13), dtype=dtype, device=device) if rank == 0 else None
         self.recv = None
-        if rank == 0 and world > 1:
+        if rank == 0 and self.collective:
             rdev = "cpu" if self.gloo_on_gpu else device
             self.recv = [[torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=rdev) for _ in range(world)] for _ in range(2)]
         self.comm = torch.cuda.Stream(device=device) if self.cuda else None
@@ -128,7 +150,7 @@ class TrajectoryGather:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            if self.world == 1:
+            if not self.collective:
                 self.out[:, t0:t1].copy_(slab)
             else:
                 send = slab.cpu() if self.gloo_on_gpu else slab

@@ -290,11 +290,9 @@ def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=
     if (noise is not None or noise_seed is not None) and noise_scale is None:
         noise_scale = 1.0
     ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale, noise_seed=noise_seed)
-    _capi.set_instance_offset(first_instance)
     try:
-        zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record)
+        zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record, first_instance=first_instance)
     finally:
-        _capi.set_instance_offset(0)
         ctrl.close()
     mechanism.set_state(zT[0])
     if isinstance(tend_or_storage, Storage) and record:

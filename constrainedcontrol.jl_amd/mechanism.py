@@ -278,6 +278,59 @@ def setJointPosition(mech, eqc, θ):
         setPosition(j.body1, j.body2, p1=j.p1, p2=j.p2, Δx=θ * a, Δq=j.qoffset)
 
 
+def joint_position_states(mech, θ):
+    """batch form of `setPosition!(mech, eqc, [θ])` applied to every joint of a TREE mechanism in root-to-leaf order (the loop of
+    examples/lqr_sawyer.jl:11-14 for n poses at once): θ [n][ne] joint coordinates in the order of mech.eqconstraints -> z [n][nb][13]
+    at rest.  Same arithmetic as setJointPosition / setPosition, vectorised over the batch (workload generator of bench.py)."""
+    θ = np.asarray(θ, dtype=np.float64).reshape(-1, len(mech.eqconstraints))
+    n, nb = θ.shape[0], len(mech.bodies)
+    index = {id(b): i for i, b in enumerate(mech.bodies)}
+    z = np.zeros((n, nb, 13))
+    z[:, :, 3] = 1.0
+
+    def bq(a, b):          # batched quaternion product, either operand [4] or [n][4]
+        a, b = np.broadcast_to(a, (n, 4)), np.broadcast_to(b, (n, 4))
+        w = a[:, 0] * b[:, 0] - np.einsum("ij,ij->i", a[:, 1:], b[:, 1:])
+        v = a[:, 0:1] * b[:, 1:] + b[:, 0:1] * a[:, 1:] + np.cross(a[:, 1:], b[:, 1:])
+        return np.concatenate([w[:, None], v], axis=1)
+
+    def brot(p, q):        # R(q) p, p [3] or [n][3]
+        p = np.broadcast_to(p, (n, 3))
+        t = 2.0 * np.cross(q[:, 1:], p)
+        return p + q[:, 0:1] * t + np.cross(q[:, 1:], t)
+
+    done = set()
+    pending = list(enumerate(mech.eqconstraints))
+    while pending:
+        rest = []
+        for k, e in pending:
+            j = e.joint
+            pa = index.get(id(j.body1), -1)
+            if pa >= 0 and pa not in done:
+                rest.append((k, e))
+                continue
+            ch = index[id(j.body2)]
+            if pa >= 0:
+                q1, x1 = z[:, pa, 3:7], z[:, pa, 0:3]
+            else:
+                q1, x1 = np.broadcast_to(j.body1.state.qc, (n, 4)), np.broadcast_to(j.body1.state.xc, (n, 3))
+            a = j.axis / np.linalg.norm(j.axis)
+            if j.kind == REVOLUTE:
+                dq = bq(np.concatenate([np.cos(θ[:, k:k + 1] / 2), np.sin(θ[:, k:k + 1] / 2) * a[None]], axis=1), j.qoffset)
+                dx = np.zeros((n, 3))
+            else:
+                dq = np.broadcast_to(j.qoffset, (n, 4))
+                dx = θ[:, k:k + 1] * a[None]
+            q2 = bq(q1, dq)
+            z[:, ch, 3:7] = q2
+            z[:, ch, 0:3] = x1 + brot(j.p1 + dx, q1) - brot(j.p2, q2)
+            done.add(ch)
+        if len(rest) == len(pending):
+            raise ValueError("joint_position_states: the mechanism is not a tree hung off the origin")
+        pending = rest
+    return z
+
+
 # ------------------------------------------------------------------ URDF subset (SURVEY 8f-2): Mechanism(path, floating=false, g=0.0)
 def parse_urdf(path):
     """links (mass, COM offset, inertia about the COM in the link frame) and revolute/prismatic joints of a URDF file.

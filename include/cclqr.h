@@ -27,7 +27,12 @@ extern "C" {
 #define CCLQR_ESINGULAR -2    /* G*Bl or M singular        (LAPACK exception from lqr.jl:151,160) */
 #define CCLQR_ENOCONV -3      /* soft: Newton / Riccati did not converge (lqr.jl:41 `@info`) */
 #define CCLQR_EHIP -4         /* HIP runtime error; cclqr_last_error() has the text */
-#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (LQR construction on closed loops, > 4 child joints on a body, nb > 32) */
+#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (> 4 child joints on a body, nb > 32, friction / noise / PID laws on closed loops) */
+
+/* ABI version = cclqr_version().  A shim built against another header must refuse to run: the structs below are passed by pointer and
+ * read in full.  200: cclqr_ctrl_desc.n_ctrl, cclqr_rollout_opts {noise_ws_dev, noise_ws_len, newton_mode}, cclqr_riccati_opts.keep_last,
+ * the thread-local setters (cclqr_set_instance_offset, cclqr_set_pid_state, cclqr_riccati_path) removed. */
+#define CCLQR_ABI_VERSION 200
 
 #define CCLQR_REVOLUTE 0      /* EqualityConstraint(Revolute(a, b, axis; p1, p2, qoffset)),  examples/lqr_cartpole.jl:26 */
 #define CCLQR_PRISMATIC 1     /* EqualityConstraint(Prismatic(a, b, axis; p1, p2, qoffset)), examples/lqr_cartpole.jl:25 */
@@ -37,7 +42,8 @@ extern "C" {
  * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
  * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
  * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (plain LQR law, one instance per wavefront, multipliers lam
- * [n_inst][5*ne]); cclqr_linearize / cclqr_riccati_tracking return CCLQR_EUNSUPPORTED for them. */
+ * [n_inst][5*ne]); LQR / TrackingLQR construction goes through cclqr_linearize_projected + cclqr_riccati / cclqr_riccati_tv with ml = 0
+ * (cclqr_linearize / cclqr_riccati_tracking, which divide by the singular G*Bλ, return CCLQR_EUNSUPPORTED for them). */
 typedef struct {
     int32_t nb, ne;
     double dt, g;          /* mechanism.Δt (lqr.jl:65), gravity along z */
@@ -65,7 +71,7 @@ typedef struct {
     const double *fric;        /* [ne] viscous joint friction of examples/trackingLQR_triple_cartpole.jl:98-101, or NULL */
     double noise_scale;        /* cart noise amplitude, same file :98 (`randn()*2`); 0 = none */
     /* PID{T,N} (src/control/pid.jl:3-40) on 1-DoF joints in minimal coordinates; control_pid! (pid.jl:69-88) runs every step.
-     * The integrated / last errors live for one launch unless cclqr_set_pid_state provides a buffer. npid = 0: none. */
+     * The integrated / last errors live for one launch unless cclqr_rollout_opts.pid_state_dev provides a buffer. npid = 0: none. */
     int32_t npid;
     const int32_t *pid_joint;  /* [npid] joint indices (eqcids) */
     const double *pid_P, *pid_I, *pid_D, *pid_goal; /* [npid]  P, I, D, goals (pid.jl:4-9) */
@@ -85,7 +91,7 @@ typedef struct cclqr_mech cclqr_mech; /* opaque: device-resident mechanism table
 typedef struct cclqr_ctrl cclqr_ctrl; /* opaque: device-resident controller tables */
 
 const char *cclqr_last_error(void);
-int cclqr_version(void);
+int cclqr_version(void);     /* CCLQR_ABI_VERSION of the library that was loaded */
 int cclqr_device_count(int32_t *n);
 int cclqr_set_device(int32_t dev);
 
@@ -101,9 +107,13 @@ int cclqr_ctrl_destroy(cclqr_ctrl *c);
  * (SURVEY 8d configs[3]: "Riccati run per instance on distinct setpoints"): linearsystem at every zd[i] (lqr.jl:63), dlqr (lqr.jl:141-184)
  * and the per-instance controller tables of cclqr_ctrl_create (instance n of a rollout reads table first_instance + n) without the gains
  * -- n_ctrl (N-1) mu 12 nb doubles: 1 GB for 1024 seven-joint arms at N = 200 -- ever visiting the host.  Q [mx][mx], R [mu][mu] already Δt-scaled
- * (lqr.jl:18-19), N = horizon in steps, zd [n_ctrl][nb][13], Fd [n_ctrl][mu] or NULL, kbreak [n_ctrl] or NULL.  Tree mechanisms. */
+ * (lqr.jl:18-19), N = horizon in steps, zd [n_ctrl][nb][13], Fd [n_ctrl][mu] or NULL, kbreak [n_ctrl] or NULL.  Tree mechanisms.
+ * infinite_horizon != 0: LQR{T,Inf} (horizon = Inf, lqr.jl:25-27 and 40-43) -- N is Ntemp = ceil(10/Δt), the recursion runs its N-1 steps
+ * (or breaks, lqr.jl:172), only Ku[1] is kept (n_ctrl mu 12 nb doubles: 39 MB for 8192 seven-joint arms) and control_lqr! is never gated
+ * (lqr.jl:116-139); a problem whose recursion has not converged is reported through kbreak[i] == 1 (lqr.jl:41 `@info`). */
 int cclqr_ctrl_create_lqr_batch(const cclqr_mech *m, int32_t n_ctrl, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
-                                const double *Q, const double *R, int32_t N, double tol, int32_t *kbreak, cclqr_ctrl **out);
+                                const double *Q, const double *R, int32_t N, int32_t infinite_horizon, double tol, int32_t *kbreak,
+                                cclqr_ctrl **out);
 
 /* linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) -- call sites lqr.jl:63, lqr_tracking.jl:88.
  * Batched over nk knots (nk = 1 for LQR, N-1 for TrackingLQR).  Host pointers.
@@ -121,7 +131,8 @@ int cclqr_linearize_projected(const cclqr_mech *m, int32_t nk, const double *zd,
 
 /* dlqr(A, Bu, Bλ, G, Q, R, N) -- lqr.jl:141-184, batched over nprob independent problems (nprob = 1 in the reference).
  * Q [mx][mx] and R [mu][mu] are the already Δt-scaled block-diagonal weights (lqr.jl:18-19).
- * K [nprob][N-1][mu][mx]; kbreak [nprob] = value of the loop index k after the loop (lqr.jl:172-181). Host pointers. */
+ * K [nprob][N-1][mu][mx] ([nprob][mu][mx] with cclqr_riccati_opts.keep_last); kbreak [nprob] = value of the loop index k after the loop
+ * (lqr.jl:172-181). Host pointers. */
 int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
                   const double *Q, const double *R, int32_t N, double tol, double *K, int32_t *kbreak);
 
@@ -132,10 +143,14 @@ int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const doubl
  *               BASELINE configs[3] ("dense Riccati on MFMA bf16 -> fp32 accumulate"): the two mx^3 products of a backward step
  *               (lqr.jl:170) run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, every fp64 operand split into that many bf16
  *               terms (1 = plain bf16, 3 = bf16x3); forces path 2.  Its gain error and speed are reported, not promised
- *               (DESIGN.md 4.3): it does NOT reproduce the fp64 gains and the 1e-5 break test of lqr.jl:172 never fires. */
+ *               (DESIGN.md 4.3): it does NOT reproduce the fp64 gains and the 1e-5 break test of lqr.jl:172 never fires.
+ *   keep_last   != 0: K is [nprob][mu][mx] and receives only the gain of the last executed backward step = Ku[1] after the back-fill of
+ *               lqr.jl:179-181 = the single gain LQR{T,Inf} keeps (lqr.jl:40-43); the (N-1)-fold table is never materialised. */
 typedef struct {
     int32_t path;
     int32_t bf16_terms;
+    int32_t keep_last;
+    int32_t reserved;
 } cclqr_riccati_opts;
 
 int cclqr_riccati_ex(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const double *A, const double *Bu, const double *Bl, const double *G,
@@ -143,14 +158,12 @@ int cclqr_riccati_ex(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const do
 int cclqr_riccati_tracking_ex(const cclqr_mech *m, int32_t mu, const int32_t *ctrl_joint, const double *zd, const double *Fd, const double *Q,
                               const double *R, int32_t N, double tol, double *K, int32_t *kbreak, const cclqr_riccati_opts *opts);
 
-/* Device workspaces of the host-pointer entry points (cclqr_linearize, cclqr_riccati*, cclqr_rollout) are cached per calling thread and
- * reused by the next call; this returns them to the driver (they are re-allocated on demand). */
+/* Device workspaces of the host-pointer entry points (cclqr_linearize, cclqr_riccati*, cclqr_rollout) are cached per calling thread, on
+ * the device that thread was on when they were allocated, and reused by the next call; after cclqr_set_device to another GPU the next
+ * call releases them there and starts a cache on the new device.  This returns them to the driver (they are re-allocated on demand);
+ * a thread that exits without calling it leaves its blocks allocated until the process ends.  Every entry point that takes a
+ * cclqr_mech returns CCLQR_EINVAL when the calling thread is not on the device the handle was created on. */
 int cclqr_release_workspaces(void);
-
-/* Deprecated process-wide default of cclqr_riccati_opts.path (kept one round).  Tuning knob for the two dlqr entry points (lqr.jl:141, lqr_tracking.jl:73): 0 = choose by problem size and count (default), 1 = one
- * LDS-resident workgroup per problem whenever the problem fits (mx up to ~96), 2 = every backward step tiled over the whole device.
- * Same results either way. */
-int cclqr_riccati_path(int32_t path);
 
 /* The recursion of lqr_tracking.jl:73-122 on per-knot linear models the caller brings: A [N-1][mx][mx], Bu [N-1][mx][mu], Bl [N-1][mx][ml],
  * G [N-1][ml][mx] (knot k = 1 .. N-1 at index k-1, as cclqr_riccati_tracking linearises them itself); ml = 0 with the projected pairs of
@@ -178,32 +191,53 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
                       double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
                       int32_t *status_dev, void *stream);
 
-/* Per-launch options of cclqr_rollout_ex (all zero = defaults).
+/* Per-launch options of cclqr_rollout_ex (NULL or all zero = defaults).
  *   first_instance  global index of instance 0 of this launch: the Philox noise stream (noise_philox) and the per-instance
  *                   controller table (n_ctrl > 1) of an instance are keyed by its GLOBAL index, so rank r of a sharded batch
  *                   passes its shard's first index and reproduces the unsharded batch;
  *   pid_state_dev   DEVICE buffer [n_inst][nb][2] (integrated error, last error per joint, opaque order) that carries the PID
  *                   integrators of pid.jl:10-11 between launches: read when k0 > 1, always written; only used by controllers with
  *                   npid > 0.  NULL: they live for one launch;
- *   pid_state_len   doubles in that buffer (checked against n_inst * nb * 2). */
+ *   pid_state_len   doubles in that buffer (checked against n_inst * nb * 2);
+ *   noise_ws_dev    DEVICE workspace of n_inst * steps doubles for the launch's Philox samples (noise_philox controllers without an
+ *                   injected noise array).  NULL: the controller handle's own workspace is used -- ONE buffer per handle, so two
+ *                   launches that share a controller on different streams or host threads must each bring their own here, and
+ *                   the handle's buffer cannot grow while `stream` is being captured into a hipGraph (CCLQR_EINVAL: size it first
+ *                   with cclqr_ctrl_reserve_noise);
+ *   noise_ws_len    doubles in that workspace (checked against n_inst * steps);
+ *   newton_mode     0 = the reference's stopping rule, ||f|| < eps AND ||step taken|| < eps (the PARITY mode).
+ *                   1 = measured-error mode: a Newton solve stops on ||f|| < eps alone.  Saves the iterations the exact rule spends
+ *                   halving steps on round-off noise; the state deviation from mode 0 is reported, not promised.
+ *                   Forests of chains only (branching trees and closed loops: CCLQR_EUNSUPPORTED). */
 typedef struct {
     int64_t first_instance;
     double *pid_state_dev;
     int64_t pid_state_len;
+    double *noise_ws_dev;
+    int64_t noise_ws_len;
+    int32_t newton_mode;
+    int32_t reserved;
 } cclqr_rollout_opts;
 
-/* cclqr_rollout_dev with explicit options instead of the thread-local setters below (opts may be NULL). */
+/* cclqr_rollout_dev with explicit options (opts may be NULL = cclqr_rollout_dev). */
 int cclqr_rollout_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0_dev,
                      double *lam_dev, const double *noise_dev, int64_t noise_stride, double *traj_dev, double *zT_dev,
                      int32_t *status_dev, const cclqr_rollout_opts *opts, void *stream);
 
-/* Deprecated (kept one round): thread-local defaults of the two options for cclqr_rollout_dev (and of first_instance for
- * cclqr_rollout).  The PID buffer set here is only ever handed to a controller with npid > 0. */
-int cclqr_set_instance_offset(int64_t first_instance);
-int cclqr_set_pid_state(double *pid_state_dev);
+/* cclqr_rollout (HOST pointers) with options: first_instance and newton_mode apply, the device-buffer fields must be NULL. */
+int cclqr_rollout_host_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0,
+                          const double *noise, double *traj, double *zT, int32_t *status, const cclqr_rollout_opts *opts);
 
-/* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py) */
+/* Sizes the controller handle's Philox noise workspace for launches of up to n_inst * steps samples (the `randn()` stream of
+ * examples/trackingLQR_triple_cartpole.jl:98,125 as generated by noise_philox).  Synchronises the device when it has to re-allocate.
+ * Call it before capturing step-per-launch rollouts of a noise_philox controller into a hipGraph (BASELINE configs[4]). */
+int cclqr_ctrl_reserve_noise(cclqr_ctrl *c, int64_t n_inst, int32_t steps);
+
+/* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py; no counterpart in the reference's simulate!,
+ * examples/lqr_cartpole.jl:44): lanes per instance and LDS bytes per workgroup; links the chain kernel's LDS image is laid out for
+ * (names the instantiation rollout_chain_kernel<lanes, links, law>; 0 when the mechanism takes the tree or the closed-loop kernel) */
 int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);
+int cclqr_rollout_layout_links(const cclqr_mech *m, int32_t *links);
 
 #ifdef __cplusplus
 }

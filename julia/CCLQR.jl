@@ -2,7 +2,7 @@
 #
 # STATUS: source only.  No Julia toolchain exists in the build/test pipeline of this repository, so this file has never been
 # executed; the ABI it binds IS exercised (by constrainedcontrol.jl_amd/_capi.py through ctypes).  Struct layouts below mirror
-# include/cclqr.h field by field.  The two functions that read ConstrainedDynamics internals (`mech_tables`) are the only
+# include/cclqr.h field by field.  `mech_tables` / `ctrl_joints`, which read ConstrainedDynamics internals, are the only
 # parts that depend on that package's field names (0.9.x); everything else is plain arrays.
 #
 # Drop-in points in the reference (janbruedigam/ConstrainedControl.jl v0.3.0):
@@ -39,6 +39,25 @@ struct RolloutOpts         # cclqr_rollout_opts
     first_instance::Int64
     pid_state_dev::Ptr{Float64}
     pid_state_len::Int64
+    noise_ws_dev::Ptr{Float64}
+    noise_ws_len::Int64
+    newton_mode::Int32
+    reserved::Int32
+end
+
+struct RiccatiOpts         # cclqr_riccati_opts
+    path::Int32
+    bf16_terms::Int32
+    keep_last::Int32
+    reserved::Int32
+end
+
+const ABI_VERSION = 200    # include/cclqr.h CCLQR_ABI_VERSION: the structs above mirror THAT header field by field
+"call once after loading: a library built from another header would read these structs past their end (ADVICE r2)"
+function check_abi()
+    v = ccall((:cclqr_version, lib), Cint, ())
+    v == ABI_VERSION || error("libcclqr.so has ABI version $v, CCLQR.jl was written for $ABI_VERSION")
+    nothing
 end
 
 const REVOLUTE = Int32(0)
@@ -57,11 +76,12 @@ end
 
 # One LQR per setpoint, built and kept on the device (cclqr_ctrl_create_lqr_batch): zd is nb*13*n doubles, Q / R the Δt-scaled weights
 # (lqr.jl:18-19) row-major; returns the controller handle for rollout!(...) and the break indices.
-function lqr_batch(mech::Ptr{Cvoid}, n::Int, zd::Vector{Float64}, ctrl_joint::Vector{Int32}, Q::Vector{Float64}, R::Vector{Float64}, N::Int; tol = 1e-5)
+function lqr_batch(mech::Ptr{Cvoid}, n::Int, zd::Vector{Float64}, ctrl_joint::Vector{Int32}, Q::Vector{Float64}, R::Vector{Float64}, N::Int;
+                   tol = 1e-5, infinite_horizon = false)      # infinite_horizon: LQR{T,Inf} -- N = ceil(10/Δt) (lqr.jl:26), only Ku[1] is kept
     h = Ref{Ptr{Cvoid}}(C_NULL); kb = zeros(Int32, n)
     check(ccall((:cclqr_ctrl_create_lqr_batch, lib), Cint,
-                (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Int32}, Ref{Ptr{Cvoid}}),
-                mech, Int32(n), zd, Int32(length(ctrl_joint)), ctrl_joint, C_NULL, Q, R, Int32(N), tol, kb, h))
+                (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Float64, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                mech, Int32(n), zd, Int32(length(ctrl_joint)), ctrl_joint, C_NULL, Q, R, Int32(N), Int32(infinite_horizon ? 1 : 0), tol, kb, h))
     return h[], kb
 end
 
@@ -88,24 +108,73 @@ end
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Mechanism -> flat tables.  Assumes ConstrainedDynamics 0.9.x field names: mechanism.bodies / eqconstraints / origin / Δt / g,
-# body.m, body.J, eqc.parentid, eqc.childids, eqc.constraints = (Translational, Rotational) with .vertices, .V3 (axis row),
-# .qoffset.  Body ids 1..Nb, joint ids Nb+1.. (examples/trackingLQR_triple_cartpole.jl:109-111).
+# body.m, body.J, eqc.parentid, eqc.childids, eqc.constraints with .vertices, .V3 (axis row), .qoffset.
+# Body ids 1..Nb, joint ids Nb+1.. (examples/trackingLQR_triple_cartpole.jl:109-111).
+#
+# An EqualityConstraint may bundle SEVERAL joints off one parent: examples/lqr_deltabot.jl:25 builds
+#   EqualityConstraint(Revolute(origin, lowerlegl, ...), Revolute(origin, lowerlegr, ...), FixedOrientation(origin, platform))
+# whose `constraints` is the flat tuple (Translational3, Rotational2, Translational3, Rotational2, Rotational3) with
+# `childids` = (l, l, r, r, platform) -- one entry per component.  The C side knows 1-DoF joints and the FixedOrientation, one child
+# each, so every EqualityConstraint is EXPANDED into one table joint per distinct child (components grouped by child id, in order):
+#   Translational{3} + Rotational{2} -> REVOLUTE,  Translational{2} + Rotational{3} -> PRISMATIC,  a lone Rotational{3} -> FIXED_ORIENTATION;
+# anything else is refused (a silent flattening would simulate a different mechanism).  `joint_of_eqc[id]` lists the 0-based table
+# joints an EqualityConstraint id became: an LQR's `eqcids` (lqr.jl:49-57; one input per 1-DoF joint) map through it.
+nrows(c) = length(c)                                  # Joint{T,N}: N constraint rows
+istrans(c) = occursin("Translational", string(typeof(c)))
 function mech_tables(mechanism)
     bodies = collect(mechanism.bodies); eqcs = collect(mechanism.eqconstraints)
-    nb, ne = length(bodies), length(eqcs)
+    nb = length(bodies)
     bodyindex = Dict(b.id => Int32(i - 1) for (i, b) in enumerate(bodies))
     mass = Float64[b.m for b in bodies]
     inertia = reduce(vcat, [vec(permutedims(Matrix(b.J))) for b in bodies])          # row-major 3x3 per body
-    parent = Int32[get(bodyindex, e.parentid, Int32(-1)) for e in eqcs]                # origin -> -1
-    child = Int32[bodyindex[e.childids[1]] for e in eqcs]
-    # Translational3+Rotational2 | Translational2+Rotational3 | a lone Rotational3 (closed-loop mechanisms: rollout only, include/cclqr.h)
-    typ = Int32[length(e.constraints) == 1 ? FIXED_ORIENTATION : (length(e.constraints[1]) == 3 ? REVOLUTE : PRISMATIC) for e in eqcs]
-    lone(i) = typ[i] == FIXED_ORIENTATION
-    p1 = reduce(vcat, [lone(i) ? zeros(3) : Vector{Float64}(e.constraints[1].vertices[1]) for (i, e) in enumerate(eqcs)])
-    p2 = reduce(vcat, [lone(i) ? zeros(3) : Vector{Float64}(e.constraints[1].vertices[2]) for (i, e) in enumerate(eqcs)])
-    axis = reduce(vcat, [lone(i) ? [1.0, 0.0, 0.0] : Vector{Float64}(vec(typ[i] == REVOLUTE ? e.constraints[2].V3 : e.constraints[1].V3)) for (i, e) in enumerate(eqcs)])
-    qoff = reduce(vcat, [Float64[q.s, q.v1, q.v2, q.v3] for q in (e.constraints[end].qoffset for e in eqcs)])
-    return (; nb, ne, dt = Float64(mechanism.Δt), g = Float64(mechanism.g), mass, inertia, parent, child, typ, p1, p2, axis, qoff)
+    parent = Int32[]; child = Int32[]; typ = Int32[]
+    p1 = Float64[]; p2 = Float64[]; axis = Float64[]; qoff = Float64[]
+    joint_of_eqc = Dict{Int,Vector{Int32}}()
+    for e in eqcs
+        cs = collect(e.constraints); cids = collect(e.childids)
+        length(cs) == length(cids) || error("EqualityConstraint $(e.id): constraints and childids differ in length")
+        joint_of_eqc[e.id] = Int32[]
+        i = 1
+        while i <= length(cs)
+            j = i
+            while j < length(cs) && cids[j+1] == cids[i]; j += 1; end
+            comp = cs[i:j]
+            tr = [c for c in comp if istrans(c)]; ro = [c for c in comp if !istrans(c)]
+            kind = if length(tr) == 1 && length(ro) == 1 && nrows(tr[1]) == 3 && nrows(ro[1]) == 2
+                REVOLUTE
+            elseif length(tr) == 1 && length(ro) == 1 && nrows(tr[1]) == 2 && nrows(ro[1]) == 3
+                PRISMATIC
+            elseif isempty(tr) && length(ro) == 1 && nrows(ro[1]) == 3
+                FIXED_ORIENTATION
+            else
+                error("EqualityConstraint $(e.id), child $(cids[i]): only Revolute, Prismatic and FixedOrientation components are supported")
+            end
+            push!(joint_of_eqc[e.id], Int32(length(typ)))
+            push!(parent, get(bodyindex, e.parentid, Int32(-1)))                       # origin -> -1
+            push!(child, bodyindex[cids[i]]); push!(typ, kind)
+            if kind == FIXED_ORIENTATION
+                append!(p1, zeros(3)); append!(p2, zeros(3)); append!(axis, [1.0, 0.0, 0.0])
+            else
+                append!(p1, Vector{Float64}(tr[1].vertices[1])); append!(p2, Vector{Float64}(tr[1].vertices[2]))
+                append!(axis, Vector{Float64}(vec(kind == REVOLUTE ? ro[1].V3 : tr[1].V3)))
+            end
+            q = ro[1].qoffset
+            append!(qoff, Float64[q.s, q.v1, q.v2, q.v3])
+            i = j + 1
+        end
+    end
+    ne = length(typ)
+    return (; nb, ne, dt = Float64(mechanism.Δt), g = Float64(mechanism.g), mass, inertia, parent, child, typ, p1, p2, axis, qoff, joint_of_eqc)
+end
+"0-based table joints of the 1-DoF joints named by an LQR's eqcids (lqr.jl:49-57): every id must have become exactly one 1-DoF joint"
+function ctrl_joints(t, eqcids)
+    out = Int32[]
+    for id in eqcids
+        js = [j for j in t.joint_of_eqc[id] if t.typ[j+1] != FIXED_ORIENTATION]
+        length(js) == 1 || throw(AssertionError("eqcid $id bundles $(length(js)) 1-DoF joints: name the joint (lqr.jl:1-2 'Only for 1dof joints')"))
+        push!(out, js[1])
+    end
+    out
 end
 
 mutable struct MechHandle
@@ -116,6 +185,7 @@ mutable struct MechHandle
         GC.@preserve t begin
             d = MechDesc(t.nb, t.ne, t.dt, t.g, pointer(t.mass), pointer(t.inertia), pointer(t.parent), pointer(t.child), pointer(t.typ),
                          pointer(t.p1), pointer(t.p2), pointer(t.axis), pointer(t.qoff))
+            check_abi()
             check(ccall((:cclqr_mech_create, lib), Cint, (Ref{MechDesc}, Ref{Ptr{Cvoid}}), d, h))
         end
         obj = new(h[], t.nb)
@@ -189,37 +259,35 @@ function CtrlHandle(h::MechHandle, ctrl::Vector{Int32}, K::Array{Float64,3}, N::
 end
 
 "Batched simulate!: z0 is 13 x Nb x n_inst; returns (traj 13 x Nb x steps x n_inst or nothing, zT, status)."
-function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, steps::Integer; record = true, noise = nothing, k0 = 1)
+function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, steps::Integer; record = true, noise = nothing, k0 = 1,
+                         first_instance = 0, newton_mode = 0)
     n = size(z0, 3)
     traj = record ? zeros(13, h.nb, steps, n) : nothing
     zT = similar(z0); status = zeros(Int32, n)
-    check(ccall((:cclqr_rollout, lib), Cint,
-                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-                h.ptr, c.ptr, n, steps, k0, z0, noise === nothing ? C_NULL : noise, record ? traj : C_NULL, zT, status))
+    o = RolloutOpts(first_instance, C_NULL, 0, C_NULL, 0, newton_mode, 0)      # first_instance: global index of instance 1 of this shard
+    check(ccall((:cclqr_rollout_host_ex, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{RolloutOpts}),
+                h.ptr, c.ptr, n, steps, k0, z0, noise === nothing ? C_NULL : noise, record ? traj : C_NULL, zT, status, o))
     traj, zT, status
 end
 
 "Device-pointer rollout with explicit options (cclqr_rollout_ex): all pointers are device addresses (e.g. from AMDGPU.jl), the launch is
  asynchronous on `stream`.  first_instance = global index of instance 1 of this shard (noise stream and per-instance controller table),
- pid_state = device buffer n_inst x Nb x 2 carrying the PID integrators between launches (C_NULL: none)."
+ pid_state = device buffer n_inst x Nb x 2 carrying the PID integrators between launches (C_NULL: none), noise_ws = device workspace of
+ n_inst x steps doubles for the Philox samples (C_NULL: the controller handle's own; see reserve_noise!), newton_mode 0 = exact rule."
 function rollout_dev!(h::MechHandle, c::CtrlHandle, n::Integer, steps::Integer, k0::Integer, z0::Ptr{Float64}, lam::Ptr{Float64},
                       traj::Ptr{Float64}, zT::Ptr{Float64}, status::Ptr{Int32}; noise::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_stride = 0,
-                      first_instance = 0, pid_state::Ptr{Float64} = Ptr{Float64}(C_NULL), stream::Ptr{Cvoid} = C_NULL)
-    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2)
+                      first_instance = 0, pid_state::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_ws::Ptr{Float64} = Ptr{Float64}(C_NULL),
+                      newton_mode = 0, stream::Ptr{Cvoid} = C_NULL)
+    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2, noise_ws, noise_ws == C_NULL ? 0 : n * steps, newton_mode, 0)
     check(ccall((:cclqr_rollout_ex, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
                  Ref{RolloutOpts}, Ptr{Cvoid}),
                 h.ptr, c.ptr, n, steps, k0, z0, lam, noise, noise_stride, traj, zT, status, o, stream))
 end
 
-"Riccati launch shape: 0 = by problem size, 1 = one persistent workgroup per problem, 2 = tiled over the device (same results)."
-riccati_path!(path::Integer) = check(ccall((:cclqr_riccati_path, lib), Cint, (Int32,), path))
-
-"Global index of instance 1 of the following simulate_batch! calls (Philox noise streams are keyed by global instance index)."
-instance_offset!(first::Integer) = check(ccall((:cclqr_set_instance_offset, lib), Cint, (Int64,), first))
-
-"Device buffer (n_inst x Nb x 2 Float64) that carries the PID integrators between device-pointer launches; C_NULL = none."
-pid_state!(ptr::Ptr{Float64}) = check(ccall((:cclqr_set_pid_state, lib), Cint, (Ptr{Float64},), ptr))
+"Size the controller handle's Philox workspace before step-per-launch rollouts are captured into a hipGraph (cclqr_ctrl_reserve_noise)."
+reserve_noise!(c::CtrlHandle, n::Integer, steps::Integer) = check(ccall((:cclqr_ctrl_reserve_noise, lib), Cint, (Ptr{Cvoid}, Int64, Int32), c.ptr, n, steps))
 
 "Storage{T}(steps, Nb) view of instance n of a batched trajectory: storage.x[i][k] etc. (lqr_tracking.jl:32-35)."
 function storage_fields(traj::Array{Float64,4}, n::Integer)

@@ -368,3 +368,41 @@ def test_deltabot_script_as_a_batch(cclqr, orc):
     rec = cclqr.simulate(mech, cclqr.Storage(steps, 5), lq, z0=z0[96:97])
     ref, _ = loop_feedback_reference(lm, z0[96].copy(), ex["Fd"], lq.K[0], z00, steps)
     assert np.abs(rec.z[0] - ref).max() < 1e-9
+
+
+def test_infinite_horizon_batch_keeps_one_gain_per_setpoint(cclqr, orc):
+    """LQR{T,Inf} for a batch of setpoints (lqr.jl:25-27, 40-43): cclqr_riccati_opts.keep_last and cclqr_ctrl_create_lqr_batch(infinite_horizon)
+    keep only Ku[1] per problem -- the gain of the last executed backward step -- without materialising the (N-1)-fold table.  That gain is
+    bit for bit row 0 of the full table (resident and tiled path), the break indices are the oracle's, and the rollout driven by the
+    batched handle equals the one driven by a host-built LQR{T,Inf} table."""
+    import json
+    import os
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    n, N = 48, 600
+    rng = np.random.default_rng(46)
+    ang = rng.uniform(-0.8, 0.8, (n, 7))
+    zd = cclqr.joint_position_states(mech, ang)
+    z0 = cclqr.joint_position_states(mech, ang + rng.uniform(-0.002, 0.002, (n, 7)))
+    mh = capi.MechHandle(t)
+    cj = list(range(7))
+    Q, R = np.eye(84) * 1000.0 * t.dt, np.eye(7) * t.dt
+    A, Bu, Bl, G = capi.linearize(mh, zd, cj, np.zeros((n, 7)))
+    Kfull, kb = capi.riccati(A, Bu, Bl, G, Q, R, N)
+    assert (kb > 1).all()                                                   # every recursion converged before the horizon ran out
+    for path in (1, 2):
+        K1, kb1 = capi.riccati(A[:6], Bu[:6], Bl[:6], G[:6], Q, R, N, path=path, keep_last=True)
+        assert K1.shape == (6, 1, 7, 84) and np.array_equal(kb1, kb[:6])
+        assert np.array_equal(K1[:, 0], Kfull[:6, 0])
+    Ko, kbo = orc.riccati(A[0], Bu[0], Bl[0], G[0], Q, R, N)
+    assert kbo == kb[0] and np.abs(Kfull[0, 0] - Ko[0]).max() < 1e-7 * np.abs(Ko[0]).max()
+    dev = capi.BatchLqrHandle(mh, zd, cj, Q, R, N, infinite_horizon=True)
+    assert np.array_equal(dev.kbreak, kb) and dev.N == 0
+    host = capi.CtrlHandle(mh, cj, K=Kfull[:, :1], N=0, zd=zd[:, None], n_ctrl=n)
+    zT_h, _, st_h = capi.rollout(mh, host, z0, 300)
+    zT_d, _, st_d = capi.rollout(mh, dev, z0, 300)
+    assert (st_h > 0).all() and np.array_equal(st_h, st_d) and np.array_equal(zT_h, zT_d)
+    assert np.abs(zT_d[:, :, 0:3] - zd[:, :, 0:3]).max() < 0.2 * np.abs(z0[:, :, 0:3] - zd[:, :, 0:3]).max()

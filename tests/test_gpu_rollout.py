@@ -71,7 +71,7 @@ def test_tracking_friction_noise(cclqr, orc):
 
 def test_philox_noise_and_instance_offset(cclqr, orc):
     """noise_philox: device-generated Philox-4x32 / Box-Muller stream per GLOBAL instance == the oracle's; a shard launched with
-    cclqr_set_instance_offset reproduces its slice of the whole batch bit for bit"""
+    cclqr_rollout_opts.first_instance reproduces its slice of the whole batch bit for bit"""
     capi = cclqr._capi
     ex = cclqr.examples.triple_cartpole()
     t = ex["mech"].tables()
@@ -88,11 +88,7 @@ def test_philox_noise_and_instance_offset(cclqr, orc):
     assert (st > 0).all()
     assert np.abs(traj[0] - traj[1]).max() > 1e-3
     assert np.abs(traj - traj_o).max() < TOL
-    try:
-        capi.set_instance_offset(20)
-        zT_s, _, _ = capi.rollout(mech, ctrl, z0[20:35], N)
-    finally:
-        capi.set_instance_offset(0)
+    zT_s, _, _ = capi.rollout(mech, ctrl, z0[20:35], N, first_instance=20)
     assert np.array_equal(zT_s, zT[20:35])
 
 
@@ -132,7 +128,7 @@ def test_chained_device_launches_equal_one_launch(cclqr, orc):
 
 
 def test_pid_state_carried_across_launches(cclqr, orc):
-    """PID (pid.jl:69-88) with step-per-launch use: with cclqr_set_pid_state the integrated / last errors survive between launches,
+    """PID (pid.jl:69-88) with step-per-launch use: with cclqr_rollout_opts.pid_state_dev the integrated / last errors survive between launches,
     so 30 + 70 steps in two launches equal 100 steps in one (and equal the oracle)"""
     import torch
     capi = cclqr._capi
@@ -155,26 +151,18 @@ def test_pid_state_carried_across_launches(cclqr, orc):
     capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr(), pid_state=pstate.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(b, one)
-    # deprecated thread-local setter: same result
-    lam.zero_(); pstate.zero_()
-    try:
-        capi.set_pid_state(pstate.data_ptr())
-        capi.rollout_dev(mech, ctrl, n, 30, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr())
-        capi.rollout_dev(mech, ctrl, n, 70, 31, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr())
-        # a controller without a PID law launched while the buffer is still set must not touch it
-        ex2 = cclqr.examples.cartpole_n(1)
-        t2 = ex2["mech"].tables()
-        m2 = capi.MechHandle(t2)
-        c2 = capi.CtrlHandle(m2, [0], K=np.zeros((5, 1, 24)), N=6, zd=None)
-        zc = torch.from_numpy(cclqr.examples.cartpole_states(1, np.linspace(-0.3, 0.3, 40), np.full((40, 1), 0.1))).to(dev)
-        keep = pstate.clone()
-        capi.rollout_dev(m2, c2, 40, 3, 1, zc.data_ptr(), 0, 0, 0, 0, torch.empty_like(zc).data_ptr(), torch.zeros(40, dtype=torch.int32, device=dev).data_ptr())
-        torch.cuda.synchronize()
-        assert torch.equal(keep, pstate)
-    finally:
-        capi.set_pid_state(0)
+    # a controller without a PID law never touches a PID buffer handed to its launch
+    ex2 = cclqr.examples.cartpole_n(1)
+    t2 = ex2["mech"].tables()
+    m2 = capi.MechHandle(t2)
+    c2 = capi.CtrlHandle(m2, [0], K=np.zeros((5, 1, 24)), N=6, zd=None)
+    zc = torch.from_numpy(cclqr.examples.cartpole_states(1, np.linspace(-0.3, 0.3, 40), np.full((40, 1), 0.1))).to(dev)
+    pst2 = torch.full((40, t2.nb, 2), 7.0, dtype=torch.float64, device=dev)
+    keep = pst2.clone()
+    capi.rollout_dev(m2, c2, 40, 3, 1, zc.data_ptr(), 0, 0, 0, 0, torch.empty_like(zc).data_ptr(), torch.zeros(40, dtype=torch.int32, device=dev).data_ptr(),
+                     pid_state=pst2.data_ptr())
     torch.cuda.synchronize()
-    assert torch.equal(b, one)
+    assert torch.equal(keep, pst2)
     zo, _, _ = orc.rollout(t, orc.ctrl_desc(2, [], K=None, N=0, pid=pid), z0, 100)
     assert np.abs(one.cpu().numpy() - zo).max() < TOL
     # without the buffer the integrators restart: a different trajectory
@@ -423,3 +411,175 @@ def test_two_ranks_chunked_rollout_and_trajectory_collection(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "SHARDED_OK" in r.stdout
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO torchrun environment starts its two ranks itself (fresh child processes; the
+    parent never touches the GPU) and the one JSON line says n_gpus = 2.  On the one-GPU box the ranks share cuda:0 and collect over gloo
+    (--rehearse-shared-gpu; RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--instances", "256", "--sim-steps", "64",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal_shared_gpu"] and d["collective_backend"] == "gloo"
+    assert d["config"]["launches_per_rollout"] == 8 and d["newton"]["failed_instances"] == 0
+    assert abs(d["value"] - 2 * 256 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["collection"]["trajectory_bytes_gathered_to_rank0_per_rollout"] == 256 * 64 * 17 * 13 * 8
+
+
+_RCCL_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+import __graft_entry__ as g
+import torch.distributed as dist
+pkg = g.load_package(); capi = pkg._capi
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r)
+rank, world, local = pkg.dist.init_from_env(force_init=True)          # backend None -> "nccl" = RCCL on a GPU box; no fallback
+assert dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", 0); capi.set_device(0)
+n_links, n, T, H = 3, 64, 32, 4
+ex = pkg.examples.cartpole_n(n_links); t = ex["mech"].tables(); nb = t.nb
+zd = pkg.examples.cartpole_states(n_links, [0.0], np.array([[np.pi] + [0.0] * (n_links - 1)]))[0]
+rng = np.random.default_rng(9)
+K = rng.normal(size=(T - 1, 1, 12 * nb)) * 0.05
+phi = rng.uniform(-0.2, 0.2, (n, n_links)); phi[:, 0] += np.pi
+z0h = pkg.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n), phi)
+mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, [0], K=K, N=T, zd=zd)
+z0 = torch.from_numpy(z0h).to(dev); zT = torch.empty_like(z0); st = torch.zeros(n, dtype=torch.int32, device=dev)
+lam = torch.zeros((n, 5 * nb), dtype=torch.float64, device=dev)
+# the single rank really calls the collective: librccl is loaded, its communicator exists, the gather runs on the second stream
+tg = pkg.dist.TrajectoryGather(rank, world, n, T, nb, H, dev, force_collective=True)
+fin = pkg.dist.RootGather(n, (nb, 13), torch.float64, dev, rank, world, force_collective=True)
+Tc = T // H
+for c in range(H):
+    tg.wait_slab_free(c)
+    capi.rollout_dev(mh, ctrl, n, Tc, c * Tc + 1, (z0 if c == 0 else zT).data_ptr(), lam.data_ptr(), 0, 0, tg.slab(c).data_ptr(), zT.data_ptr(), st.data_ptr(),
+                     torch.cuda.current_stream().cuda_stream)
+    tg.submit(c)
+traj = tg.finish()
+zall = fin(zT)
+torch.cuda.synchronize()
+zT1, traj1, st1 = capi.rollout(mh, ctrl, z0h, T, record=True)
+assert (st1 > 0).all()
+assert np.array_equal(traj.cpu().numpy(), traj1) and np.array_equal(zall.cpu().numpy(), zT1)
+libs = [l.split()[-1] for l in open("/proc/self/maps") if "rccl" in l]
+assert libs, "librccl is not mapped into the process"
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", sorted(set(libs))[0])
+"""
+
+
+def test_rccl_executes_once_with_one_rank(tmp_path):
+    """the `nccl` backend (= RCCL) is initialised with world_size 1 and ONE chunked rollout goes through
+    dist.TrajectoryGather / dist.RootGather with the collective forced, so that librccl's load, its communicator, the stream ordering of
+    the gather behind the rollout launch and HSA_ENABLE_IPC_MODE_LEGACY are exercised once on the GPU box (a hardware scaling curve is
+    still unmeasured: one GPU).  The collected trajectory equals one launch of the batch bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from conftest import free_port
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % {"root": root, "port": str(free_port())})
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL_OK" in r.stdout
+
+
+def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
+    """configs[4] as written -- the friction + noise law of trackingLQR_triple_cartpole.jl:93-111 AND a hipGraph-captured step: 20
+    single-step launches with device-generated Philox noise captured into a graph == one fused 20-step launch (the samples are keyed by
+    (global instance, step), so the split does not change them), and == the oracle.  The controller's noise workspace is sized before
+    the capture (cclqr_ctrl_reserve_noise): nothing may be allocated while a stream is being captured."""
+    import torch
+    capi = cclqr._capi
+    ex = cclqr.examples.triple_cartpole()
+    t = ex["mech"].tables()
+    N, n = 40, 192
+    rng = np.random.default_rng(12)
+    z00 = ex["mech"].state()
+    zd = np.tile(z00, (N, 1, 1))
+    K = rng.normal(size=(N - 1, 1, 48)) * 0.3
+    kw = dict(K=K, N=N, zd=zd, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+    z0 = np.tile(z00, (n, 1, 1))
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], **kw)
+    dev = torch.device("cuda", 0)
+    z0_d = torch.from_numpy(z0).to(dev)
+    ref = torch.empty_like(z0_d)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, ref.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    assert (st > 0).all() and float((ref[0] - ref[1]).abs().max()) > 1e-4        # the noise is there and differs per instance
+    ctrl2 = capi.CtrlHandle(mech, [0], **kw)          # a fresh handle: its workspace has never been sized by a launch
+    ctrl2.reserve_noise(n, 1)
+    za, zb = z0_d.clone(), torch.empty_like(z0_d)
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        src, dst = za, zb
+        for k in range(1, 21):
+            capi.rollout_dev(mech, ctrl2, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
+            src, dst = dst, src
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):                                  # the second replay runs on fresh inputs through the same captured buffers
+        za.copy_(z0_d)
+        lam.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(src, ref)
+    # caller-owned workspace (two launches sharing one controller on different streams would each bring their own)
+    ws = torch.empty(n * 20, dtype=torch.float64, device=dev)
+    out = torch.empty_like(z0_d)
+    capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    with pytest.raises(capi.CclqrError):
+        capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20 - 1)
+    zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0[:16], 20)
+    assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
+
+
+def test_newton_mode_residual_only_is_a_measured_error_option(cclqr, orc):
+    """cclqr_rollout_opts.newton_mode = 1 (stop on ||f|| < eps alone): NOT the parity mode.  The default stays the exact rule (= the
+    oracle, checked here once more); the option's deviation from it is measured and must stay under the north star's 1e-8 on a
+    well-conditioned workload; its Newton iteration counts are never larger.  Refused for trees and closed loops."""
+    capi = cclqr._capi
+    n_links, steps, n = 7, 200, 96
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    rng = np.random.default_rng(31)
+    K = rng.normal(size=(steps + 19, 1, 12 * t.nb)) * 0.05
+    phi = rng.uniform(-0.2, 0.2, (n, n_links))
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n), phi)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=steps + 20, zd=zd)
+    zT0, tr0, st0 = capi.rollout(mech, ctrl, z0, steps, record=True)
+    zT1, tr1, st1 = capi.rollout(mech, ctrl, z0, steps, record=True, newton_mode=1)
+    _, tro, sto = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=steps + 20, zd=zd), z0[:8], steps, record=True)
+    assert np.abs(tr0[:8] - tro).max() < TOL and np.array_equal(st0[:8], sto)
+    dev = np.abs(tr1 - tr0).max()
+    print("newton_mode 1: max |state - exact rule| over %d steps = %.3g; max Newton iterations %d -> %d" % (steps, dev, st0.max(), st1.max()))
+    assert (st1 > 0).all() and dev < 1e-8 and (st1 <= st0).all() and st1.max() < st0.max()
+    ext = cclqr.examples.dual_cartpole()                     # a branching tree: the LDS-resident kernel keeps the exact rule only
+    tt = ext["mech"].tables()
+    mt = capi.MechHandle(tt)
+    ct = capi.CtrlHandle(mt, [0], K=np.zeros((5, 1, 12 * tt.nb)), N=6, zd=None)
+    with pytest.raises(capi.CclqrError) as e:
+        capi.rollout(mt, ct, ext["mech"].state()[None], 3, newton_mode=1)
+    assert e.value.code == capi.EUNSUPPORTED

@@ -74,24 +74,23 @@ def test_riccati_matches_oracle(cclqr, orc, n_links, N):
 
 @pytest.mark.parametrize("path", [1, 2])
 def test_riccati_both_paths(cclqr, orc, path):
-    """the LDS-resident and the tiled implementation of dlqr (cclqr_riccati_path) against the oracle: time-invariant with an
+    """the LDS-resident and the tiled implementation of dlqr (cclqr_riccati_opts.path) against the oracle: time-invariant with an
     early break, batched, time-varying (lqr_tracking.jl:73-122), multi-input (mu = 3), and a singular G*Bλ"""
     capi = cclqr._capi
-    capi.riccati_path(path)
-    try:
+    if True:
         ex = cclqr.examples.cartpole_n(3)
         t = ex["mech"].tables()
         zd = upright_setpoint(3)
         A, Bu, Bl, G = orc.linearize(t, zd, [0], np.zeros(1))
         Q, R = sl.block_diag(*ex["Q"]) * t.dt, sl.block_diag(*ex["R"]) * t.dt
-        K, kb = capi.riccati(A, Bu, Bl, G, Q, R, 400)
+        K, kb = capi.riccati(A, Bu, Bl, G, Q, R, 400, path=path)
         Ko, kbo = orc.riccati(A, Bu, Bl, G, Q, R, 400)
         assert kb == kbo and _rel(K, Ko) < 1e-7
         # three actuated joints, batch of 3 distinct problems, a horizon with an early break in some of them
         mats = [orc.linearize(t, cclqr.examples.cartpole_states(3, [0.1 * p], np.full((1, 3), 0.05 * p))[0], [0, 1, 3], np.zeros(3)) for p in range(3)]
         Ab, Bub, Blb, Gb = (np.stack([m[i] for m in mats]) for i in range(4))
         R3 = np.diag([0.01, 0.02, 0.03])
-        Kb, kbb = capi.riccati(Ab, Bub, Blb, Gb, Q * 100, R3, 150, tol=1e-3)
+        Kb, kbb = capi.riccati(Ab, Bub, Blb, Gb, Q * 100, R3, 150, tol=1e-3, path=path)
         for p in range(3):
             Ko, kbo = orc.riccati(Ab[p], Bub[p], Blb[p], Gb[p], Q * 100, R3, 150, tol=1e-3)
             assert kbb[p] == kbo and _rel(Kb[p], Ko) < 1e-7
@@ -103,23 +102,21 @@ def test_riccati_both_paths(cclqr, orc, path):
         Fd = rng.normal(size=(N, 1))
         Q3, R3 = np.eye(48) * 0.01, np.eye(1) * 0.01
         mech = capi.MechHandle(t3)
-        Kt, kbt = capi.riccati_tracking(mech, [0], zs, Fd, Q3, R3, N)
+        Kt, kbt = capi.riccati_tracking(mech, [0], zs, Fd, Q3, R3, N, path=path)
         Kto, kbto = orc.riccati_tracking(t3, [0], zs, Fd, Q3, R3, N)
         assert kbt == kbto and _rel(Kt, Kto) < 1e-7
         # singular G*Bλ (a duplicated constraint row) is reported, lqr.jl:151
         G2, Bl2 = G.copy(), Bl.copy()
         G2[1] = G2[0]
         with pytest.raises(capi.CclqrError) as e:
-            capi.riccati(A, Bu, Bl2, G2, Q, R, 50)
+            capi.riccati(A, Bu, Bl2, G2, Q, R, 50, path=path)
         assert e.value.code == capi.ESINGULAR
         # N = 1 and N = 2 edge cases (empty / single gain)
-        K1, kb1 = capi.riccati(A, Bu, Bl, G, Q, R, 1)
+        K1, kb1 = capi.riccati(A, Bu, Bl, G, Q, R, 1, path=path)
         assert K1.shape[0] == 0 and kb1 == 0
-        K2, kb2 = capi.riccati(A, Bu, Bl, G, Q, R, 2)
+        K2, kb2 = capi.riccati(A, Bu, Bl, G, Q, R, 2, path=path)
         Ko2, kbo2 = orc.riccati(A, Bu, Bl, G, Q, R, 2)
         assert kb2 == kbo2 and _rel(K2, Ko2) < 1e-7
-    finally:
-        capi.riccati_path(0)
 
 
 def test_riccati_batched(cclqr, orc):

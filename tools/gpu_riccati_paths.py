@@ -18,10 +18,8 @@ def timed(f, reps=2):
 def case(name, A, Bu, Bl, G, Q, R, N, tol=1e-5):
     res = {}
     for path in (1, 2):
-        capi.riccati_path(path)
-        dt, (K, kb) = timed(lambda: capi.riccati(A, Bu, Bl, G, Q, R, N, tol=tol))
+        dt, (K, kb) = timed(lambda: capi.riccati(A, Bu, Bl, G, Q, R, N, tol=tol, path=path))
         res[path] = (dt, K, np.atleast_1d(kb))
-    capi.riccati_path(0)
     steps = (N - np.maximum(res[1][2], 1)).max() + 1
     d = np.abs(res[1][1] - res[2][1]).max() / max(1.0, np.abs(res[1][1]).max())
     print("%-34s steps %4d: resident %.4fs (%.1f us/step)  tiled %.4fs (%.1f us/step)  speedup %.2fx  |dK|rel %.1e kb %s" % (
