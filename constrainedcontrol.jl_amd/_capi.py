@@ -45,7 +45,8 @@ class RiccatiOpts(C.Structure):
 
 class RolloutOpts(C.Structure):
     _fields_ = [("first_instance", C.c_int64), ("pid_state_dev", C.c_void_p), ("pid_state_len", C.c_int64),
-                ("noise_ws_dev", C.c_void_p), ("noise_ws_len", C.c_int64), ("newton_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("noise_ws_dev", C.c_void_p), ("noise_ws_len", C.c_int64), ("newton_mode", C.c_int32), ("reserved", C.c_int32),
+                ("newton_eps_alone", C.c_double)]
 
 
 _lib = None
@@ -229,7 +230,7 @@ class BatchLqrHandle:
             pass
 
 
-def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instance=0, newton_mode=0):
+def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instance=0, newton_mode=0, newton_eps_alone=0.0):
     """host-pointer rollout: returns (zT, traj or None, status)"""
     nb = mech.tables.nb
     z0 = f64(z0).reshape(-1, nb, 13)
@@ -238,14 +239,14 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instanc
     zT = np.zeros_like(z0)
     status = np.zeros(n, dtype=np.int32)
     noise = None if noise is None else f64(noise).reshape(n, steps)
-    o = RolloutOpts(int(first_instance), None, 0, None, 0, int(newton_mode), 0)
+    o = RolloutOpts(int(first_instance), None, 0, None, 0, int(newton_mode), 0, float(newton_eps_alone))
     check(lib().cclqr_rollout_host_ex(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
                                       _i(status), C.byref(o)))
     return zT, traj, status
 
 
 def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0,
-                first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0):
+                first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0, newton_eps_alone=0.0):
     """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
     Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][nb][2] doubles, noise_ws / noise_ws_len = caller's
     Philox workspace, newton_mode; none given: cclqr_rollout_dev (= NULL options)"""
@@ -255,7 +256,7 @@ def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise
                                       vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
         return
     o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.nb * 2 if pid_state else 0,
-                    int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), 0)
+                    int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), 0, float(newton_eps_alone))
     check(lib().cclqr_rollout_ex(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), C.byref(o), vp(stream)))
 

@@ -315,6 +315,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
     const int newton_mode = opts ? opts->newton_mode : 0;
+    a.eps_alone = (opts && opts->newton_eps_alone > 0.0) ? opts->newton_eps_alone : 1e-10;
     if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");
     if (newton_mode != 0 && (m->host.loop || m->host.tree || extra != 0))
         return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists for forests of chains under the plain LQR / TrackingLQR law only");

@@ -23,6 +23,7 @@ struct RolloutArgs {
     double* traj;         // [n_inst][steps][nb][13] or null
     double* zT;           // [n_inst][nb][13]
     int* status;          // [n_inst] or null
+    double eps_alone;     // measured-error Newton mode (RELAX kernels only): a solve also stops when ||f|| falls below this
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) instead of once per launch: remembers the largest size set so

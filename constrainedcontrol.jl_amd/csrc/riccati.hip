@@ -182,6 +182,7 @@ static __device__ unsigned long long g_rprof[RP_N];
 #define RSTAMP(c)
 #endif
 
+#define RIC_MU_REG 7   // the mu x mu system of a backward step is solved in registers up to this many inputs (8: spills under the 256-register budget)
 #define RIC_LDS_M 96   // G Bλ (ml x ml) is kept in LDS for its pivoted LU when ml <= 96 (72 KB)
 
 // =====================================================================================================================
@@ -585,11 +586,67 @@ __device__ inline v4d wave_tile16(int K, FA la, FB lb) {
     return acc;
 }
 
+// Ku = (R + D'PkD) \ (D'Pk A') for ONE column j, entirely in registers (lqr.jl:152-164 in the projected form).  S = R + D'PkD is
+// symmetric positive definite for every valid LQR (R > 0, Pk >= 0), so it is factorised WITHOUT pivoting: every thread reads S (MU^2
+// broadcast LDS reads: all lanes read the same addresses), runs the LU itself with compile-time register indices, and the threads that
+// own a column of D'Pk A' substitute.  No barrier and no LDS round trip between the pivot steps -- the pivoted LDS version below
+// (riccati_resident_kernel's general path) is one wavefront stepping through three fenced LDS passes per pivot with a 512-thread
+// barrier on either side, 28 % of a backward step at mu = 7.  Returns false, having written nothing, when a pivot is not positive
+// (S not positive definite: the caller falls back to the pivoted LU, which also detects a singular S); the decision is a function of
+// S alone, hence uniform over the workgroup.  Also writes R Ku for the Ku'RKu term of lqr.jl:170.
+template <int MU>
+__device__ __forceinline__ bool gain_in_registers(int j, bool owner, int mx, int na, const lds_double* S, const lds_double* Rl, const lds_double* TS,
+                                                  lds_double* Ku, lds_double* KRK, double* Kdst) {
+    double Sr[MU][MU], x[MU];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < MU; r++)
+#pragma unroll
+        for (int cc = 0; cc < MU; cc++) Sr[r][cc] = S[r * MU + cc];
+#pragma unroll
+    for (int c = 0; c < MU; c++) {
+        ok = ok && (Sr[c][c] > 0.0);
+        const double pinv = 1.0 / Sr[c][c];
+#pragma unroll
+        for (int r = c + 1; r < MU; r++) Sr[r][c] *= pinv;
+#pragma unroll
+        for (int r = c + 1; r < MU; r++)
+#pragma unroll
+            for (int cc = c + 1; cc < MU; cc++) Sr[r][cc] -= Sr[r][c] * Sr[c][cc];
+    }
+    if (!ok || !owner) return ok;
+#pragma unroll
+    for (int r = 0; r < MU; r++) x[r] = TS[r * na + j];
+#pragma unroll
+    for (int i = 1; i < MU; i++)
+#pragma unroll
+        for (int r = 0; r < i; r++) x[i] -= Sr[i][r] * x[r];
+#pragma unroll
+    for (int i = MU - 1; i >= 0; i--) {
+#pragma unroll
+        for (int r = i + 1; r < MU; r++) x[i] -= Sr[i][r] * x[r];
+        x[i] = x[i] / Sr[i][i];
+    }
+#pragma unroll
+    for (int q = 0; q < MU; q++) { Ku[q * mx + j] = x[q]; Kdst[(size_t)q * mx + j] = x[q]; }   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
+#pragma unroll
+    for (int q = 0; q < MU; q++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < MU; r++) sacc += Rl[q * MU + r] * x[r];
+        KRK[q * mx + j] = sacc;
+    }
+    return true;
+}
+
 size_t ric_resident_lds_bytes(int mx, int mu) {
     const size_t na = (size_t)mx + mu;
     return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2) * sizeof(double) + (mu + 2) * sizeof(int);
 }
 
+// MUT: the number of inputs as a compile-time constant (1 .. RIC_MU_REG: the mu x mu system is solved in registers, gain_in_registers), or 0:
+// any mu, pivoted LU in LDS
+template <int MUT>
 __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a) {
     extern __shared__ double rl[];
 #ifdef CCLQR_PROFILE
@@ -597,7 +654,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
 #endif
     __shared__ int sing;
     const int prob = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int mx = a.mx, mu = a.mu, na = a.na, N = a.N;
+    const int mx = a.mx, mu = MUT > 0 ? MUT : a.mu, na = a.na, N = a.N;
     if (a.stop[prob]) return;            // G Bλ was singular in the projection (status already set)
     lds_double* P = (lds_double*)rl;
     lds_double* W = P + (size_t)mx * mx;
@@ -654,42 +711,51 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
             }
         }
         __syncthreads();
-        for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];
+        for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];       // S = R + D'PkD   lqr.jl:152-153
         __syncthreads();
-        if (wave == 0) {                                     // LU with partial pivoting (mu <= 32) by ONE wavefront: LDS is in order per
-            for (int c = 0; c < mu; c++) {                   // wavefront, so fences replace the workgroup barriers
-                int bi = c;
-                {
-                    double best = -1.0;
-                    for (int r = c; r < mu; r++) { double v = fabs(S[r * mu + c]); if (v > best) { best = v; bi = r; } }   // every lane: same scan
-                    if (!(best > 0.0)) { if (lane == 0) sing = 1; break; }
-                }
-                if (lane == 0) piv[c] = bi;
-                if (bi != c && lane < mu) { double t = S[c * mu + lane]; S[c * mu + lane] = S[bi * mu + lane]; S[bi * mu + lane] = t; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const double pinv = 1.0 / S[c * mu + c];
-                if (lane > c && lane < mu) S[lane * mu + c] *= pinv;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int w = mu - c - 1;
-                for (int e = lane; e < w * w; e += 64) {
-                    const int r = c + 1 + e / w, j = c + 1 + e % w;
-                    S[r * mu + j] -= S[r * mu + c] * S[c * mu + j];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
+        bool in_regs = false;
+        if (MUT > 0) {                 // mu x mu system in registers (mu <= 7: every BASELINE config), see gain_in_registers
+            double* Kdst = Kout + (a.keep_last ? 0 : (size_t)(k - 1) * mu * mx);
+            in_regs = gain_in_registers<(MUT > 0 ? MUT : 1)>(tid, tid < mx, mx, na, S, Rl, TS, Ku, KRK, Kdst);
         }
-        __syncthreads();
-        if (sing) { status = CCLQR_ESINGULAR_; break; }
-        for (int j = tid; j < mx; j += RIC_THREADS) {         // Ku = S \ (D' Pk A'), one column per thread
-            for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[c * na + j]; TS[c * na + j] = TS[p * na + j]; TS[p * na + j] = t; } }
-            for (int i = 1; i < mu; i++) { double sacc = TS[i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[r * na + j]; TS[i * na + j] = sacc; }
-            for (int i = mu - 1; i >= 0; i--) {
-                double sacc = TS[i * na + j];
-                for (int r = i + 1; r < mu; r++) sacc -= S[i * mu + r] * TS[r * na + j];
-                TS[i * na + j] = sacc / S[i * mu + i];
+        if (in_regs) {
+            __syncthreads();
+        } else {
+            if (wave == 0) {                                     // LU with partial pivoting (mu <= 32) by ONE wavefront: LDS is in order per
+                for (int c = 0; c < mu; c++) {                   // wavefront, so fences replace the workgroup barriers
+                    int bi = c;
+                    {
+                        double best = -1.0;
+                        for (int r = c; r < mu; r++) { double v = fabs(S[r * mu + c]); if (v > best) { best = v; bi = r; } }   // every lane: same scan
+                        if (!(best > 0.0)) { if (lane == 0) sing = 1; break; }
+                    }
+                    if (lane == 0) piv[c] = bi;
+                    if (bi != c && lane < mu) { double t = S[c * mu + lane]; S[c * mu + lane] = S[bi * mu + lane]; S[bi * mu + lane] = t; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const double pinv = 1.0 / S[c * mu + c];
+                    if (lane > c && lane < mu) S[lane * mu + c] *= pinv;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int w = mu - c - 1;
+                    for (int e = lane; e < w * w; e += 64) {
+                        const int r = c + 1 + e / w, j = c + 1 + e % w;
+                        S[r * mu + j] -= S[r * mu + c] * S[c * mu + j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
             }
-            for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(a.keep_last ? 0 : (size_t)(k - 1) * mu * mx) + (size_t)q * mx + j] = v; }   // lqr.jl:162-164 (keep_last: one slot, the last step's gain stays)
-            for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += Rl[q * mu + r] * TS[r * na + j]; KRK[q * mx + j] = sacc; }
+            __syncthreads();
+            if (sing) { status = CCLQR_ESINGULAR_; break; }
+            for (int j = tid; j < mx; j += RIC_THREADS) {         // Ku = S \ (D' Pk A'), one column per thread
+                for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[c * na + j]; TS[c * na + j] = TS[p * na + j]; TS[p * na + j] = t; } }
+                for (int i = 1; i < mu; i++) { double sacc = TS[i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[r * na + j]; TS[i * na + j] = sacc; }
+                for (int i = mu - 1; i >= 0; i--) {
+                    double sacc = TS[i * na + j];
+                    for (int r = i + 1; r < mu; r++) sacc -= S[i * mu + r] * TS[r * na + j];
+                    TS[i * na + j] = sacc / S[i * mu + i];
+                }
+                for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(a.keep_last ? 0 : (size_t)(k - 1) * mu * mx) + (size_t)q * mx + j] = v; }   // lqr.jl:162-164 (keep_last: one slot, the last step's gain stays)
+                for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += Rl[q * mu + r] * TS[r * na + j]; KRK[q * mx + j] = sacc; }
+            }
         }
         __syncthreads();
         RSTAMP(RP_GAIN);
@@ -842,9 +908,13 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     }
     if (!ric_use_tiled(a)) {
         const size_t rl = ric_resident_lds_bytes(a.mx, a.mu);
-        e = set_max_dynamic_lds_once((const void*)riccati_resident_kernel, rl);
+        typedef void (*ResKernel)(RicGrid);
+        static const ResKernel table[RIC_MU_REG + 1] = {riccati_resident_kernel<0>, riccati_resident_kernel<1>, riccati_resident_kernel<2>, riccati_resident_kernel<3>,
+                                                        riccati_resident_kernel<4>, riccati_resident_kernel<5>, riccati_resident_kernel<6>, riccati_resident_kernel<7>};
+        const ResKernel kern = table[(a.mu >= 1 && a.mu <= RIC_MU_REG) ? a.mu : 0];
+        e = set_max_dynamic_lds_once((const void*)kern, rl);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(riccati_resident_kernel, dim3(a.nprob), dim3(RIC_THREADS), rl, stream, g);
+        hipLaunchKernelGGL(kern, dim3(a.nprob), dim3(RIC_THREADS), rl, stream, g);
         return hipGetLastError();
     }
     const size_t lds_gain = (mu * na + mu * mu + 2 * RU * mu) * sizeof(double) + (mu + 2) * sizeof(int), lds_pn = 2 * mu * 32 * sizeof(double);

@@ -206,9 +206,11 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *                   with cclqr_ctrl_reserve_noise);
  *   noise_ws_len    doubles in that workspace (checked against n_inst * steps);
  *   newton_mode     0 = the reference's stopping rule, ||f|| < eps AND ||step taken|| < eps (the PARITY mode).
- *                   1 = measured-error mode: a Newton solve stops on ||f|| < eps alone.  Saves the iterations the exact rule spends
- *                   halving steps on round-off noise; the state deviation from mode 0 is reported, not promised.
- *                   Forests of chains only (branching trees and closed loops: CCLQR_EUNSUPPORTED). */
+ *                   1 = measured-error mode: a Newton solve ALSO stops as soon as ||f|| < newton_eps_alone, whatever the step size.
+ *                   Saves the iterations the exact rule spends halving steps on round-off noise; the state deviation from mode 0
+ *                   is reported, not promised.  Forests of chains under the plain LQR / TrackingLQR law only
+ *                   (CCLQR_EUNSUPPORTED otherwise);
+ *   newton_eps_alone  threshold of mode 1 (<= 0: 1e-10, the rule's own eps: stop on the residual alone). */
 typedef struct {
     int64_t first_instance;
     double *pid_state_dev;
@@ -217,6 +219,7 @@ typedef struct {
     int64_t noise_ws_len;
     int32_t newton_mode;
     int32_t reserved;
+    double newton_eps_alone;
 } cclqr_rollout_opts;
 
 /* cclqr_rollout_dev with explicit options (opts may be NULL = cclqr_rollout_dev). */

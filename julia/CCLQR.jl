@@ -43,6 +43,7 @@ struct RolloutOpts         # cclqr_rollout_opts
     noise_ws_len::Int64
     newton_mode::Int32
     reserved::Int32
+    newton_eps_alone::Float64
 end
 
 struct RiccatiOpts         # cclqr_riccati_opts
@@ -260,11 +261,11 @@ end
 
 "Batched simulate!: z0 is 13 x Nb x n_inst; returns (traj 13 x Nb x steps x n_inst or nothing, zT, status)."
 function simulate_batch!(h::MechHandle, c::CtrlHandle, z0::Array{Float64,3}, steps::Integer; record = true, noise = nothing, k0 = 1,
-                         first_instance = 0, newton_mode = 0)
+                         first_instance = 0, newton_mode = 0, newton_eps_alone = 0.0)
     n = size(z0, 3)
     traj = record ? zeros(13, h.nb, steps, n) : nothing
     zT = similar(z0); status = zeros(Int32, n)
-    o = RolloutOpts(first_instance, C_NULL, 0, C_NULL, 0, newton_mode, 0)      # first_instance: global index of instance 1 of this shard
+    o = RolloutOpts(first_instance, C_NULL, 0, C_NULL, 0, newton_mode, 0, newton_eps_alone)      # first_instance: global index of instance 1 of this shard
     check(ccall((:cclqr_rollout_host_ex, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{RolloutOpts}),
                 h.ptr, c.ptr, n, steps, k0, z0, noise === nothing ? C_NULL : noise, record ? traj : C_NULL, zT, status, o))
@@ -278,8 +279,8 @@ end
 function rollout_dev!(h::MechHandle, c::CtrlHandle, n::Integer, steps::Integer, k0::Integer, z0::Ptr{Float64}, lam::Ptr{Float64},
                       traj::Ptr{Float64}, zT::Ptr{Float64}, status::Ptr{Int32}; noise::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_stride = 0,
                       first_instance = 0, pid_state::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_ws::Ptr{Float64} = Ptr{Float64}(C_NULL),
-                      newton_mode = 0, stream::Ptr{Cvoid} = C_NULL)
-    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2, noise_ws, noise_ws == C_NULL ? 0 : n * steps, newton_mode, 0)
+                      newton_mode = 0, newton_eps_alone = 0.0, stream::Ptr{Cvoid} = C_NULL)
+    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2, noise_ws, noise_ws == C_NULL ? 0 : n * steps, newton_mode, 0, newton_eps_alone)
     check(ccall((:cclqr_rollout_ex, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
                  Ref{RolloutOpts}, Ptr{Cvoid}),

@@ -400,7 +400,9 @@ def test_infinite_horizon_batch_keeps_one_gain_per_setpoint(cclqr, orc):
         assert np.array_equal(K1[:, 0], Kf[:, 0])
         assert np.abs(Kf[:, 0] - Kfull[:6, 0]).max() < 1e-9 * np.abs(Kfull[:6, 0]).max()
     Ko, kbo = orc.riccati(A[0], Bu[0], Bl[0], G[0], Q, R, N)
-    assert kbo == kb[0] and np.abs(Kfull[0, 0] - Ko[0]).max() < 1e-7 * np.abs(Ko[0]).max()
+    # at these poses |Pk - Pkp1| shrinks by ~1 % per step where it crosses 1e-5: the oracle's (mu+ml)-square formulation and the device's
+    # projected one may see the crossing one step apart (the gains then differ by one more, converged, backward step)
+    assert abs(int(kbo) - int(kb[0])) <= 1 and np.abs(Kfull[0, 0] - Ko[0]).max() < 1e-7 * np.abs(Ko[0]).max()
     dev = capi.BatchLqrHandle(mh, zd, cj, Q, R, N, infinite_horizon=True)
     assert np.array_equal(dev.kbreak, kb) and dev.N == 0
     Kt, _ = capi.riccati(A, Bu, Bl, G, Q, R, N, keep_last=True)             # the launch shape the batched constructor picks for 48 problems too

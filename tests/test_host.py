@@ -297,7 +297,9 @@ def test_chain_rollout_kernel_resources(tmp_path):
         variant = int(re.search(r"ELi(\d)ELb[01]EEEv", name).group(1))
         if variant == 0:
             assert k["sgpr_spill"] == 0, (name, k)
-            assert k["vgpr_spill"] == 0, (name, k)
+            # the exact-rule kernels park nothing beyond what the allocator places in AGPRs itself; the measured-error (RELAX) variants
+            # read one more launch argument in the accept phase and may move two values to AGPRs for it (never to scratch)
+            assert k["vgpr_spill"] <= (4 if "ELb1EEEv" in name else 0), (name, k)
             # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
             assert k["vgpr"] <= (496 if "ILi32ELi1" in name else 440), (name, k)
         elif variant == 1:
@@ -316,8 +318,9 @@ def test_linearize_and_riccati_kernel_resources(tmp_path):
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
         assert k["sgpr_spill"] <= (23 if "ILb1E" in name else 6), (name, k)
     ric = _kernel_resources(tmp_path, "riccati.hip", "ric")
-    assert len(ric) >= 7, sorted(ric)
-    bound = {"riccati_resident_kernel": 58, "ric_gain_update_kernel": 42}
+    assert len(ric) >= 14, sorted(ric)
+    # riccati_resident_kernel<MU>: 54 (any mu, pivoted LU in LDS) .. 91 (mu = 7 solved in registers: the unrolled per-input loops hold more offsets)
+    bound = {"riccati_resident_kernel": 91, "ric_gain_update_kernel": 42}
     for name, k in ric.items():
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
         # every riccati kernel runs >= 2 wavefronts per SIMD (512-thread workgroups / tiles): <= 256 registers per lane
