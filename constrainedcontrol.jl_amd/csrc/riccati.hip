@@ -639,6 +639,32 @@ __device__ __forceinline__ bool gain_in_registers(int j, bool owner, int mx, int
     return true;
 }
 
+// The same tile with the operands addressed by pointer and stride (no per-load lambdas and predicates) and DOUBLE-BUFFERED: the loads of
+// the next four k-groups are in flight while the MFMAs of the current four issue, so a wavefront no longer stops for a full LDS / L2
+// round trip in front of every batch of MFMAs (with two wavefronts per SIMD the partner covers part of it; the single-buffered form ran at
+// a third of the matrix core's rate).  pa / pb point at the lane's element of k-group 0 (row lk of the group, the lane's column clamped
+// into range by the caller: rows / columns past the edge compute garbage that the caller does not store); ga / gb = elements between
+// consecutive k-groups.  K must be a multiple of 4 (mx = 12 nb always is; other sizes take wave_tile16).
+template <class PA, class PB>
+__device__ inline v4d wave_tile16_db(int ngroups, PA pa, int ga, PB pb, int gb) {
+    constexpr int CH = 4;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    double a0[CH], b0[CH], a1[CH], b1[CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++) { const bool ok = u < ngroups; a0[u] = ok ? pa[(size_t)u * ga] : 0.0; b0[u] = ok ? pb[(size_t)u * gb] : 0.0; }
+    for (int g0 = 0; g0 < ngroups; g0 += 2 * CH) {
+#pragma unroll
+        for (int u = 0; u < CH; u++) { const int g = g0 + CH + u; const bool ok = g < ngroups; a1[u] = ok ? pa[(size_t)g * ga] : 0.0; b1[u] = ok ? pb[(size_t)g * gb] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < CH; u++) if (g0 + u < ngroups) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < CH; u++) { const int g = g0 + 2 * CH + u; const bool ok = g < ngroups; a0[u] = ok ? pa[(size_t)g * ga] : 0.0; b0[u] = ok ? pb[(size_t)g * gb] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < CH; u++) if (g0 + CH + u < ngroups) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 size_t ric_resident_lds_bytes(int mx, int mu) {
     const size_t na = (size_t)mx + mu;
     return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2) * sizeof(double) + (mu + 2) * sizeof(int);
@@ -681,8 +707,8 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         for (int tile = wave; tile < t16m * t16n; tile += RIC_WAVES) {
             const int i0 = (tile / t16n) << 4, j0 = (tile % t16n) << 4;
             const bool iok = i0 + li < mx, jok = j0 + li < na;
-            const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? P[kk * mx + i0 + li] : 0.0; },
-                                        [&](int kk) { return jok ? AD[(size_t)kk * na + j0 + li] : 0.0; });
+            const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : na - 1;
+            const v4d acc = wave_tile16_db(mx >> 2, P + lk * mx + ic, 4 * mx, AD + (size_t)lk * na + jc, 4 * na);
             if (jok) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < mx) W[row * na + j0 + li] = acc[r]; }
@@ -695,8 +721,8 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
             for (int tile = wave; tile < t16n; tile += RIC_WAVES) {
                 const int j0 = tile << 4;
                 const bool iok = li < mu, jok = j0 + li < na;
-                const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? Dl[kk * mu + li] : 0.0; },
-                                            [&](int kk) { return jok ? W[kk * na + j0 + li] : 0.0; });
+                const int ic = iok ? li : mu - 1, jc = jok ? j0 + li : na - 1;
+                const v4d acc = wave_tile16_db(mx >> 2, Dl + lk * mu + ic, 4 * mu, W + lk * na + jc, 4 * na);
                 if (jok) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) { const int row = lk + 4 * r; if (row < mu) TS[row * na + j0 + li] = acc[r]; }
@@ -785,8 +811,8 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
             const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
             const bool iok = i0 + li < mx, jok = j0 + li < mx;
-            const v4d acc = wave_tile16(mx, [&](int kk) { return iok ? Abar[(size_t)kk * mx + i0 + li] : 0.0; },
-                                        [&](int kk) { return jok ? W[kk * na + j0 + li] : 0.0; });
+            const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : mx - 1;
+            const v4d acc = wave_tile16_db(mx >> 2, Abar + (size_t)lk * mx + ic, 4 * mx, W + lk * na + jc, 4 * na);
             if (jok) {
                 const int j = j0 + li;
 #pragma unroll
@@ -855,7 +881,8 @@ size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_
     return (size_t)nprob * (nlin * mx * na + mx * na + 3 * (size_t)mx * mx + 2 * (size_t)mu * mx + 2 * tm * tm + tm * mu * na + nlin * sc + nlin * (ml + 2) + 8) + 64;
 }
 
-static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024; }
+// P and W in one CU's LDS, and whole k-groups of four for the double-buffered tiles (mx = 12 nb always is a multiple of 4)
+static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024 && (a.mx & 3) == 0; }
 // resident (one workgroup per problem, P and W in LDS) whenever it fits; otherwise the tiled three-launch step
 static bool ric_use_tiled(const RicArgs& a) {
     if (!ric_resident_fits(a) || a.bf16_terms > 0) return true;       // the measured-error mode exists on the tiled path only
