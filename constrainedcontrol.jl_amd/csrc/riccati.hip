@@ -555,13 +555,14 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_pn_kernel(RicGrid a, int k) 
 }
 
 // =====================================================================================================================
-// RESIDENT path (problems whose P and W = P [A'|D] fit one CU's LDS, mx up to ~96): one 512-thread workgroup per problem
-// runs the whole sweep with P and W resident in LDS; A' | D (constant, or per knot) and Abar stream through L2.  Per step:
-//   W = Pk [A' | D]                       16x16 MFMA tiles, A operand from LDS, B operand from global
-//   S = R + D'W_D ; Ku = S \ D'W_A'       mu x mu pivoted LU in LDS                                   lqr.jl:152-164
-//   W_A' -= W_D Ku (= Pk Abar) ; Abar = A' - D Ku -> global scratch                                   lqr.jl:169
+// RESIDENT path (problems whose P and W = P [A'|D] fit one CU's LDS, mx up to 96): one 512-thread workgroup per problem
+// runs the whole sweep with P and W resident in LDS and the [A'|D] / Abar MFMA fragments in registers (ric_wave_tiles).  Per step:
+//   W = Pk [A' | D]                       16x16 MFMA tiles, A operand from LDS, B operand from the wavefront's register fragment
+//   S = R + D'W_D ; Ku = S \ D'W_A'       mu x mu system in registers (gain_in_registers), pivoted LU in LDS as the fallback      lqr.jl:152-164
+//   W_A' -= W_D Ku (= Pk Abar) in LDS ; Abar = A' - D Ku as a register fragment                       lqr.jl:169
 //   Pkp1 = Q + Ku'RKu + Abar' (Pk Abar)   tiles again, written over Pk in LDS while |Pk - Pkp1|^2 is summed   lqr.jl:170-176
-// No flags, no launches per step: this is the shape for many small problems (config 4 with a setpoint per instance).
+// No flags, no launches per step, no global memory operand inside a step but Q and the gain that leaves: this is the shape for many
+// small problems (config 4 with a setpoint per instance).
 // 16x16 tile of sum_k a(k) b(k) by one wavefront, eight k-groups (16 operand loads) per pass.  Measured alternatives that were
 // slower under the 256-register budget of a 512-thread workgroup: all of a tile's operands in one pass, strips of tiles sharing the
 // global operand's fragments, two register buffers with the next pass prefetched (spills in every case).
@@ -665,6 +666,25 @@ __device__ inline v4d wave_tile16_db(int ngroups, PA pa, int ga, PB pb, int gb) 
     return acc;
 }
 
+// Tile ownership of the resident kernel.  Every wavefront works on ONE 16-column block `col` of [A' | D] for the whole sweep, so that the
+// block's MFMA fragment (A'|D)[k][col*16 + lane] -- the B operand of W = Pk [A'|D] -- stays in its registers across all backward steps of a
+// time-invariant problem, and Abar[k][col*16 + lane] = A' - D Ku, the A operand of Abar'(Pk Abar), is formed from it in registers: no MFMA
+// operand comes from global memory any more (the L2 round trips of the streamed A'|D and of the Abar scratch kept the matrix cores at a
+// third of their rate).  The C <= 8 column blocks are dealt to the 8 wavefronts; blocks that get several wavefronts split the T row tiles
+// (of W; column tiles of Pkp1) among them.  For the Sawyer shape (C = 6 blocks): wavefronts 0-3 take blocks 0-3 whole, 4/5 halves of block
+// 4, 6/7 halves of block 5 -- wavefronts w and w + 4 share a SIMD, which then has 9 tiles whichever pair it hosts.
+__device__ inline void ric_wave_tiles(int wave, int C, int T, int* col, int* lo, int* hi) {
+    *col = -1; *lo = 0; *hi = 0;
+    if (C > RIC_WAVES) return;                           // (never: the resident path is chosen for na <= 128 only)
+    const int base = RIC_WAVES / C, extra = RIC_WAVES % C;   // the LAST `extra` blocks get one wavefront more
+    int w = 0;
+    for (int c = 0; c < C; c++) {
+        const int n = base + (c >= C - extra ? 1 : 0);
+        if (wave >= w && wave < w + n) { const int p = wave - w; *col = c; *lo = (T * p) / n; *hi = (T * (p + 1)) / n; return; }
+        w += n;
+    }
+}
+
 size_t ric_resident_lds_bytes(int mx, int mu) {
     const size_t na = (size_t)mx + mu;
     return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2) * sizeof(double) + (mu + 2) * sizeof(int);
@@ -672,7 +692,57 @@ size_t ric_resident_lds_bytes(int mx, int mu) {
 
 // MUT: the number of inputs as a compile-time constant (1 .. RIC_MU_REG: the mu x mu system is solved in registers, gain_in_registers), or 0:
 // any mu, pivoted LU in LDS
-template <int MUT>
+// NGT: mx / 4 as a compile-time constant (the [A'|D] / Abar MFMA fragments live in registers, ric_wave_tiles), or 0: any mx, the operands
+// stream from L2 through the double-buffered tiles
+// BF: 0 = fp64 MFMA (parity mode); 1..3 = the measured-error mode of BASELINE configs[3] on THIS kernel ("dense Riccati on MFMA bf16 -> fp32
+// accumulate"): the two mx^3 products run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, every fp64 operand split into BF bf16 terms
+// (products t_i t_j with i + j < BF).  The register fragment is split once per step, the LDS operand on the fly per tile; Pk, W, the gain
+// solve and the rank-mu update stay fp64.  Only with NGT > 0.
+template <int BF, int NGF>
+struct RicBf16Frag {
+    static constexpr int NKB = (NGF + 3) / 4;        // k-blocks of 16: lane (li, lk) holds k = 16 kb + 4 t + lk, t = 0..3 (same map for both operands)
+    v4s t[NKB][BF > 0 ? BF : 1];
+    __device__ __forceinline__ void split(const double* frag) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                short ts[BF > 0 ? BF : 1];
+                bf16_split<(BF > 0 ? BF : 1)>((4 * kb + u) < NGF ? frag[(4 * kb + u) < NGF ? 4 * kb + u : 0] : 0.0, ts);
+#pragma unroll
+                for (int s_ = 0; s_ < (BF > 0 ? BF : 1); s_++) t[kb][s_][u] = ts[s_];
+            }
+    }
+};
+// one 16x16 tile with the register fragment `F` as one operand and an LDS column (element of k-group g at p[g * gs]) as the other;
+// REG_IS_A: the fragment is the A operand (Pkp1 tiles) or the B operand (W tiles)
+template <int BF, int NGF, bool REG_IS_A>
+__device__ __forceinline__ v4d ric_tile_bf16(const RicBf16Frag<BF, NGF>& F, const lds_double* p, int gs) {
+    constexpr int NS = BF > 0 ? BF : 1;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < RicBf16Frag<BF, NGF>::NKB; kb++) {
+        v4s o[NS];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            short ts[NS];
+            bf16_split<NS>((4 * kb + u) < NGF ? p[(4 * kb + u) * gs] : 0.0, ts);
+#pragma unroll
+            for (int s_ = 0; s_ < NS; s_++) o[s_][u] = ts[s_];
+        }
+#pragma unroll
+        for (int sa = NS - 1; sa >= 0; sa--)            // smallest products first
+#pragma unroll
+            for (int sb = NS - 1; sb >= 0; sb--)
+                if (sa + sb < NS)
+                    acc = REG_IS_A ? __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(F.t[kb][sa], o[sb], acc, 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(o[sa], F.t[kb][sb], acc, 0, 0, 0);
+    }
+    v4d r = {(double)acc[0], (double)acc[1], (double)acc[2], (double)acc[3]};
+    return r;
+}
+
+template <int MUT, int NGT, int BF = 0>
 __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a) {
     extern __shared__ double rl[];
 #ifdef CCLQR_PROFILE
@@ -680,7 +750,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
 #endif
     __shared__ int sing;
     const int prob = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int mx = a.mx, mu = MUT > 0 ? MUT : a.mu, na = a.na, N = a.N;
+    const int mx = NGT > 0 ? 4 * NGT : a.mx, mu = MUT > 0 ? MUT : a.mu, na = mx + mu, N = a.N;
     if (a.stop[prob]) return;            // G Bλ was singular in the projection (status already set)
     lds_double* P = (lds_double*)rl;
     lds_double* W = P + (size_t)mx * mx;
@@ -692,26 +762,65 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
     lds_double* Rl = S + (size_t)mu * mu;
     lds_double* red = Rl + (size_t)mu * mu;
     int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2));
-    double* Abar = a.Abar + (size_t)prob * mx * mx;
     double* Kout = a.K + (size_t)prob * (a.keep_last ? 1 : (N > 1 ? N - 1 : 0)) * mu * mx;
     if (tid == 0) sing = 0;
     for (int e = tid; e < mx * mx; e += RIC_THREADS) P[e] = a.Q[e];       // Pk = Q                                  lqr.jl:147
     for (int e = tid; e < mu * mu; e += RIC_THREADS) Rl[e] = a.R[e];
     __syncthreads();
     const int t16m = (mx + 15) >> 4, t16n = (na + 15) >> 4;
+    int col, tlo, thi;                   // this wavefront's column block of [A'|D] and its share of the row tiles (ric_wave_tiles)
+    ric_wave_tiles(wave, t16n, t16m, &col, &tlo, &thi);
+    const int cj = col >= 0 ? col * 16 + li : 0;
+    const bool cj_ok = col >= 0 && cj < na;               // the lane's column of [A'|D] exists
+    const int cjc = cj_ok ? cj : na - 1;                  // clamped: lanes past the edge compute garbage that is never stored
+    const bool pp_col = col >= 0 && col * 16 < mx;        // the block holds columns of A' (not only of D): it owns a row strip of Pkp1
+    const int cic = (cj < mx) ? cj : mx - 1;
+    // (A'|D)[4 g + lk][cj]: B operand of the W tiles; after the gain it becomes Abar[4 g + lk][cj], the A operand of the Pkp1 tiles.  Fetched at
+    // the top of every step (one batch of mx/4 loads per lane, L2-resident; keeping a second copy for time-invariant models costs 48
+    // registers the 256-register budget of a 512-thread workgroup does not have)
+    constexpr int NGF = NGT > 0 ? NGT : 1;
+    double frag[NGF];
+    RicBf16Frag<BF, NGF> fsplit;         // the fragment's bf16 terms (BF > 0 only)
+    double* Abar = a.Abar + (size_t)prob * mx * mx;      // scratch of the streaming form (NGT = 0)
     int k = 0, status = 0;
     for (k = N - 1; k >= 1; k--) {                                        // for outer k=N-1:-1:1                    lqr.jl:150
         const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
         for (int e = tid; e < mx * mu; e += RIC_THREADS) Dl[e] = AD[(size_t)(e / mu) * na + mx + e % mu];
-        // W = Pk [A' | D]   (Pk symmetric)
-        for (int tile = wave; tile < t16m * t16n; tile += RIC_WAVES) {
-            const int i0 = (tile / t16n) << 4, j0 = (tile % t16n) << 4;
-            const bool iok = i0 + li < mx, jok = j0 + li < na;
-            const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : na - 1;
-            const v4d acc = wave_tile16_db(mx >> 2, P + lk * mx + ic, 4 * mx, AD + (size_t)lk * na + jc, 4 * na);
-            if (jok) {
+        if (NGT > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < mx) W[row * na + j0 + li] = acc[r]; }
+            for (int g = 0; g < NGF; g++) frag[g] = col >= 0 ? AD[(size_t)(4 * g + lk) * na + cjc] : 0.0;
+            if (BF > 0) fsplit.split(frag);
+        }
+        if (NGT > 0) {
+            // W = Pk [A' | D]   (Pk symmetric): the wavefront's column block, its share of the row tiles; A operand from LDS, B from registers
+            if (col >= 0) {
+                for (int rt = tlo; rt < thi; rt++) {
+                    const int i0 = rt << 4;
+                    const int ic = (i0 + li < mx) ? i0 + li : mx - 1;
+                    const lds_double* pa = P + lk * mx + ic;
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    if (BF > 0) acc = ric_tile_bf16<BF, NGF, false>(fsplit, pa, 4 * mx);
+                    else {
+#pragma unroll
+                        for (int g = 0; g < NGF; g++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[g * 4 * mx], frag[g], acc, 0, 0, 0);
+                    }
+                    if (cj_ok) {       // accumulator rows of a lane: lk + 4 r (v_mfma_f64_16x16x4) / 4 lk + r (v_mfma_f32_16x16x16_bf16)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { const int row = i0 + (BF > 0 ? 4 * lk + r : lk + 4 * r); if (row < mx) W[row * na + cj] = acc[r]; }
+                    }
+                }
+            }
+        } else {
+            // W = Pk [A' | D]   (Pk symmetric)
+            for (int tile = wave; tile < t16m * t16n; tile += RIC_WAVES) {
+                const int i0 = (tile / t16n) << 4, j0 = (tile % t16n) << 4;
+                const bool iok = i0 + li < mx, jok = j0 + li < na;
+                const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : na - 1;
+                const v4d acc = wave_tile16_db(mx >> 2, P + lk * mx + ic, 4 * mx, AD + (size_t)lk * na + jc, 4 * na);
+                if (jok) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < mx) W[row * na + j0 + li] = acc[r]; }
+                }
             }
         }
         __syncthreads();
@@ -785,45 +894,111 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         }
         __syncthreads();
         RSTAMP(RP_GAIN);
-        // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) -> global scratch
-        for (int i = tid >> 5; i < mx; i += RIC_THREADS / 32) {
-            for (int j0 = tid & 31; j0 < mx; j0 += 128) {          // four columns of a row per pass: their A' loads are in flight together
-                double ab[4], pw[4];
+        if (NGT > 0) {
+            // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169): the wavefront's column strip of it, as the
+            // MFMA fragment Abar[4 g + lk][cj], from the A' fragment it already holds (never written to memory)
+            // W_A' -= W_D Ku on the matrix core: a rank-mu update, ceil(mu / 4) MFMAs per 16x16 tile with the tile itself as the accumulator
+            for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
+                const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
+                const bool iok = i0 + li < mx, jok = j0 + li < mx;
+                const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : mx - 1;
+                v4d acc;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = j0 + 32 * u;
-                    ab[u] = j < mx ? AD[(size_t)i * na + j] : 0.0;
-                    pw[u] = j < mx ? W[i * na + j] : 0.0;
+                for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; acc[r] = W[(row < mx ? row : mx - 1) * na + jc]; }
+                for (int q0 = 0; q0 < mu; q0 += 4) {
+                    const int q = q0 + lk;
+                    const double av = q < mu ? -W[ic * na + mx + q] : 0.0, bv = q < mu ? Ku[q * mx + jc] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
+                if (jok) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < mx) W[row * na + j0 + li] = acc[r]; }
+                }
+            }
+            if (pp_col) {
                 for (int q = 0; q < mu; q++) {
-                    const double dq = Dl[i * mu + q], wq = W[i * na + mx + q];
+                    const double kq = Ku[q * mx + cic];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; const double kq = j < mx ? Ku[q * mx + j] : 0.0; ab[u] -= dq * kq; pw[u] -= wq * kq; }
+                    for (int g = 0; g < NGF; g++) frag[g] -= Dl[(4 * g + lk) * mu + q] * kq;
                 }
+                if (BF > 0) fsplit.split(frag);
+            }
+        } else {
+            // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) -> global scratch
+            for (int i = tid >> 5; i < mx; i += RIC_THREADS / 32) {
+                for (int j0 = tid & 31; j0 < mx; j0 += 128) {          // four columns of a row per pass: their A' loads are in flight together
+                    double ab[4], pw[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; if (j < mx) { Abar[(size_t)i * mx + j] = ab[u]; W[i * na + j] = pw[u]; } }
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + 32 * u;
+                        ab[u] = j < mx ? AD[(size_t)i * na + j] : 0.0;
+                        pw[u] = j < mx ? W[i * na + j] : 0.0;
+                    }
+                    for (int q = 0; q < mu; q++) {
+                        const double dq = Dl[i * mu + q], wq = W[i * na + mx + q];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; const double kq = j < mx ? Ku[q * mx + j] : 0.0; ab[u] -= dq * kq; pw[u] -= wq * kq; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int j = j0 + 32 * u; if (j < mx) { Abar[(size_t)i * mx + j] = ab[u]; W[i * na + j] = pw[u]; } }
+                }
             }
         }
         __syncthreads();
         RSTAMP(RP_UPD);
         // Pkp1 = Q + Kuk'*R*Kuk + Abar'*(Pk*Abar), over Pk; |Pk - Pkp1|^2 on the way                                lqr.jl:170-176
         double nacc = 0.0;
-        for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
-            const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
-            const bool iok = i0 + li < mx, jok = j0 + li < mx;
-            const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : mx - 1;
-            const v4d acc = wave_tile16_db(mx >> 2, Abar + (size_t)lk * mx + ic, 4 * mx, W + lk * na + jc, 4 * na);
-            if (jok) {
-                const int j = j0 + li;
+        if (NGT > 0) {
+            if (pp_col) {        // row strip i0 = col * 16 of Pkp1: A operand from registers (Abar fragment), B operand Pk Abar from LDS
+                const int i0 = col << 4;
+                for (int ct = tlo; ct < thi; ct++) {
+                    const int j0 = ct << 4;
+                    const bool jok = j0 + li < mx;
+                    const int jc = jok ? j0 + li : mx - 1;
+                    const lds_double* pb = W + lk * na + jc;
+                    double qv[4];                     // Q of the tile's outputs, fetched BEFORE the MFMAs: its L2 round trip hides under them
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int i = i0 + lk + 4 * r;
-                    if (i < mx) {
-                        double v = a.Q[(size_t)i * mx + j] + acc[r];
-                        for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j];
-                        const double d = P[i * mx + j] - v;
-                        nacc += d * d;
-                        P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
+                    for (int r = 0; r < 4; r++) { const int i = i0 + (BF > 0 ? 4 * lk + r : lk + 4 * r); qv[r] = a.Q[(size_t)(i < mx ? i : mx - 1) * mx + jc]; }
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    if (BF > 0) acc = ric_tile_bf16<BF, NGF, true>(fsplit, pb, 4 * na);
+                    else {
+#pragma unroll
+                        for (int g = 0; g < NGF; g++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[g], pb[g * 4 * na], acc, 0, 0, 0);
+                    }
+                    if (jok) {
+                        const int j = j0 + li;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int i = i0 + (BF > 0 ? 4 * lk + r : lk + 4 * r);
+                            if (i < mx) {
+                                double v = qv[r] + acc[r];
+                                for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j];
+                                const double d = P[i * mx + j] - v;
+                                nacc += d * d;
+                                P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
+                const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
+                const bool iok = i0 + li < mx, jok = j0 + li < mx;
+                const int ic = iok ? i0 + li : mx - 1, jc = jok ? j0 + li : mx - 1;
+                const v4d acc = wave_tile16_db(mx >> 2, Abar + (size_t)lk * mx + ic, 4 * mx, W + lk * na + jc, 4 * na);
+                if (jok) {
+                    const int j = j0 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = i0 + lk + 4 * r;
+                        if (i < mx) {
+                            double v = a.Q[(size_t)i * mx + j] + acc[r];
+                            for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j];
+                            const double d = P[i * mx + j] - v;
+                            nacc += d * d;
+                            P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
+                        }
                     }
                 }
             }
@@ -882,10 +1057,15 @@ size_t ric_grid_work_doubles(int nprob, int mx, int mu, int ml, int N, int time_
 }
 
 // P and W in one CU's LDS, and whole k-groups of four for the double-buffered tiles (mx = 12 nb always is a multiple of 4)
-static bool ric_resident_fits(const RicArgs& a) { return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024 && (a.mx & 3) == 0; }
+static bool ric_resident_fits(const RicArgs& a) {
+    return ric_resident_lds_bytes(a.mx, a.mu) <= 158 * 1024 && (a.mx & 3) == 0 && (a.mx + a.mu + 15) / 16 <= RIC_WAVES;
+}
 // resident (one workgroup per problem, P and W in LDS) whenever it fits; otherwise the tiled three-launch step
+// shapes for which the bf16 measured-error mode exists on the resident kernel (the register-fragment specialisations)
+static bool ric_resident_has_bf16(const RicArgs& a) { return (a.mu == 7 && a.mx == 84) || (a.mu == 1 && a.mx == 24); }
 static bool ric_use_tiled(const RicArgs& a) {
-    if (!ric_resident_fits(a) || a.bf16_terms > 0) return true;       // the measured-error mode exists on the tiled path only
+    if (!ric_resident_fits(a)) return true;
+    if (a.bf16_terms > 0 && !ric_resident_has_bf16(a)) return true;   // elsewhere the measured-error mode exists on the tiled path only
     const int path = a.path;      // 0 auto, 1 LDS-resident workgroup per problem, 2 tiled
     if (path != 0) return path == 2;
     // measured crossover: a single 84..96-state problem is faster spread over the device (41 vs 59 us per step), small problems
@@ -936,9 +1116,19 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (!ric_use_tiled(a)) {
         const size_t rl = ric_resident_lds_bytes(a.mx, a.mu);
         typedef void (*ResKernel)(RicGrid);
-        static const ResKernel table[RIC_MU_REG + 1] = {riccati_resident_kernel<0>, riccati_resident_kernel<1>, riccati_resident_kernel<2>, riccati_resident_kernel<3>,
-                                                        riccati_resident_kernel<4>, riccati_resident_kernel<5>, riccati_resident_kernel<6>, riccati_resident_kernel<7>};
-        const ResKernel kern = table[(a.mu >= 1 && a.mu <= RIC_MU_REG) ? a.mu : 0];
+        // specialised (inputs, states / 4) shapes: the BASELINE mechanisms; every other shape takes the generic forms
+        static const ResKernel by_mu[RIC_MU_REG + 1] = {riccati_resident_kernel<0, 0>, riccati_resident_kernel<1, 0>, riccati_resident_kernel<2, 0>, riccati_resident_kernel<3, 0>,
+                                                        riccati_resident_kernel<4, 0>, riccati_resident_kernel<5, 0>, riccati_resident_kernel<6, 0>, riccati_resident_kernel<7, 0>};
+        ResKernel kern = by_mu[(a.mu >= 1 && a.mu <= RIC_MU_REG) ? a.mu : 0];
+        const int ng4 = a.mx >> 2;
+        if (a.mu == 1 && ng4 == 3) kern = riccati_resident_kernel<1, 3>;          // pendulum (mx 12)
+        else if (a.mu == 1 && ng4 == 6) kern = riccati_resident_kernel<1, 6>;     // cartpole, acrobot (mx 24)
+        else if (a.mu == 1 && ng4 == 12) kern = riccati_resident_kernel<1, 12>;   // triple cartpole (mx 48)
+        else if (a.mu == 7 && ng4 == 21) kern = riccati_resident_kernel<7, 21>;   // Sawyer (mx 84)
+        if (a.bf16_terms > 0) {      // ric_use_tiled has checked that the shape is one of these
+            if (a.mu == 7) kern = a.bf16_terms == 1 ? riccati_resident_kernel<7, 21, 1> : (a.bf16_terms == 2 ? riccati_resident_kernel<7, 21, 2> : riccati_resident_kernel<7, 21, 3>);
+            else kern = a.bf16_terms == 1 ? riccati_resident_kernel<1, 6, 1> : (a.bf16_terms == 2 ? riccati_resident_kernel<1, 6, 2> : riccati_resident_kernel<1, 6, 3>);
+        }
         e = set_max_dynamic_lds_once((const void*)kern, rl);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(a.nprob), dim3(RIC_THREADS), rl, stream, g);

@@ -142,8 +142,10 @@ int cclqr_riccati(int32_t nprob, int32_t mx, int32_t mu, int32_t ml, const doubl
  *   bf16_terms  0 = fp64 MFMA, the PARITY mode (gains equal the reference recursion's to 1e-7).  1..3 = measured-error mode of
  *               BASELINE configs[3] ("dense Riccati on MFMA bf16 -> fp32 accumulate"): the two mx^3 products of a backward step
  *               (lqr.jl:170) run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, every fp64 operand split into that many bf16
- *               terms (1 = plain bf16, 3 = bf16x3); forces path 2.  Its gain error and speed are reported, not promised
- *               (DESIGN.md 4.3): it does NOT reproduce the fp64 gains and the 1e-5 break test of lqr.jl:172 never fires.
+ *               terms (1 = plain bf16, 3 = bf16x3).  Available on the tiled path for every shape and on the LDS-resident batched
+ *               kernel for the Sawyer (mx 84, mu 7) and cartpole (mx 24, mu 1) shapes; other shapes take the tiled path.  Its gain
+ *               error and speed are reported, not promised: it does NOT reproduce the fp64 gains and the 1e-5 break
+ *               test of lqr.jl:172 never fires.
  *   keep_last   != 0: K is [nprob][mu][mx] and receives only the gain of the last executed backward step = Ku[1] after the back-fill of
  *               lqr.jl:179-181 = the single gain LQR{T,Inf} keeps (lqr.jl:40-43); the (N-1)-fold table is never materialised. */
 typedef struct {

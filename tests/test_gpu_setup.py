@@ -486,3 +486,33 @@ def test_bench_line_contract(tmp_path):
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] in ("port", "reference")
     assert abs(d["value"] - 512 * 40 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_riccati_bf16_mode_on_the_batched_resident_kernel(cclqr, orc):
+    """BASELINE configs[3] as written -- "dense Riccati on MFMA bf16 -> fp32 accumulate" on the BATCHED recursion: the
+    LDS-resident kernel (one workgroup per problem, path = 1) with cclqr_riccati_opts.bf16_terms = 1..3 on distinct Sawyer setpoints.
+    Measured, not promised: bf16x3 reproduces the fp64 gains of the same kernel to ~1e-5, bf16x2 to ~1e-3, plain bf16 not at all; the
+    fp64 MFMA mode stays the parity mode (= oracle to 1e-7, checked here for one problem)."""
+    import json
+    import os
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    n, N = 12, 400
+    rng = np.random.default_rng(8)
+    zd = cclqr.joint_position_states(mech, rng.uniform(-0.6, 0.6, (n, 7)))
+    mh = capi.MechHandle(t)
+    A, Bu, Bl, G = capi.linearize(mh, zd, list(range(7)), np.zeros((n, 7)))
+    Q, R = np.eye(84) * 1000.0 * t.dt, np.eye(7) * t.dt
+    Kref, kbref = capi.riccati(A, Bu, Bl, G, Q, R, N, path=1, keep_last=True)
+    Ko, kbo = orc.riccati(A[0], Bu[0], Bl[0], G[0], Q, R, N)
+    assert kbo == kbref[0] and np.abs(Kref[0, 0] - Ko[0]).max() < 1e-7 * np.abs(Ko[0]).max()
+    err = {}
+    for terms in (3, 2, 1):
+        K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N, path=1, keep_last=True, bf16_terms=terms)
+        assert np.isfinite(K).all()
+        err[terms] = float(np.abs(K - Kref).max() / np.abs(Kref).max())
+    print("batched resident Riccati, bf16 split terms -> relative gain error vs fp64 MFMA:", err)
+    assert err[3] < 1e-3 and err[3] < err[2] < 5e-2 and err[1] > err[2], err

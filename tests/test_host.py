@@ -318,9 +318,14 @@ def test_linearize_and_riccati_kernel_resources(tmp_path):
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
         assert k["sgpr_spill"] <= (23 if "ILb1E" in name else 6), (name, k)
     ric = _kernel_resources(tmp_path, "riccati.hip", "ric")
-    assert len(ric) >= 14, sorted(ric)
-    # riccati_resident_kernel<MU>: 54 (any mu, pivoted LU in LDS) .. 91 (mu = 7 solved in registers: the unrolled per-input loops hold more offsets)
-    bound = {"riccati_resident_kernel": 91, "ric_gain_update_kernel": 42}
+    assert len(ric) >= 24, sorted(ric)
+    for name, k in ric.items():
+        if "riccati_resident_kernel" in name and not re.search(r"ILi\dELi0ELi0EEEv", name):
+            assert k["sgpr_spill"] <= 69, (name, k)          # the specialised shapes
+    # riccati_resident_kernel<MU, NG, BF>: the register-fragment specialisations (NG > 0: the BASELINE shapes) spill 0 .. 69 scalars, the
+    # generic forms (any mx: operands streamed through the double-buffered tiles, unrolled per-input loops) up to 136 -- to VGPR lanes, never
+    # to memory
+    bound = {"riccati_resident_kernel": 136, "ric_gain_update_kernel": 42}
     for name, k in ric.items():
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
         # every riccati kernel runs >= 2 wavefronts per SIMD (512-thread workgroups / tiles): <= 256 registers per lane
