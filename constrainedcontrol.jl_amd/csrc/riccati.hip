@@ -916,10 +916,22 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
             if (pp_col) {
-                for (int q = 0; q < mu; q++) {
-                    const double kq = Ku[q * mx + cic];
+                // Abar fragment = A' fragment - D Ku, also a rank-mu update on the matrix core: the fragment's element (k = 4 g + lk, column cj)
+                // IS accumulator register r = g - 4 T of the 16-row tile T = g / 4 in v_mfma_f64_16x16x4's output layout (row lk + 4 r)
+                constexpr int NT = (NGF + 3) / 4;
 #pragma unroll
-                    for (int g = 0; g < NGF; g++) frag[g] -= Dl[(4 * g + lk) * mu + q] * kq;
+                for (int T = 0; T < NT; T++) {
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = (4 * T + r) < NGF ? frag[(4 * T + r) < NGF ? 4 * T + r : 0] : 0.0;
+                    const int dr = (16 * T + li < mx) ? 16 * T + li : mx - 1;
+                    for (int q0 = 0; q0 < mu; q0 += 4) {
+                        const int q = q0 + lk;
+                        const double av = q < mu ? -Dl[dr * mu + q] : 0.0, bv = q < mu ? Ku[q * mx + cic] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if ((4 * T + r) < NGF) frag[4 * T + r] = acc[r];
                 }
                 if (BF > 0) fsplit.split(frag);
             }
@@ -962,6 +974,16 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
                     if (BF > 0) acc = ric_tile_bf16<BF, NGF, true>(fsplit, pb, 4 * na);
                     else {
+                        // Q + Kuk'*(R*Kuk) + Abar'*(Pk*Abar) in ONE accumulation chain: Q is the initial accumulator, the rank-mu term
+                        // ceil(mu / 4) more k-groups (A = Ku[q][i], B = (R Ku)[q][j])
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[r] = qv[r];
+                        const int ia = (i0 + li < mx) ? i0 + li : mx - 1;
+                        for (int q0 = 0; q0 < mu; q0 += 4) {
+                            const int q = q0 + lk;
+                            const double av = q < mu ? Ku[q * mx + ia] : 0.0, bv = q < mu ? KRK[q * mx + jc] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                        }
 #pragma unroll
                         for (int g = 0; g < NGF; g++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[g], pb[g * 4 * na], acc, 0, 0, 0);
                     }
@@ -971,8 +993,8 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                         for (int r = 0; r < 4; r++) {
                             const int i = i0 + (BF > 0 ? 4 * lk + r : lk + 4 * r);
                             if (i < mx) {
-                                double v = qv[r] + acc[r];
-                                for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j];
+                                double v = acc[r];
+                                if (BF > 0) { v += qv[r]; for (int q = 0; q < mu; q++) v += Ku[q * mx + i] * KRK[q * mx + j]; }
                                 const double d = P[i * mx + j] - v;
                                 nacc += d * d;
                                 P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
