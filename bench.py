@@ -245,7 +245,7 @@ def main():
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,
                    "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes, "launches_per_rollout": chunks},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "rollout_chain_kernel<%d, %d, 0>" % (lanes, mh.layout_links()),
+                     "traffic": traffic, "kernel": "rollout_chain_kernel<%d, %d, 0, false>" % (lanes, mh.layout_links()),
                      "kernel_ms": kern_ms_launch, "launches_per_rollout": chunks, "algorithmic_bytes_per_instance_step": bs,
                      "kernel_source_sha": kernel_source_sha()},
         "collection": {"trajectory_bytes_gathered_to_rank0_per_rollout": gathered, "chunks": chunks,
@@ -284,7 +284,7 @@ def chain_rate(pkg, capi, torch, dev, n_links, n_inst, T):
     ctrl = lq._ctrl_handle(mh)
     lanes, _ = mh.geometry()
     out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, T, True, reps=2), lqr_construct_s=setup, riccati_kbreak=int(lq.kbreak),
-               kernel="rollout_chain_kernel<%d, %d, 0>" % (lanes, mh.layout_links()),
+               kernel="rollout_chain_kernel<%d, %d, 0, false>" % (lanes, mh.layout_links()),
                workload="lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, y0~U(-0.5,0.5) phi_i~U(-0.2,0.2), "
                         "%d instances, record=true" % (n_links, t.nb, T * t.dt, n_inst))
     ctrl.close()

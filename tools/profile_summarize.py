@@ -4,11 +4,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-src, rnd = sys.argv[1], sys.argv[2]                     # e.g. gpurun_out/prof_r02 r02
+src, rnd = sys.argv[1], sys.argv[2]                     # e.g. gpurun_out/prof_r03 r03
 tag = sys.argv[3] if len(sys.argv) > 3 else "bench"
-KERNEL = "rollout_chain_kernel<32, 17, 0>"
+# argv[4]: where the summary goes.  Default profiles/<round>/ (run here, on files merged back from the box); tools/profile_round.sh passes
+# gpurun_out/<dir>/summary so that it runs ON THE BOX and only the summaries travel back (the raw counter CSVs are tens of MiB)
+KERNEL = "rollout_chain_kernel<32, 17, 0, false>"
 WAVES, STEPS, NINST = 4096.0, 1000.0, 8192.0
-dst = os.path.join(ROOT, "profiles", rnd)
+dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
 def counters(sub):
@@ -37,7 +39,8 @@ traffic = {"config": {"links": 16, "instances_per_gpu": 8192, "sim_steps": 1000,
            "kernel_source_sha": bench.kernel_source_sha(), "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
            "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 6672.0 * NINST * STEPS,
            "note": "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, one launch of the default bench workload; separate --pmc passes"}
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+if len(sys.argv) <= 4:
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 
 tot = {}
