@@ -269,7 +269,36 @@ def main():
         out.update(cpu_baseline(pkg, t, lqr, z0, T))
     if world == 1:
         out["extra"] = extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args)
+        if record and chunks == 1:
+            try:
+                out["extra"]["headline_workload_newton_mode1"] = newton_mode1_line(capi, torch, dev, mh, ctrl, z0_d, traj_d, n_inst, T, nb, value)
+            except Exception as e:
+                out["extra"]["headline_workload_newton_mode1"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
+
+
+def newton_mode1_line(capi, torch, dev, mh, ctrl, z0_d, traj_exact, n_inst, T, nb, exact_value, eps=1e-12):
+    """NOT the headline: the same workload with the measured-error Newton mode of cclqr_rollout_opts (newton_mode 1: a solve also stops as soon
+    as ||f|| < eps_alone, instead of iterating on until the step it takes is below 1e-10 too), with its max state deviation from the
+    exact-rule trajectories of the timed headline run measured here, over all instances and steps"""
+    zT = torch.empty_like(z0_d)
+    st = torch.zeros(n_inst, dtype=torch.int32, device=dev)
+    traj = torch.empty_like(traj_exact)
+    stream = torch.cuda.current_stream().cuda_stream
+    run = lambda: capi.rollout_dev(mh, ctrl, n_inst, T, 1, z0_d.data_ptr(), 0, 0, 0, traj.data_ptr(), zT.data_ptr(), st.data_ptr(), stream,
+                                   newton_mode=1, newton_eps_alone=eps)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    dev_max = float((traj - traj_exact).abs().max().item())
+    bad = int((st <= 0).sum().item())
+    return {"value": (n_inst * T / (ms * 1e-3)) if bad == 0 else None, "unit": "instance-steps/s", "ms_per_rollout": ms, "failed_instances": bad,
+            "newton_eps_alone": eps, "max_state_deviation_vs_exact_rule": dev_max, "speedup_vs_exact_rule": (n_inst * T / (ms * 1e-3)) / exact_value,
+            "workload": "the headline workload with cclqr_rollout_opts.newton_mode = 1 (stop on ||f|| < %g alone): a measured-error OPTION; "
+                        "the headline value above is the exact stopping rule" % eps}
 
 
 def chain_rate(pkg, capi, torch, dev, n_links, n_inst, T):

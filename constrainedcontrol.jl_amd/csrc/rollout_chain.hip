@@ -92,6 +92,50 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
     return nrm;
 }
 
+// ---- line search of the 32-lane instantiations (two instances per wavefront): TWO step lengths per pass in a group's own lanes, and when
+// only ONE of the wavefront's two instances is still searching the other group's idle lanes evaluate two more for it.  The noise-floor
+// searches of the exact stopping rule are heavy-tailed (9 % of them run to the 10th halving), and a wavefront pays the longer of its two:
+// the accept sequence -- first level that does not grow, level LINE_MAXIT at the latest -- and every bit of the result are unchanged.
+struct TrialIn { double z[7], s[6], ds[6], cd[6]; };
+__device__ __forceinline__ double other_half(double v) { return __shfl_xor(v, 32, 64); }
+// ||f|| of the owning group at the trial points s - a ds (constraint forces C - a cd) for a = a1 and a = a2; Lc = LDS image of the instance
+template <int G>
+__device__ __forceinline__ void chain_eval2(LinkC& c, const TrialIn& T, const double* Lc, int t, const Lay& Y, double a1, double a2, bool active, double dt,
+                                            double& n1, double& n2) {
+    double part1 = 0.0, part2 = 0.0, xq1[7], xq2[7];
+    LINK_FLAGS_FRESH(c);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { xq1[k] = T.z[k]; xq2[k] = T.z[k]; }
+    if (active) {
+        double cf1[6], cf2[6], sv1[6], sv2[6], cTR[6], d1[6], d2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double cc = Lc[Y.C + 6 * t + k];
+            cTR[k] = Lc[Y.D + 6 * t + k];
+            cf1[k] = cc - a1 * T.cd[k]; cf2[k] = cc - a2 * T.cd[k];
+            sv1[k] = T.s[k] - a1 * T.ds[k]; sv2[k] = T.s[k] - a2 * T.ds[k];
+        }
+        part1 = ck_body_eval<false>(c, T.z, sv1, cf1, cTR, cTR + 3, dt, xq1, d1, nullptr, nullptr);
+        part2 = ck_body_eval<false>(c, T.z, sv2, cf2, cTR, cTR + 3, dt, xq2, d2, nullptr, nullptr);
+    }
+    double p1[7], p2[7];
+    from_prev<7>(xq1, p1);
+    from_prev<7>(xq2, p2);
+    if (!c.has_a()) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) { p1[i] = (i == 3) ? 1.0 : 0.0; p2[i] = p1[i]; }
+    }
+    if (active) {
+        double g1[5], g2[5];
+        joint_eval_sparse<false>(c, p1, p1 + 3, xq1, xq1 + 3, nullptr, nullptr, g1, (double(*)[3]) nullptr, (double(*)[3]) nullptr, (double(*)[3]) nullptr);
+        joint_eval_sparse<false>(c, p2, p2 + 3, xq2, xq2 + 3, nullptr, nullptr, g2, (double(*)[3]) nullptr, (double(*)[3]) nullptr, (double(*)[3]) nullptr);
+#pragma unroll
+        for (int i = 0; i < 5; i++) { part1 += g1[i] * g1[i]; part2 += g2[i] * g2[i]; }
+    }
+    n1 = sqrt(group_sum<G>(part1));
+    n2 = sqrt(group_sum<G>(part2));
+}
+
 // Counter-based noise (noise_philox): the samples of a launch are generated by this kernel into a workspace and the rollout
 // reads them like an injected array -- sqrt/log/cos inside the persistent kernel cost it ~20 scalar registers of polynomial
 // constants for its whole lifetime.  sample (instance n, step k) = Box-Muller of Philox-4x32-10 keyed by the GLOBAL instance index.
@@ -364,13 +408,54 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     if (!(normf1 > normf0)) ls_done = true;
                 }
             }
-            for (int lv = 1; lv <= LINE_MAXIT; lv++) {
-                if (!__any(!ls_done)) break;
-                const double a_l = ldexp(1.0, -lv);
-                const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, c.live() && !ls_done, dt PROF_PASS);
-                if (!ls_done) {
-                    normf1 = nf; alpha = a_l; jac_ok = false;
-                    if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
+            if (G == 32) {
+                for (int lv = 1; lv <= LINE_MAXIT;) {
+                    if (!__any(!ls_done)) break;
+                    const bool mine = !ls_done;                                   // uniform over the group
+                    const bool other = __shfl_xor(mine ? 1 : 0, 32, 64) != 0;     // the wavefront's other instance is searching too
+                    const bool helping = !mine && other;                          // this group's lanes evaluate two more levels of the other's search
+                    TrialIn T;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) T.z[i] = S.z[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { T.s[i] = S.s[i]; T.ds[i] = S.ds[i]; T.cd[i] = S.cd[i]; }
+                    if (mine != other) {       // (symmetric in the two groups: a wavefront-uniform branch) one searches, one helps: hand the trial over
+#pragma unroll
+                        for (int i = 0; i < 7; i++) { const double o = other_half(S.z[i]); T.z[i] = helping ? o : T.z[i]; }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            const double o1 = other_half(S.s[i]), o2 = other_half(S.ds[i]), o3 = other_half(S.cd[i]);
+                            T.s[i] = helping ? o1 : T.s[i]; T.ds[i] = helping ? o2 : T.ds[i]; T.cd[i] = helping ? o3 : T.cd[i];
+                        }
+                    }
+                    const double* Lc = helping ? lds + (1 - grp) * Y.total : L;
+                    const int l0 = helping ? lv + 2 : lv;
+                    double n1, n2;
+                    chain_eval2<G>(c, T, Lc, t, Y, ldexp(1.0, -l0), ldexp(1.0, -(l0 + 1)), c.on() && (mine || helping) && l0 <= LINE_MAXIT, dt, n1, n2);
+                    PCOUNT(PF_EVALS);
+                    const double h1 = other_half(n1), h2 = other_half(n2);
+                    if (mine) {
+                        const double cand[4] = {n1, n2, h1, h2};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int l = lv + i;
+                            if (!ls_done && l <= LINE_MAXIT && (i < 2 || !other)) {
+                                normf1 = cand[i]; alpha = ldexp(1.0, -l); jac_ok = false;
+                                if (!(cand[i] > normf0) || l == LINE_MAXIT) ls_done = true;
+                            }
+                        }
+                    }
+                    lv += (mine && other) ? 2 : 4;
+                }
+            } else {
+                for (int lv = 1; lv <= LINE_MAXIT; lv++) {
+                    if (!__any(!ls_done)) break;
+                    const double a_l = ldexp(1.0, -lv);
+                    const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, c.live() && !ls_done, dt PROF_PASS);
+                    if (!ls_done) {
+                        normf1 = nf; alpha = a_l; jac_ok = false;
+                        if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
+                    }
                 }
             }
             bool need_jac = false;

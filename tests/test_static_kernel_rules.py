@@ -18,10 +18,10 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc")
 
-CROSS = re.compile(r"\b(wave_from_prev|wave_from_next|from_prev\s*<|from_next\s*<|group_sum\s*<|dpp_f64\s*<|dpp_row_ror\s*<|wave_max_key|key_dpp_max\s*<|__shfl\w*|"
+CROSS = re.compile(r"\b(wave_from_prev|wave_from_next|from_prev\s*<|from_next\s*<|group_sum\s*<|dpp_f64\s*<|dpp_row_ror\s*<|wave_max_key|key_dpp_max\s*<|other_half|__shfl\w*|"
                    r"__builtin_amdgcn_(readlane|readfirstlane|update_dpp|mov_dpp|permlane\w*|ds_bpermute|ds_swizzle)|__syncthreads|__any|__all|__ballot)\b")
 # definitions of the cross-lane helpers themselves (their bodies ARE the cross-lane instruction)
-HELPER_DEF = re.compile(r"(double|void|int|v4d|unsigned long long)\s+(wave_from_prev|wave_from_next|from_prev|from_next|group_sum|dpp_f64|dpp_row_ror|wave_max_key|key_dpp_max)\s*\(")
+HELPER_DEF = re.compile(r"(double|void|int|v4d|unsigned long long)\s+(wave_from_prev|wave_from_next|from_prev|from_next|group_sum|dpp_f64|dpp_row_ror|wave_max_key|key_dpp_max|other_half)\s*\(")
 
 PER_LANE_HEADERS = ["cclqr_chain.h", "cclqr_dev.h", "cclqr_lin_dev.h", "cclqr_loop.h"]
 ORCHESTRATION = ["rollout_chain.hip", "rollout.hip", "rollout_loop.hip", "linearize.hip", "cclqr_newton.h"]
@@ -33,6 +33,9 @@ UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAX
            r"^int iter = 1; iter <= NEWTON_MAXIT", r"^int lv = 1; lv <= LINE_MAXIT", r"^int ls = 0; ls <= LINE_MAXIT", r"^int ci = 0; ci < nchains", r"^int c = 0; c < nchains",
            r"^int i = 0; i < P\.steps", r"^int j = 0; j < P\.steps", r"^int q = 0; q < (LEVEL_SLOTS|NL)", r"^gate && ", r"^k < ", r"^step < ", r"^int step = ",
            r"^int p = 0; p < ", r"^p < ", r"^int it = ",
+           # rollout_chain.hip line search: `mine` is uniform over a 32-lane group and `other` is the partner group's `mine`, so `mine != other`
+           # has the same value in both groups of the wavefront
+           r"^mine != other$", r"^int i = 0; i < \d+; i\+\+$",        # (compile-time unrolled component loops)
            # rollout_loop.hip loop_solve: mr = 5 M->nj; `rank` and the pivot it stops on come out of wave_max_key (v_readlane 63: the same in every lane)
            r"^int k = 0; k < mr", r"^int k = rank - 1; k >= 0", r"^it <= ", r"^nsteps", r"^steps", r"^mode", r"^int kk = ", r"^rank < ", r"^int e = t; e < Y\.total"]
 
