@@ -275,8 +275,8 @@ def linearize(mech, zd, ctrl_joint, Fd=None):
 
 
 def linearize_projected(mech, zd, ctrl_joint, Fd=None, h=0.0):
-    """projected linear model (A', D) of the device's constrained step map by central differences: zd [nk][nb][13] -> A' [nk][mx][mx],
-    D [nk][mx][mu] (cclqr_linearize_projected; any topology, the only linearisation of closed-loop mechanisms)"""
+    """projected linear model (A', D) of the constrained step map: zd [nk][nb][13] -> A' [nk][mx][mx], D [nk][mx][mu] (cclqr_linearize_projected;
+    any topology, the only linearisation of closed-loop mechanisms).  h <= 0: analytic on the device; h > 0: central differences of the device's step"""
     t = mech.tables
     zd = f64(zd).reshape(-1, t.nb, 13)
     nk = zd.shape[0]

@@ -460,13 +460,64 @@ __global__ void fd_quotient_kernel(const double* zT, int nk, int per, int nb, in
         else D[((size_t)k * mx + r) * mu + (col - mx)] = v;
     }
 }
+// The projected pair ANALYTICALLY (h <= 0): the exact Jacobians of the one-step map with the multipliers exogenous -- linearize_kernel for
+// trees, linearize_loop_kernel (cclqr_lin_loop.h) for closed loops, nothing leaves the device -- and then the multipliers eliminated by
+// project_model_kernel, whose complete pivoting stops at the numerical rank of G Bl (singular for a loop: redundant constraint rows).
+static int linearize_projected_analytic(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
+                                        double* Ap, double* D) {
+    const int nb = m->nb, nj = m->host.loop ? m->nj : nb, mx = 12 * nb, ml = 5 * nj;
+    const size_t nz = 13 * (size_t)nb;
+    if (!m->host.loop && linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    if (project_model_lds_bytes(mx, mu, ml) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "the projection of this model does not fit LDS (use h > 0)");
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = m->dev; a.nk = nk; a.mu = mu;
+    for (int i = 0; i < mu; i++) {
+        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nj) return fail(CCLQR_EINVAL, "controlled joint out of range");
+        a.cj[i] = m->host.loop ? ctrl_joint[i] : m->link_of_joint[ctrl_joint[i]];      // closed-loop tables keep the caller's joint order
+    }
+    const size_t mu1 = (size_t)(mu > 0 ? mu : 1);
+    double *dzd = nullptr, *dFd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr, *dAp = nullptr, *dD = nullptr, *dres = nullptr;
+    int *dst = nullptr, *drank = nullptr;
+    std::vector<int> st(nk), rank(nk);
+    std::vector<double> res(nk);
+    WsScope scope;
+    hipError_t e = ws_get((void**)&dzd, nk * nz * sizeof(double));
+    if (e == hipSuccess && Fd && mu > 0) e = ws_get((void**)&dFd, (size_t)nk * mu * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dA, (size_t)nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBu, (size_t)nk * mx * mu1 * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dBl, (size_t)nk * mx * ml * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dG, (size_t)nk * ml * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dAp, (size_t)nk * mx * mx * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dD, (size_t)nk * mx * mu1 * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dres, (size_t)nk * sizeof(double));
+    if (e == hipSuccess) e = ws_get((void**)&dst, (size_t)nk * sizeof(int));
+    if (e == hipSuccess) e = ws_get((void**)&drank, (size_t)nk * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
+    a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
+    if (e == hipSuccess) e = m->host.loop ? launch_linearize_loop(a, nb, nj, nullptr) : launch_linearize(a, nb, m->host.tree, m->host.npairs, nullptr);
+    if (e == hipSuccess) e = launch_project_model(nk, mx, mu, ml, dA, dBu, dBl, dG, dAp, dD, dres, drank, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(Ap, dAp, (size_t)nk * mx * mx * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mu > 0) e = hipMemcpy(D, dD, (size_t)nk * mx * mu * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dst, nk * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(res.data(), dres, nk * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("linearize_projected: ") + hipGetErrorString(e));
+    for (int k = 0; k < nk; k++) {
+        if (st[k] <= 0) return fail(CCLQR_ENOCONV, "Newton did not converge at the setpoint of knot " + std::to_string(k));
+        if (!(res[k] < 1e-6)) return fail(CCLQR_ESINGULAR, "the constraint rows of the linear model are inconsistent at knot " + std::to_string(k) + " (G Bl rank-deficient beyond redundancy)");
+    }
+    return CCLQR_OK;
+}
+
 extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const double* zd, int32_t mu, const int32_t* ctrl_joint, const double* Fd,
                                          double h, double* Ap, double* D) {
     if (!m || !zd || !Ap || (mu > 0 && (!ctrl_joint || !D))) return fail(CCLQR_EINVAL, "null argument");
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     if (nk < 0 || mu < 0 || mu > m->nj) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
-    if (!(h > 0.0)) h = 1e-6;
+    if (!(h > 0.0)) return linearize_projected_analytic(m, nk, zd, mu, ctrl_joint, Fd, Ap, D);
     const int nb = m->nb, mx = 12 * nb;
     const size_t nz = 13 * (size_t)nb;
     const int per = 1 + 2 * mx + 2 * mu;            // nominal, +-h in every state error coordinate, +-h in every input
@@ -516,9 +567,7 @@ extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const 
     if (e == hipSuccess) e = ws_get((void**)&dD, (size_t)nk * mx * (size_t)(mu > 0 ? mu : 1) * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dz0, z0.data(), n * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        cclqr_rollout_opts o;
-        o.first_instance = 0; o.pid_state_dev = nullptr; o.pid_state_len = 0;
-        rc = cclqr_rollout_ex(m, c, (int64_t)n, 1, 1, dz0, nullptr, nullptr, 0, nullptr, dzT, dst, &o, nullptr);
+        rc = cclqr_rollout_ex(m, c, (int64_t)n, 1, 1, dz0, nullptr, nullptr, 0, nullptr, dzT, dst, nullptr, nullptr);
     }
     if (rc == CCLQR_OK && e == hipSuccess) {
         const long long work = (long long)nk * (mx + mu) * nb;

@@ -53,6 +53,12 @@ struct LinArgs {
     int* status;             // [nk]
 };
 size_t linearize_lds_bytes(int nb, int tree, int npairs);
+// closed-loop mechanisms (rollout_loop.hip): the model with the multipliers exogenous, and the rank-revealing projection onto (A', D)
+size_t linearize_loop_lds_bytes(int nb, int nj);
+hipError_t launch_linearize_loop(const LinArgs& a, int nb, int nj, hipStream_t stream);
+size_t project_model_lds_bytes(int mx, int mu, int ml);
+hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A, const double* Bu, const double* Bl, const double* G, double* Ap, double* D,
+                                double* res, int* rank, hipStream_t stream);
 hipError_t launch_linearize(const LinArgs& a, int nb, int tree, int npairs, hipStream_t stream);
 
 struct RicArgs {

@@ -51,25 +51,16 @@ HD void axpy9(double sc, const double* A, double* o, bool add) {
     for (int i = 0; i < 9; i++) o[i] = (add ? o[i] : 0.0) + sc * A[i];
 }
 
-// L1: joint t: sensitivities of the constraint force G(z)'lambda* and of the applied input to the poses of both bodies
-HD void ph_lin_joint(int t, int nb, const Lay& Y, int JB, double* L, const LaneRegs& r) {
-    if (t >= nb) return;
-    double* o = L + JB + LJB * t;
+// L1: one joint: sensitivities of the constraint force G(z)'lambda* and of the applied input u to the poses of both bodies, into the joint's
+// scratch o (7 blocks of 9).  r holds the joint's constants; (xa, qa) / (xb, qb) are the parent's / child's pose at the current knot
+// (has_a false: the parent is the origin).  Shared by the tree layout (ph_lin_joint) and the closed-loop layout (cclqr_lin_loop.h).
+HD void lin_joint_core(double* o, const LaneRegs& r, bool has_a, const double* xa, const double* qa, const double* xb, const double* qb, const double* lam, double u) {
     for (int i = 0; i < 63; i++) o[i] = 0.0;
-    const int a = r.parent;
-    const bool has_a = a >= 0;
-    const double X0[3] = {0, 0, 0};
-    const double* xa = has_a ? L + Y.Z + 13 * a : X0;
-    const double* qa = has_a ? L + Y.Z + 13 * a + 3 : QID_;
-    const double* xb = L + Y.Z + 13 * t;
-    const double* qb = xb + 3;
-    const double* lam = L + Y.LAM + 5 * t;
     double mu3[3] = {0, 0, 0}, nu3[3] = {0, 0, 0};
     for (int row = 0; row < 5; row++) {
         bool rot = (r.rotmask >> row) & 1;
         for (int i = 0; i < 3; i++) { double v = r.sel[row][i] * lam[row]; if (rot) nu3[i] += v; else mu3[i] += v; }
     }
-    const double u = L[Y.UJ + t];
     const double f[3] = {r.axis[0] * u, r.axis[1] * u, r.axis[2] * u};
     double mue[3] = {mu3[0], mu3[1], mu3[2]};
     if (r.type == 1) for (int i = 0; i < 3; i++) mue[i] += f[i];   // prismatic input acts like a translational multiplier on F and tau_b
@@ -137,6 +128,15 @@ HD void ph_lin_joint(int t, int nb, const Lay& Y, int JB, double* L, const LaneR
             vblk(M3, 1.0, o + J_PRQB, true);
         }
     }
+}
+
+HD void ph_lin_joint(int t, int nb, const Lay& Y, int JB, double* L, const LaneRegs& r) {
+    if (t >= nb) return;
+    const int a = r.parent;
+    const bool has_a = a >= 0;
+    const double X0[3] = {0, 0, 0};
+    const double* xb = L + Y.Z + 13 * t;
+    lin_joint_core(L + JB + LJB * t, r, has_a, has_a ? L + Y.Z + 13 * a : X0, has_a ? L + Y.Z + 13 * a + 3 : QID_, xb, xb + 3, L + Y.LAM + 5 * t, L[Y.UJ + t]);
 }
 
 struct LinOut {

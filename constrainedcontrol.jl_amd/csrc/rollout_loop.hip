@@ -5,6 +5,7 @@
 // (src/control/lqr.jl:89-139).  Not a throughput kernel: loop mechanisms are small (the reference's only one has five bodies) and
 // the solve is a 5 nj-step pivoted elimination; the chain / tree kernels keep every mechanism without loops.
 #include "cclqr_loop.h"
+#include "cclqr_lin_loop.h"
 #include "cclqr_internal.h"
 #include "cclqr_newton.h"
 
@@ -75,6 +76,41 @@ __device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const
     STAMP(PF_TRI_BWD);
 }
 
+// newton! on the instance held in LDS (S / LAM = guess in, solution out), the rules of the tree kernels: returns the
+// iterations used; *failed = a non-finite residual (the instance has left the integrator's domain) or no convergence in NEWTON_MAXIT
+__device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, bool* failed PROF_ARG) {
+    bool done = false, fail = false;
+    int its = 0;
+    double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);
+    for (int iter = 1; iter <= NEWTON_MAXIT && !done; iter++) {
+        PCOUNT(PF_NEWTON_ITERS);
+        loop_solve(t, Y, L, M PROF_PASS);
+        lp_body_solve(t, Y, L, M);
+        __syncthreads();
+        STAMP(PF_BODY_SOLVE);
+        double alpha = 1.0, normf1 = 0.0;
+        const double nd = sqrt(group_sum<64>(lp_trial(t, Y, L, M, alpha)));
+        __syncthreads();
+        STAMP(PF_TRIAL);
+        for (int ls = 0; ls <= LINE_MAXIT; ls++) {     // halve while ||f|| grows; level LINE_MAXIT is taken as it is
+            normf1 = loop_eval<false>(t, Y, L, r, M, Y.ST, alpha PROF_PASS);
+            if (!(normf1 > normf0) || ls == LINE_MAXIT) break;
+            alpha *= 0.5;
+            lp_trial(t, Y, L, M, alpha);
+            __syncthreads();
+        }
+        lp_accept(t, Y, L, M, alpha);
+        __syncthreads();
+        STAMP(PF_ACCEPT);
+        its = iter;
+        if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
+        if (!(normf1 < 1e300)) { done = true; fail = true; }
+        if (!done) normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);     // Jacobians at the accepted point
+    }
+    *failed = fail || !done;
+    return its;
+}
+
 __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     const int t = threadIdx.x;
@@ -133,34 +169,9 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
         STAMP(PF_FORCES);
         PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
-        bool done = dead, failed = false;
-        int its = 0;
-        double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);
-        for (int iter = 1; iter <= NEWTON_MAXIT && !done; iter++) {
-            PCOUNT(PF_NEWTON_ITERS);
-            loop_solve(t, Y, L, M PROF_PASS);
-            lp_body_solve(t, Y, L, M);
-            __syncthreads();
-            STAMP(PF_BODY_SOLVE);
-            double alpha = 1.0, normf1 = 0.0;
-            const double nd = sqrt(group_sum<64>(lp_trial(t, Y, L, M, alpha)));
-            __syncthreads();
-            STAMP(PF_TRIAL);
-            for (int ls = 0; ls <= LINE_MAXIT; ls++) {     // halve while ||f|| grows; level LINE_MAXIT is taken as it is
-                normf1 = loop_eval<false>(t, Y, L, r, M, Y.ST, alpha PROF_PASS);
-                if (!(normf1 > normf0) || ls == LINE_MAXIT) break;
-                alpha *= 0.5;
-                lp_trial(t, Y, L, M, alpha);
-                __syncthreads();
-            }
-            lp_accept(t, Y, L, M, alpha);
-            __syncthreads();
-            STAMP(PF_ACCEPT);
-            its = iter;
-            if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
-            if (!(normf1 < 1e300)) { done = true; failed = true; }
-            if (!done) normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);     // Jacobians at the accepted point
-        }
+        bool failed = false;
+        const int its = dead ? 0 : loop_newton(t, Y, L, r, M, &failed PROF_PASS);
+        const bool done = true;
         if (!dead) {
             const bool conv = done && !failed;
             if (!conv) bad = true;
@@ -191,6 +202,162 @@ extern "C" int cclqr_prof_read_loop(unsigned long long* out, int reset) {
     return e == hipSuccess ? PF_N : -1;
 }
 #endif
+
+// linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) (lqr.jl:63, lqr_tracking.jl:88) for a closed-loop mechanism: one knot per
+// wavefront -- one converged Newton step at the setpoint, then A, Bu, Bl, G with the multipliers exogenous (cclqr_lin_loop.h).  a.cj = joint
+// indices of the inputs; zd in the caller's body order (the closed-loop tables keep it).
+__global__ __launch_bounds__(64) void linearize_loop_kernel(LinArgs a) {
+    extern __shared__ double lds[];
+    const int t = threadIdx.x, knot = blockIdx.x;
+    const MechDev* M = a.M;
+    const int nb = M->nb, nj = M->nj, nz = 13 * nb, mx = 12 * nb, ml = 5 * nj, mu = a.mu;
+    const Lay Y = make_loop_layout(nb, nj);
+    const int JB = Y.total;
+    double* L = lds;
+    LinOut O;
+    O.A = a.A + (size_t)knot * mx * mx; O.Bu = a.Bu + (size_t)knot * mx * mu; O.Bl = a.Bl + (size_t)knot * mx * ml;
+    O.G = a.G + (size_t)knot * ml * mx; O.mx = mx; O.mu = mu; O.ml = ml;
+    for (int e = t; e < mx * mx; e += 64) O.A[e] = 0.0;
+    for (int e = t; e < mx * mu; e += 64) O.Bu[e] = 0.0;
+    for (int e = t; e < mx * ml; e += 64) O.Bl[e] = 0.0;
+    for (int e = t; e < ml * mx; e += 64) O.G[e] = 0.0;
+    LaneRegs r;
+    loop_load_consts(r, M, t);
+    for (int e = t; e < Y.total + LJB * nj; e += 64) L[e] = 0.0;
+    __syncthreads();
+    for (int e = t; e < nz; e += 64) L[Y.Z + e] = a.zd[(size_t)knot * nz + e];
+    __syncthreads();
+    if (t == 0)
+        for (int i = 0; i < mu; i++) L[Y.UJ + a.cj[i]] += a.Fd ? a.Fd[(size_t)knot * mu + i] : 0.0;
+    __syncthreads();
+    lp_forces(t, Y, L, r, M);
+    lp_knot_jac(t, Y, L, r, M);
+    __syncthreads();
+    lp_force_map(t, Y, L, M);
+    __syncthreads();
+#ifdef CCLQR_PROFILE
+    Prof prof;
+    prof.start();
+#endif
+    bool failed = false;
+    const int its = loop_newton(t, Y, L, r, M, &failed PROF_PASS);
+    loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);      // D_R^-1, N D_R^-1 and the next pose at the converged solution
+    __syncthreads();
+    lp_lin_joint(t, Y, JB, L, r, M);
+    __syncthreads();
+    __threadfence_block();
+    lp_lin_rows_A(t, Y, JB, L, r, M, O);
+    lp_lin_rows_B(t, Y, L, r, M, a.cj, O);
+    if (t == 0 && a.status) a.status[knot] = failed ? -its : its;
+}
+
+// The projected pair of the recursion (lqr.jl:151: D = Bu - Bl/(G Bl) G Bu, and A' = A - Bl/(G Bl) G A likewise) from a linear model
+// whose G Bl may be SINGULAR (closed loops: redundant constraint rows): (G Bl) [X | Y] = G [A | Bu] is consistent, so it is solved by
+// Gauss-Jordan elimination with complete pivoting that stops at the numerical rank -- free components 0, a basic solution; Bl X is the same
+// for every solution because the null space of G Bl is that of the force map G_k'.  One workgroup per knot, the system in LDS.
+// res[knot] = largest |entry| left in the rows that found no pivot, relative to the largest entry of the right-hand side (consistency).
+#define PROJ_THREADS 256
+__global__ __launch_bounds__(PROJ_THREADS) void project_model_kernel(int mx, int mu, int ml, const double* A, const double* Bu, const double* Bl, const double* G,
+                                                                     double* Ap, double* D, double* res, int* rank_out) {
+    extern __shared__ double ps[];
+    __shared__ double red_v[PROJ_THREADS];
+    __shared__ int red_i[PROJ_THREADS];
+    __shared__ int s_pi, s_pj, s_rank;
+    __shared__ double s_first;
+    const int tid = threadIdx.x, knot = blockIdx.x, na = mx + mu, ld = ml + na;
+    A += (size_t)knot * mx * mx; Bu += (size_t)knot * mx * mu; Bl += (size_t)knot * mx * ml; G += (size_t)knot * ml * mx;
+    Ap += (size_t)knot * mx * mx; D += (size_t)knot * mx * mu;
+    double* S = ps;                         // [ml][ld]: G Bl | G A | G Bu
+    double* f = S + (size_t)ml * ld;        // [ml] elimination factors
+    int* rowp = (int*)(f + ml);             // [ml] pivot column of a row (-1: none)
+    int* colu = rowp + ml;                  // [ml] 1: the column has been a pivot column
+    for (int e = tid; e < ml * ld; e += PROJ_THREADS) {
+        const int i = e / ld, j = e - i * ld;
+        double acc = 0.0;
+        for (int k = 0; k < mx; k++) {
+            const double b = j < ml ? Bl[(size_t)k * ml + j] : (j < ml + mx ? A[(size_t)k * mx + (j - ml)] : Bu[(size_t)k * mu + (j - ml - mx)]);
+            acc += G[(size_t)i * mx + k] * b;
+        }
+        S[e] = acc;
+    }
+    for (int e = tid; e < ml; e += PROJ_THREADS) { rowp[e] = -1; colu[e] = 0; }
+    if (tid == 0) s_rank = 0;
+    __syncthreads();
+    double rhs_max = 0.0;
+    for (int e = tid; e < ml * na; e += PROJ_THREADS) { const int i = e / na, j = e - i * na; rhs_max = fmax(rhs_max, fabs(S[i * ld + ml + j])); }
+    red_v[tid] = rhs_max;
+    __syncthreads();
+    for (int o = PROJ_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red_v[tid] = fmax(red_v[tid], red_v[tid + o]); __syncthreads(); }
+    const double rhs_scale = red_v[0];
+    __syncthreads();
+    for (int k = 0; k < ml; k++) {
+        double best = -1.0; int bi = 0;
+        for (int e = tid; e < ml * ml; e += PROJ_THREADS) {
+            const int i = e / ml, j = e - i * ml;
+            if (rowp[i] < 0 && !colu[j]) { const double v = fabs(S[i * ld + j]); if (v > best) { best = v; bi = e; } }
+        }
+        red_v[tid] = best; red_i[tid] = bi;
+        __syncthreads();
+        for (int o = PROJ_THREADS / 2; o > 0; o >>= 1) {
+            if (tid < o && (red_v[tid + o] > red_v[tid] || (red_v[tid + o] == red_v[tid] && red_i[tid + o] < red_i[tid]))) { red_v[tid] = red_v[tid + o]; red_i[tid] = red_i[tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (k == 0) s_first = red_v[0];
+            if (red_v[0] > LOOP_RANK_TOL * s_first && red_v[0] > 0.0) { s_pi = red_i[0] / ml; s_pj = red_i[0] - (red_i[0] / ml) * ml; s_rank = k + 1; }
+            else s_pi = -1;
+        }
+        __syncthreads();
+        if (s_pi < 0) break;
+        const int pi = s_pi, pj = s_pj;
+        const double pinv = 1.0 / S[pi * ld + pj];
+        for (int i = tid; i < ml; i += PROJ_THREADS) f[i] = (i == pi) ? 0.0 : S[i * ld + pj] * pinv;
+        if (tid == 0) { rowp[pi] = pj; colu[pj] = 1; }
+        __syncthreads();
+        for (int e = tid; e < ml * ld; e += PROJ_THREADS) {
+            const int i = e / ld, j = e - i * ld;
+            if (i != pi) S[e] = (j == pj) ? 0.0 : S[e] - f[i] * S[pi * ld + j];
+        }
+        __syncthreads();
+    }
+    // consistency: what is left of the right-hand side in the rows without a pivot
+    double left = 0.0;
+    for (int e = tid; e < ml * na; e += PROJ_THREADS) { const int i = e / na, j = e - i * na; if (rowp[i] < 0) left = fmax(left, fabs(S[i * ld + ml + j])); }
+    red_v[tid] = left;
+    __syncthreads();
+    for (int o = PROJ_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red_v[tid] = fmax(red_v[tid], red_v[tid + o]); __syncthreads(); }
+    if (tid == 0) { if (res) res[knot] = rhs_scale > 0.0 ? red_v[0] / rhs_scale : 0.0; if (rank_out) rank_out[knot] = s_rank; }
+    // X[c][:] = (row with pivot column c)[rhs] / pivot, 0 for free columns;  [A' | D] = [A | Bu] - Bl X
+    for (int e = tid; e < mx * na; e += PROJ_THREADS) {
+        const int i = e / na, j = e - i * na;
+        double acc = j < mx ? A[(size_t)i * mx + j] : Bu[(size_t)i * mu + (j - mx)];
+        for (int rI = 0; rI < ml; rI++) {
+            const int c = rowp[rI];
+            if (c >= 0) acc -= Bl[(size_t)i * ml + c] * (S[rI * ld + ml + j] / S[rI * ld + c]);
+        }
+        if (j < mx) Ap[(size_t)i * mx + j] = acc; else D[(size_t)i * mu + (j - mx)] = acc;
+    }
+}
+
+size_t linearize_loop_lds_bytes(int nb, int nj) { return (size_t)(make_loop_layout(nb, nj).total + LJB * nj) * sizeof(double); }
+hipError_t launch_linearize_loop(const LinArgs& a, int nb, int nj, hipStream_t stream) {
+    if (a.nk <= 0) return hipSuccess;
+    const size_t lds = linearize_loop_lds_bytes(nb, nj);
+    hipError_t e = set_max_dynamic_lds_once((const void*)linearize_loop_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(linearize_loop_kernel, dim3(a.nk), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+size_t project_model_lds_bytes(int mx, int mu, int ml) { return ((size_t)ml * (ml + mx + mu) + ml) * sizeof(double) + 2 * (size_t)ml * sizeof(int) + 16; }
+hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A, const double* Bu, const double* Bl, const double* G, double* Ap, double* D,
+                                double* res, int* rank, hipStream_t stream) {
+    if (nk <= 0) return hipSuccess;
+    const size_t lds = project_model_lds_bytes(mx, mu, ml);
+    hipError_t e = set_max_dynamic_lds_once((const void*)project_model_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(project_model_kernel, dim3(nk), dim3(PROJ_THREADS), lds, stream, mx, mu, ml, A, Bu, Bl, G, Ap, D, res, rank);
+    return hipGetLastError();
+}
 
 size_t loop_lds_bytes(int nb, int nj) { return (size_t)make_loop_layout(nb, nj).total * sizeof(double); }
 

@@ -112,7 +112,7 @@ class LQR(Controller):
         if self.projected:
             # closed loops (examples/lqr_deltabot.jl:47-53): G Bλ of lqr.jl:151 is singular (redundant constraint rows), but the pair the
             # recursion works with -- A' = A - Bλ (G Bλ)^-1 G A, D = Bu - Bλ (G Bλ)^-1 G Bu -- is unique: it is the Jacobian of the
-            # constrained one-step map, taken from the device by central differences, and the recursion runs on it with no multipliers
+            # constrained one-step map, formed analytically on the device (cclqr_linearize_projected), and the recursion runs on it with no multipliers
             mx = 12 * nb
             Ap, D = _capi.linearize_projected(dev, self.zd, self.ctrl_joints, self.Fd)
             self.A, self.Bu, self.Bλ, self.G = Ap[0], D[0], np.zeros((mx, 0)), np.zeros((0, mx))

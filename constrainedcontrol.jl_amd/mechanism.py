@@ -215,7 +215,8 @@ class Mechanism:
         parent = [e.joint.body1.id - 1 for e in self.eqconstraints]
         child = [e.joint.body2.id - 1 for e in self.eqconstraints]
         # closed loops (examples/lqr_deltabot.jl:25-33): more joints than bodies, a body that is the child of two joints, or a
-        # FixedOrientation constraint.  The device rolls them out (rollout_loop.hip); LQR construction on them is out of scope.
+        # FixedOrientation constraint.  The device rolls them out (rollout_loop.hip); LQR / TrackingLQR on them are built from the projected
+        # linear model (cclqr_linearize_projected + the recursion with no multipliers left, lqr.py).
         self.has_loops = ne != nb or sorted(child) != list(range(nb)) or any(e.joint.kind == FIXED_ORIENTATION for e in self.eqconstraints)
         if ne < nb or not set(range(nb)) <= set(child) | {p for p in parent if p >= 0}:
             raise ValueError("every body must hang off at least one joint (Nb=%d, Ne=%d)" % (nb, ne))

@@ -122,10 +122,14 @@ int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t m
                     double *A, double *Bu, double *Bl, double *G);
 
 /* The same linear model with the multipliers eliminated -- A' = A - Bλ (G Bλ)^-1 G A and D = Bu - Bλ (G Bλ)^-1 G Bu, the projected pair the
- * recursion of lqr.jl:151-170 works with -- obtained as central differences (step h in every error coordinate x, v, q~, ω of lqr.jl:92-103
- * and every input; h <= 0: 1e-6) of the DEVICE's own constrained one-step map, one launch of nk (1 + 24 nb + 2 mu) single-step rollouts.
- * Defined for every topology cclqr_mech_create takes, and the only linearisation of closed-loop mechanisms (examples/lqr_deltabot.jl:47-53),
- * where G Bλ is singular but A', D are still unique; feed them to cclqr_riccati with ml = 0.  Ap [nk][mx][mx], D [nk][mx][mu]. Host pointers. */
+ * recursion of lqr.jl:151-170 works with.  Defined for every topology cclqr_mech_create takes, and the only linearisation of closed-loop
+ * mechanisms (examples/lqr_deltabot.jl:47-53), where G Bλ is singular (redundant constraint rows) but A', D are still unique; feed them to
+ * cclqr_riccati with ml = 0.
+ *   h <= 0: ANALYTIC -- the exact Jacobians of the one-step map on the device (linearsystem of lqr.jl:63 with the multipliers exogenous, for
+ *           loops in their own bookkeeping), then G Bλ eliminated with complete pivoting up to its numerical rank;
+ *   h > 0:  central differences (step h in every error coordinate x, v, q~, ω of lqr.jl:92-103 and every input) of the DEVICE's own constrained
+ *           one-step map, one launch of nk (1 + 24 nb + 2 mu) single-step rollouts: an independent cross-check of the analytic form.
+ * Ap [nk][mx][mx], D [nk][mx][mu]. Host pointers. */
 int cclqr_linearize_projected(const cclqr_mech *m, int32_t nk, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
                               double h, double *Ap, double *D);
 

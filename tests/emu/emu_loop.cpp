@@ -5,6 +5,7 @@
 // GPU.  The LDS image has exactly the kernel's size (an out-of-range offset is an out-of-bounds access for a sanitizer build).
 #include "../../constrainedcontrol.jl_amd/csrc/cclqr_tables.h"
 #include "../../constrainedcontrol.jl_amd/csrc/cclqr_loop.h"
+#include "../../constrainedcontrol.jl_amd/csrc/cclqr_lin_loop.h"
 #include <math.h>
 #include <string>
 #include <vector>
@@ -142,5 +143,69 @@ extern "C" int emu_loop_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc
         if (lam) for (int e = 0; e < 5 * nj; e++) lam[inst * 5 * nj + e] = L[Y.LAM + e];
         if (status) status[inst] = bad ? -worst : worst;
     }
+    return CCLQR_OK;
+}
+
+
+// linearsystem on the closed-loop layout (csrc/cclqr_lin_loop.h) in the phase order of linearize_loop_kernel (csrc/rollout_loop.hip): one
+// converged Newton step at the setpoint, then A, Bu, Bl, G with the multipliers exogenous (row major, caller's body / joint order).
+// force_loop != 0 sends a TREE through the closed-loop tables too, so that the result can be compared with the tree linearisation.
+extern "C" int emu_loop_linearize(const cclqr_mech_desc* md, int force_loop, const double* zd, int mu, const int32_t* ctrl_joint, const double* Fd,
+                                  double* A, double* Bu, double* Bl, double* G, int* status) {
+    cclqr_mech m;
+    std::string err;
+    int rc = force_loop ? build_loop_tables(md, &m, err) : build_mech_tables(md, &m, err);
+    if (rc) return rc;
+    if (!m.host.loop) return CCLQR_EUNSUPPORTED;
+    const MechDev* M = &m.host;
+    const int nb = M->nb, nj = M->nj, nz = 13 * nb, mx = 12 * nb, ml = 5 * nj;
+    LoopInst I;
+    I.M = M;
+    I.Y = make_loop_layout(nb, nj);
+    const int JB = I.Y.total;
+    I.lds.assign(I.Y.total + LJB * nj, 0.0);
+    I.L = I.lds.data();
+    I.r.resize(64);
+    const Lay& Y = I.Y;
+    double* L = I.L;
+    for (int t = 0; t < 64; t++) loop_load_consts(I.r[t], M, t);
+    for (int e = 0; e < nz; e++) L[Y.Z + e] = zd[e];
+    std::vector<int> cj(mu > 0 ? mu : 1, 0);
+    for (int i = 0; i < mu; i++) { cj[i] = ctrl_joint[i]; L[Y.UJ + cj[i]] += Fd ? Fd[i] : 0.0; }
+    for (int t = 0; t < 64; t++) lp_forces(t, Y, L, I.r[t], M);
+    for (int t = 0; t < 64; t++) lp_knot_jac(t, Y, L, I.r[t], M);
+    for (int t = 0; t < 64; t++) lp_force_map(t, Y, L, M);
+    bool done = false, failed = false;
+    int its = 0;
+    double normf0 = loop_eval<true>(I, Y.S, 0.0);
+    for (int iter = 1; iter <= 100 && !done; iter++) {
+        loop_solve(I);
+        for (int t = 0; t < 64; t++) lp_body_solve(t, Y, L, M);
+        double alpha = 1.0, normf1 = 0.0, pd = 0.0;
+        for (int t = 0; t < 64; t++) pd += lp_trial(t, Y, L, M, alpha);
+        const double nd = sqrt(pd);
+        for (int ls = 0; ls <= 10; ls++) {
+            normf1 = loop_eval<false>(I, Y.ST, alpha);
+            if (!(normf1 > normf0) || ls == 10) break;
+            alpha *= 0.5;
+            for (int t = 0; t < 64; t++) lp_trial(t, Y, L, M, alpha);
+        }
+        for (int t = 0; t < 64; t++) lp_accept(t, Y, L, M, alpha);
+        its = iter;
+        if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
+        if (!(normf1 < 1e300)) { done = true; failed = true; }
+        if (!done) normf0 = loop_eval<true>(I, Y.S, 0.0);
+    }
+    loop_eval<true>(I, Y.S, 0.0);        // D_R^-1, N D_R^-1 and the next pose at the converged solution
+    if (status) *status = (done && !failed) ? its : -its;
+    for (int e = 0; e < mx * mx; e++) A[e] = 0.0;
+    for (int e = 0; e < mx * mu; e++) Bu[e] = 0.0;
+    for (int e = 0; e < mx * ml; e++) Bl[e] = 0.0;
+    for (int e = 0; e < ml * mx; e++) G[e] = 0.0;
+    LinOut O;
+    O.A = A; O.Bu = Bu; O.Bl = Bl; O.G = G; O.mx = mx; O.mu = mu; O.ml = ml;
+    for (int t = 0; t < 64; t++) lp_lin_joint(t, Y, JB, L, I.r[t], M);
+    for (int t = 0; t < 64; t++) lp_lin_rows_A(t, Y, JB, L, I.r[t], M, O);
+    for (int t = 0; t < 64; t++) lp_lin_rows_B(t, Y, L, I.r[t], M, cj.data(), O);
     return CCLQR_OK;
 }

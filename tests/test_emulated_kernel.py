@@ -356,3 +356,69 @@ def test_emulated_closed_loop_deltabot(cclqr, orc, emu):
     zT, traj, st = emu_loop_rollout(emu, orc, t, fb, z0, steps)
     ref, zref = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], K[0], zd[0], steps)
     assert st[0] > 0 and np.abs(traj[0] - ref).max() < 1e-9 and np.abs(zT[0] - zref).max() < 1e-9
+
+
+def emu_loop_linearize(emu, orc, t, zd, cj, Fd, force_loop):
+    m = orc.mech_desc(t)
+    nb, nj, mu = t.nb, t.ne, len(cj)
+    mx, ml = 12 * nb, 5 * nj
+    A, Bu, Bl, G = np.zeros((mx, mx)), np.zeros((mx, max(mu, 1))), np.zeros((mx, ml)), np.zeros((ml, mx))
+    cja = np.ascontiguousarray(cj, dtype=np.int32)
+    Fd = np.ascontiguousarray(Fd, dtype=np.float64)
+    zd = np.ascontiguousarray(zd, dtype=np.float64)
+    st = C.c_int(0)
+    rc = emu.emu_loop_linearize(C.byref(m.desc), C.c_int(1 if force_loop else 0), zd.ctypes.data_as(dp), C.c_int(mu), cja.ctypes.data_as(C.POINTER(C.c_int32)),
+                                Fd.ctypes.data_as(dp), A.ctypes.data_as(dp), Bu.ctypes.data_as(dp), Bl.ctypes.data_as(dp), G.ctypes.data_as(dp), C.byref(st))
+    assert rc == 0 and st.value > 0, (rc, st.value)
+    return A, Bu[:, :mu].copy() if mu else Bu[:, :0], Bl, G
+
+
+def projected_pair(A, Bu, Bl, G):
+    """A' = A - Bl X, D = Bu - Bl Y with (G Bl) [X | Y] = G [A | Bu] in the minimum-norm least-squares sense (a loop makes G Bl singular;
+    Bl X is the same for every solution)"""
+    XY = np.linalg.lstsq(G @ Bl, G @ np.concatenate([A, Bu], axis=1), rcond=1e-11)[0]
+    P = np.concatenate([A, Bu], axis=1) - Bl @ XY
+    return P[:, :A.shape[1]], P[:, A.shape[1]:]
+
+
+def test_emulated_loop_linearisation(cclqr, orc, emu):
+    """csrc/cclqr_lin_loop.h (linearsystem on the closed-loop layout, lqr.jl:63 for examples/lqr_deltabot.jl:47-53), run by the emulator:
+      * TREES sent through the closed-loop tables (a three-link cartpole off its equilibrium with a feed-forward input, the 7-body Sawyer arm with dense inertias, at
+        moving setpoints): A, Bu, Bl, G equal the oracle's analytic tree linearisation to 1e-10 -- same model, other bookkeeping;
+      * the deltabot at its holding torque: the projected pair built from (A, Bu, Bl, G) equals central differences of the oracle's dense-KKT
+        step map (oracle/loops.py) to the accuracy of those differences, G [A' | D] = 0, and rank(G Bl) = 28 of 35."""
+    import json
+    import os
+    from oracle import loops
+    ex = cclqr.examples.cartpole_n(3)
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(5)
+    zd = cclqr.examples.cartpole_states(3, [0.13], np.array([[0.4, -0.3, 0.25]]))[0]
+    Fd = np.array([1.7])
+    Ao, Buo, Blo, Go = orc.linearize(t, zd, [0], Fd)
+    A, Bu, Bl, G = emu_loop_linearize(emu, orc, t, zd, [0], Fd, force_loop=True)
+    for X, Xo, name in ((A, Ao, "A"), (Bu, Buo, "Bu"), (Bl, Blo, "Bl"), (G, Go, "G")):
+        assert np.abs(X - Xo).max() < 1e-10 * max(1.0, np.abs(Xo).max()), (name, np.abs(X - Xo).max())
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    exs = cclqr.examples.sawyer(tab)
+    ts = exs["mech"].tables()
+    zs = cclqr.joint_position_states(exs["mech"], rng.uniform(-0.6, 0.6, (1, 7)))[0]
+    cj = [0, 2, 5]
+    Fs = np.array([0.3, -0.2, 0.1])
+    Ao, Buo, Blo, Go = orc.linearize(ts, zs, cj, Fs)
+    A, Bu, Bl, G = emu_loop_linearize(emu, orc, ts, zs, cj, Fs, force_loop=True)
+    for X, Xo, name in ((A, Ao, "A"), (Bu, Buo, "Bu"), (Bl, Blo, "Bl"), (G, Go, "G")):
+        assert np.abs(X - Xo).max() < 1e-10 * max(1.0, np.abs(Xo).max()), (name, np.abs(X - Xo).max())
+    # the deltabot
+    exd = cclqr.examples.deltabot()
+    mech = exd["mech"]
+    td = mech.tables()
+    cjd = [mech.joint_index(e) for e in exd["eqcids"]]
+    lm, z, u = loops.deltabot()
+    A, Bu, Bl, G = emu_loop_linearize(emu, orc, td, mech.state(), cjd, exd["Fd"].reshape(-1), force_loop=False)
+    sv = np.linalg.svd(G @ Bl, compute_uv=False)
+    assert int((sv > 1e-9 * sv[0]).sum()) == 28
+    Ap, D = projected_pair(A, Bu, Bl, G)
+    assert np.abs(G @ Ap).max() < 1e-8 and np.abs(G @ D).max() < 1e-8
+    Apo, Do = loops.projected_linear_model(lm, z, u, cjd)
+    assert np.abs(Ap - Apo).max() < 2e-6 * max(1.0, np.abs(Apo).max()) and np.abs(D - Do).max() < 2e-6 * max(1.0, np.abs(Do).max())

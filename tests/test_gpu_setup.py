@@ -246,10 +246,12 @@ def test_sawyer_config4_pipeline(cclqr, orc):
 def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
     """examples/lqr_deltabot.jl:47-53 end to end.  The redundant constraint rows of a closed loop make G Bλ (lqr.jl:151) singular, but the
     pair the recursion works with -- A' = A - Bλ (G Bλ)^-1 G A, D = Bu - Bλ (G Bλ)^-1 G Bu -- is the Jacobian of the constrained one-step
-    map and stays unique; `cclqr_linearize_projected` takes it from the device by central differences.
-    (i) on a TREE it equals the projection of the analytic `cclqr_linearize` output to 1e-7 (relative 1e-9);
-    (ii) on the deltabot it equals the same differences of the ORACLE's dense-KKT step (oracle/loops.py) to 1e-6, and the gains of the
-    recursion (lqr.jl:141-184 with no multipliers left) equal the oracle's to 1e-6 relative;
+    map and stays unique; `cclqr_linearize_projected` forms it on the device ANALYTICALLY (h <= 0: exact Jacobians in the loop's own
+    bookkeeping, G Bλ eliminated with complete pivoting up to its numerical rank) or, as a cross-check, by central differences (h > 0).
+    (i) on a TREE the analytic pair equals the numpy projection of the `cclqr_linearize` output to 1e-9 and the differences to 1e-7;
+    (ii) on the deltabot it equals central differences (h = 1e-5) of the ORACLE's dense-KKT step (oracle/loops.py) to 2e-8 at |A'| = 200
+    (the device's own differences: 1e-6), and the gains of the recursion (lqr.jl:141-184 with no multipliers left)
+    equal the oracle's to 1e-7 relative;
     (iii) the LQR holds the mechanism: from a state 0.13 off the setpoint the closed loop returns to it, the open loop falls."""
     from oracle import loops
     capi = cclqr._capi
@@ -260,7 +262,9 @@ def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
     A, Bu, Bl, G = (M[0] for M in capi.linearize(mh, zd[None], [0], np.zeros((1, 1))))
     AD = np.hstack([A, Bu]) - Bl @ np.linalg.solve(G @ Bl, G @ np.hstack([A, Bu]))
     Ap, D = capi.linearize_projected(mh, zd[None], [0], np.zeros((1, 1)))
-    assert np.abs(Ap[0] - AD[:, :48]).max() < 1e-7 and np.abs(D[0] - AD[:, 48:]).max() < 1e-9 and np.abs(AD).max() > 100
+    assert np.abs(Ap[0] - AD[:, :48]).max() < 1e-9 and np.abs(D[0] - AD[:, 48:]).max() < 1e-11 and np.abs(AD).max() > 100
+    Af, Df = capi.linearize_projected(mh, zd[None], [0], np.zeros((1, 1)), h=1e-6)          # the differences of the device's step map
+    assert np.abs(Af[0] - AD[:, :48]).max() < 1e-7 and np.abs(Df[0] - AD[:, 48:]).max() < 1e-9
     # deltabot
     ex = cclqr.examples.deltabot()
     mech = ex["mech"]
@@ -271,10 +275,12 @@ def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
                    Fτd=[[ex["Fd"][0]], [ex["Fd"][1]]])
     assert lq.projected and lq.K.shape == (999, 2, 60) and lq.G.shape == (0, 60)
     lm, z, u = loops.deltabot()
-    Ao, Do = loops.projected_linear_model(lm, z, u, [0, 1])
-    assert np.abs(lq.A - Ao).max() < 1e-6 and np.abs(lq.Bu - Do).max() < 1e-6 and np.abs(Ao).max() > 1
+    Ao, Do = loops.projected_linear_model(lm, z, u, [0, 1], h=1e-5)
+    assert np.abs(lq.A - Ao).max() < 2e-8 and np.abs(lq.Bu - Do).max() < 2e-8 and np.abs(Ao).max() > 100
+    Afd, Dfd = capi.linearize_projected(mech._cclqr_handle, z0[None], lq.ctrl_joints, ex["Fd"].reshape(1, 2), h=1e-6)
+    assert np.abs(Afd[0] - lq.A).max() < 1e-6 and np.abs(Dfd[0] - lq.Bu).max() < 1e-6
     Ko, kbo = orc.riccati(Ao, Do, np.zeros((60, 0)), np.zeros((0, 60)), lq.Q, lq.R, 1000)
-    assert int(lq.kbreak) == kbo and np.abs(lq.K - Ko).max() < 1e-6 * np.abs(Ko).max()
+    assert int(lq.kbreak) == kbo and np.abs(lq.K - Ko).max() < 1e-7 * np.abs(Ko).max()
     # closed loop vs open loop from a consistent perturbed state (eight steps with 90 % of the holding torque)
     weak = capi.CtrlHandle(mech._cclqr_handle, lq.ctrl_joints, K=None, N=0, zd=z0[None], Fd=0.9 * ex["Fd"].reshape(1, 2))
     zp, _, st = capi.rollout(mech._cclqr_handle, weak, z0[None], 8)
@@ -288,7 +294,7 @@ def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
 
 def test_tracking_lqr_on_the_deltabot(cclqr, orc):
     """TrackingLQR (lqr_tracking.jl:17-43) on a closed-loop mechanism: per-knot projected models from the device (cclqr_linearize_projected,
-    119 knots x 125 single-step rollouts in one launch), the time-varying recursion on them (cclqr_riccati_tv, no multipliers left).
+    119 knots linearised analytically in one launch), the time-varying recursion on them (cclqr_riccati_tv, no multipliers left).
     The model of a mid-trajectory knot equals the oracle's dense-KKT differences about the same (state, input); the gains equal a numpy
     restatement of the recursion (lqr_tracking.jl:73-122) on the same models; and the controller pulls a perturbed start back onto the
     recorded trajectory where the replayed inputs alone drift away."""
@@ -309,9 +315,9 @@ def test_tracking_lqr_on_the_deltabot(cclqr, orc):
     lm, z, u = loops.deltabot()
     k = 40
     uk = np.zeros(7); uk[:2] = U[k]
-    Ao, Do = loops.projected_linear_model(lm, s0.z[0, k].copy(), uk, [0, 1])
+    Ao, Do = loops.projected_linear_model(lm, s0.z[0, k].copy(), uk, [0, 1], h=1e-5)
     Ap, D = capi.linearize_projected(mech._cclqr_handle, s0.z[0, k:k + 1], tl.ctrl_joints, U[k:k + 1])
-    assert np.abs(Ap[0] - Ao).max() < 1e-6 and np.abs(D[0] - Do).max() < 1e-6
+    assert np.abs(Ap[0] - Ao).max() < 5e-8 and np.abs(D[0] - Do).max() < 5e-8
     # the recursion on the device's models, restated in numpy (ml = 0: D = Bu, lqr.jl:151-176 with the knot's matrices)
     Aall, Dall = capi.linearize_projected(mech._cclqr_handle, s0.z[0, :N - 1], tl.ctrl_joints, U[:N - 1])
     P, Kref = tl.Q.copy(), np.zeros_like(tl.K)
