@@ -36,6 +36,9 @@ UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAX
            # rollout_chain.hip line search: `mine` is uniform over a 32-lane group and `other` is the partner group's `mine`, so `mine != other`
            # has the same value in both groups of the wavefront
            r"^mine != other$", r"^int i = 0; i < \d+; i\+\+$",        # (compile-time unrolled component loops)
+           # rollout_loop.hip project_model_kernel: tree reductions over a fixed workgroup size, pivot steps up to the kernel argument ml, and the
+           # stop on s_pi -- a __shared__ word written by thread 0 and read by everyone behind a barrier
+           r"^int o = PROJ_THREADS / 2; o > 0; o >>= 1$", r"^int k = 0; k < ml", r"^s_pi < 0$",
            # rollout_loop.hip loop_solve: mr = 5 M->nj; `rank` and the pivot it stops on come out of wave_max_key (v_readlane 63: the same in every lane)
            r"^int k = 0; k < mr", r"^int k = rank - 1; k >= 0", r"^it <= ", r"^nsteps", r"^steps", r"^mode", r"^int kk = ", r"^rank < ", r"^int e = t; e < Y\.total"]
 
@@ -132,7 +135,7 @@ def test_device_loops_have_one_exit():
             kws = enclosing_headers(txt, m.start())
             if kws and kws[0][0] == "switch":
                 continue
-            assert re.search(r"if \(!__any\(", stmt) or f == "rollout_loop.hip" and re.search(r"best > |normf1 > normf0", stmt), \
+            assert re.search(r"if \(!__any\(", stmt) or f == "rollout_loop.hip" and re.search(r"best > |normf1 > normf0|s_pi < 0", stmt), \
                 "%s:%d: `%s` -- a second loop exit must be a wavefront vote" % (f, line, stmt)
 
 
