@@ -388,18 +388,20 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
                                double* A, double* Bu, double* Bl, double* G) {
     if (!m || !zd || !A || !Bl || !G || (mu > 0 && (!ctrl_joint || !Bu))) return fail(CCLQR_EINVAL, "null argument");
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
-    if (m->host.loop) return fail(CCLQR_EUNSUPPORTED, "linearsystem of a closed-loop mechanism divides by the singular G*Bl (lqr.jl:151): use cclqr_linearize_projected");
-    if (nk < 0 || mu < 0 || mu > m->nb) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
+    // a closed-loop mechanism has its own tables (bodies and joints in the caller's order, ml = 5 rows per joint incl. the two null rows of a
+    // FixedOrientation); its G*Bl is singular, so the recursion takes the projected pair of cclqr_linearize_projected, not these four
+    const bool loop = m->host.loop != 0;
+    const int nb = m->nb, nj = loop ? m->nj : nb;
+    if (nk < 0 || mu < 0 || mu > nj) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
-    const int nb = m->nb;
-    const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nb;
-    if (linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    const size_t nz = 13 * (size_t)nb, mx = 12 * (size_t)nb, ml = 5 * (size_t)nj;
+    if (!loop && linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     LinArgs a;
     memset(&a, 0, sizeof(a));
     a.M = m->dev; a.nk = nk; a.mu = mu;
     for (int i = 0; i < mu; i++) {
-        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nb) return fail(CCLQR_EINVAL, "controlled joint out of range");
-        a.cj[i] = m->link_of_joint[ctrl_joint[i]];
+        if (ctrl_joint[i] < 0 || ctrl_joint[i] >= nj) return fail(CCLQR_EINVAL, "controlled joint out of range");
+        a.cj[i] = loop ? ctrl_joint[i] : m->link_of_joint[ctrl_joint[i]];
     }
     double *dzd = nullptr, *dFd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr;
     int* dst = nullptr;
@@ -415,7 +417,7 @@ extern "C" int cclqr_linearize(const cclqr_mech* m, int32_t nk, const double* zd
     if (e == hipSuccess) e = hipMemcpy(dzd, zd, nk * nz * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && dFd) e = hipMemcpy(dFd, Fd, (size_t)nk * mu * sizeof(double), hipMemcpyHostToDevice);
     a.zd = dzd; a.Fd = dFd; a.A = dA; a.Bu = dBu; a.Bl = dBl; a.G = dG; a.status = dst;
-    if (e == hipSuccess) e = launch_linearize(a, nb, m->host.tree, m->host.npairs, nullptr);
+    if (e == hipSuccess) e = loop ? launch_linearize_loop(a, nb, nj, nullptr) : launch_linearize(a, nb, m->host.tree, m->host.npairs, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(A, dA, nk * mx * mx * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mu > 0) e = hipMemcpy(Bu, dBu, nk * mx * mu * sizeof(double), hipMemcpyDeviceToHost);

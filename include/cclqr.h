@@ -42,8 +42,9 @@ extern "C" {
  * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
  * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
  * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (plain LQR law, one instance per wavefront, multipliers lam
- * [n_inst][5*ne]); LQR / TrackingLQR construction goes through cclqr_linearize_projected + cclqr_riccati / cclqr_riccati_tv with ml = 0
- * (cclqr_linearize / cclqr_riccati_tracking, which divide by the singular G*Bλ, return CCLQR_EUNSUPPORTED for them). */
+ * [n_inst][5*ne]); cclqr_linearize returns their A, Bu, Bλ, G (ml = 5*ne rows, a FixedOrientation contributing two null rows), but G*Bλ
+ * is singular for a loop, so LQR / TrackingLQR construction goes through cclqr_linearize_projected + cclqr_riccati / cclqr_riccati_tv with
+ * ml = 0 (cclqr_riccati_tracking, which divides by G*Bλ at every knot, returns CCLQR_EUNSUPPORTED for them). */
 typedef struct {
     int32_t nb, ne;
     double dt, g;          /* mechanism.Δt (lqr.jl:65), gravity along z */
@@ -117,7 +118,7 @@ int cclqr_ctrl_create_lqr_batch(const cclqr_mech *m, int32_t n_ctrl, const doubl
 
 /* linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) -- call sites lqr.jl:63, lqr_tracking.jl:88.
  * Batched over nk knots (nk = 1 for LQR, N-1 for TrackingLQR).  Host pointers.
- * zd [nk][nb][13], Fd [nk][mu]; outputs A [nk][mx][mx], Bu [nk][mx][mu], Bl [nk][mx][ml], G [nk][ml][mx]. */
+ * zd [nk][nb][13], Fd [nk][mu]; outputs A [nk][mx][mx], Bu [nk][mx][mu], Bl [nk][mx][ml], G [nk][ml][mx], ml = 5*ne. */
 int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t mu, const int32_t *ctrl_joint, const double *Fd,
                     double *A, double *Bu, double *Bl, double *G);
 

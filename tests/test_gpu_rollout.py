@@ -313,8 +313,9 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     """examples/lqr_deltabot.jl:25-53 through the C-ABI (`rollout_loop_kernel`, csrc/rollout_loop.hip): 33 constraint rows on 30 body
     coordinates.  (i) the reference's own number: Fτd = +-6.7879484 on the platform joints holds the script's pose at rest; (ii) with
     80 % of it, open loop and with a feedback law u = Fτd - K dz on top, every instance's trajectory equals the oracle's dense-KKT
-    minimum-norm solution (oracle/loops.py) to 1e-9; (iii) the batch is bitwise independent of the instance's position; (iv) LQR
-    construction on the loop mechanism is refused loudly, not approximated"""
+    minimum-norm solution (oracle/loops.py) to 1e-9; (iii) the batch is bitwise independent of the instance's position; (iv) linearsystem
+    on the loop mechanism returns A, Bu, Bλ, G with rank(G Bλ) = 28 of 35 -- the reference's own recursion form is refused on it
+    (CCLQR_ESINGULAR), the projected pair is what LQR construction uses"""
     from oracle import loops
     from test_emulated_kernel import loop_feedback_reference
     capi = cclqr._capi
@@ -348,9 +349,19 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     one = capi.CtrlHandle(mech, cj, K=K[3], N=0, zd=zd, Fd=Fd[3])
     zT1, traj1, _ = capi.rollout(mech, one, z0[None], steps, record=True)
     assert np.array_equal(zT1[0], zT[3]) and np.array_equal(traj1[0], traj[3])
+    # linearsystem of the loop mechanism: A, Bu, Bλ, G with the multipliers exogenous come out (35 constraint rows, two of them the
+    # FixedOrientation's null rows), G Bλ has rank 28, and eliminating λ in numpy gives the pair cclqr_linearize_projected forms on the device
+    A, Bu, Bl, G = (M[0] for M in capi.linearize(mech, zd, cj, Fd[3].reshape(1, -1)))
+    assert G.shape == (35, 60) and Bl.shape == (60, 35)
+    sv = np.linalg.svd(G @ Bl, compute_uv=False)
+    assert int((sv > 1e-9 * sv[0]).sum()) == 28
+    XY = np.linalg.lstsq(G @ Bl, G @ np.hstack([A, Bu]), rcond=1e-11)[0]
+    AD = np.hstack([A, Bu]) - Bl @ XY
+    Ap, D = capi.linearize_projected(mech, zd, cj, Fd[3].reshape(1, -1))
+    assert np.abs(Ap[0] - AD[:, :60]).max() < 1e-9 * np.abs(AD).max() and np.abs(D[0] - AD[:, 60:]).max() < 1e-9 * np.abs(AD).max()
     with pytest.raises(capi.CclqrError) as e:
-        capi.linearize(mech, zd, cj)          # Bλ and G separately: not for redundant constraint rows (cclqr_linearize_projected is)
-    assert e.value.code == -5
+        capi.riccati(A, Bu, Bl, G, np.eye(60) * 0.01, np.eye(len(cj)) * 0.01, 20)      # the reference's own form divides by the singular G Bλ (lqr.jl:151)
+    assert e.value.code == capi.ESINGULAR
 
 
 
