@@ -73,6 +73,43 @@ def test_cfg3_chain16_8192_shard_equivalence(cclqr, orc):
     assert np.abs(zo - zT[[0, 8191]]).max() < 1e-9
 
 
+def test_headline_workload_every_instance_over_the_full_horizon(cclqr, orc):
+    """The bench workload itself, whole: 8192 instances of the 17-body chain regulated about the hanging equilibrium, 1000 steps -- EVERY
+    instance's final state against the oracle's (16 host threads, ~25 s).  Tolerance: north_star's "fp64 state error < 1e-8"; what is
+    measured (printed with -s) sits two orders below it.  The final state carries whatever 1000 closed-loop steps accumulated."""
+    import os
+    capi = cclqr._capi
+    n_links, n, steps = 16, 8192, 1000
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain16_hanging_cfg3.npz"))
+    K = np.tile(g["K_first"][None], (999, 1, 1))
+    rng = np.random.default_rng(0)
+    phi = rng.uniform(-0.2, 0.2, (n, n_links))
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, n), phi)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=1000, zd=zd)
+    zT, _, st = capi.rollout(mech, ctrl, z0, steps)
+    assert (st > 0).all()
+    zo, _, sto = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=1000, zd=zd), z0, steps, nthreads=16)
+    assert (sto > 0).all()
+    err = np.abs(zT - zo).reshape(n, -1).max(axis=1)
+    print("headline workload, 8192 x 1000 steps: max |state - oracle| = %.3g (median over instances %.3g); the controller has moved the state by %.3g"
+          % (err.max(), np.median(err), np.abs(zT - z0).max()))
+    assert err.max() < 1e-8
+    assert np.abs(zT - z0).max() > 0.1        # (not a comparison of two things that did nothing)
+    # the measured-error Newton option (cclqr_rollout_opts.newton_mode = 1, stop on ||f|| < 1e-12 alone) against the same oracle run: reported
+    # next to the exact rule's own distance from the oracle -- both are round-off amplified by 1000 closed-loop steps
+    zT1, _, st1 = capi.rollout(mech, ctrl, z0, steps, newton_mode=1, newton_eps_alone=1e-12)
+    assert (st1 > 0).all()
+    err1 = np.abs(zT1 - zo).reshape(n, -1).max(axis=1)
+    print("  newton_mode = 1 (1e-12): max |state - oracle| = %.3g (median %.3g); max |mode 1 - exact rule| on the device = %.3g"
+          % (err1.max(), np.median(err1), np.abs(zT1 - zT).max()))
+    assert err1.max() < 1e-8
+
+
 def test_ragged_and_empty_batches(cclqr):
     capi = cclqr._capi
     ex = cclqr.examples.cartpole_n(1)
