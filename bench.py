@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--sim-steps", type=int, default=1000)
     ap.add_argument("--no-record", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (the counter passes of tools/profile_round.sh: counters serialise every dispatch)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline sample (0 = auto)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="launches per rollout (trajectory collected chunk by chunk); 0 = 1 on one GPU, 8 on several")
@@ -267,7 +268,7 @@ def main():
                                    "HBM carries only the recorded trajectory (traffic < algorithmic bytes: state never leaves the chip)"}
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline(pkg, t, lqr, z0, T))
-    if world == 1:
+    if world == 1 and not args.no_extra:
         out["extra"] = extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args)
         if record and chunks == 1:
             try:
