@@ -36,8 +36,8 @@ struct Prof {
 template <int N>
 __device__ __forceinline__ double dpp_row_ror(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // sum over the G lanes of a group, result in every lane of the group: rotate-and-add inside each 16-lane row (DPP), then
@@ -45,8 +45,8 @@ __device__ __forceinline__ double dpp_row_ror(double v) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int G>
