@@ -536,8 +536,12 @@ HD bool tri_step(TriCur& K, int i, const double* L, double* tg, double* zy, int*
 #pragma unroll
     for (int r = 0; r < 5; r++) zy[r] = L[K.oRhs + r];
     const bool mstep = i == K.imerge;          // both fronts fold into the middle link now: this one's share goes to the scratch block
+    // (loaded unconditionally and then selected: a load inside the conditional becomes five separately EXEC-masked reads)
+    double tl[5];
 #pragma unroll
-    for (int r = 0; r < 5; r++) tg[r] = mstep ? 0.0 : L[K.oTgt + r];
+    for (int r = 0; r < 5; r++) tl[r] = L[K.oTgt + r];
+#pragma unroll
+    for (int r = 0; r < 5; r++) tg[r] = mstep ? 0.0 : tl[r];
 #pragma unroll
     for (int e = 0; e < 25; e++) sql[e] = L[K.oQL + e];
     lu5_factor(lu);
@@ -720,7 +724,7 @@ HD void cr_back(int t, int cs, int n, int st, const Lay& Y, double* L, bool skip
     const bool has_n = idx + 1 < n;
     double dp[5], dn[5];
 #pragma unroll
-    for (int cI = 0; cI < 5; cI++) { dp[cI] = L[Y.DL + 5 * p + cI]; dn[cI] = has_n ? L[Y.DL + 5 * nx + cI] : 0.0; }
+    for (int cI = 0; cI < 5; cI++) { dp[cI] = L[Y.DL + 5 * p + cI]; const double dnx = L[Y.DL + 5 * nx + cI]; dn[cI] = has_n ? dnx : 0.0; }   // nx <= one link past the chain: inside the image
     const int oZm = Y.SJP + 25 * l, oZp = has_n ? Y.SPJ + 25 * (l + 1) : oZm;
     double out[(5 + W - 1) / W];
 #pragma unroll
