@@ -309,6 +309,28 @@ def test_chain_rollout_kernel_resources(tmp_path):
             assert k["sgpr_spill"] <= 8, (name, k)
 
 
+def test_headline_kernel_instruction_budget(tmp_path):
+    """ISA-level regressions of the headline kernel rollout_chain_kernel<32, 17, 0, false> that cost time without changing a result (round 3 found
+    two by reading the assembly): every DPP shift must be a lone v_mov_b32_dpp with bound_ctrl -- without it the compiler zero-initialises the
+    destination first (265 extra v_mov_b32) --, and an LDS operand of a lane-conditional select must not come back as per-element EXEC-masked
+    loads.  Bounds = today's counts + a margin; a failure here means: read the block that grew."""
+    import subprocess
+    asm = str(tmp_path / "rollout_chain.s")
+    src = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc", "rollout_chain.hip")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=fast", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", asm, src],
+                          stderr=subprocess.DEVNULL)
+    lines = open(asm).read().splitlines()
+    start = [i for i, l in enumerate(lines) if l.startswith("_ZN5cclqr20rollout_chain_kernelILi32ELi17ELi0ELb0EEEvNS_11RolloutArgsE:")][0]
+    end = [i for i in range(start, len(lines)) if "s_endpgm" in lines[i]][0]
+    ops = [l.split()[0] for l in (x.strip() for x in lines[start:end]) if l and not l.startswith((";", ".")) and not l.endswith(":")]
+    count = lambda prefix: sum(o.startswith(prefix) for o in ops)
+    assert len(ops) <= 10800, len(ops)                                   # 10 648 today (10 941 before the two fixes)
+    assert count("v_mov_b32_e32") <= 200, count("v_mov_b32_e32")         # 152 today (417 with zero-initialised DPP destinations)
+    dpp = [x.strip() for x in lines[start:end] if "v_mov_b32_dpp" in x]
+    assert dpp and all("bound_ctrl" in x for x in dpp)
+    assert count("s_and_saveexec_b64") + count("s_or_saveexec_b64") <= 135      # 126 today
+
+
 def test_linearize_and_riccati_kernel_resources(tmp_path):
     """csrc/linearize.hip and csrc/riccati.hip: no scratch memory and no vector-register spill in any kernel; the scalar spills the
     compiler makes today (to VGPR lanes, never to memory) are recorded as upper bounds so that an edit that pushes a kernel further
