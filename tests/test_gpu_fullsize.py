@@ -102,6 +102,15 @@ def test_headline_workload_every_instance_over_the_full_horizon(cclqr, orc):
           % (err.max(), np.median(err), np.abs(zT - z0).max()))
     assert err.max() < 1e-8
     assert np.abs(zT - z0).max() > 0.1        # (not a comparison of two things that did nothing)
+    # whole RECORDED trajectories (every knot of the Storage layout, not only the final state) for every 16th instance: 512 x 1000 knots
+    sel = np.arange(0, n, 16)
+    zTs, trs, _ = capi.rollout(mech, ctrl, z0[sel], steps, record=True)
+    assert np.array_equal(zTs, zT[sel])                       # an instance's result does not depend on the batch it is in
+    _, tro, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=1000, zd=zd), z0[sel], steps, record=True, nthreads=16)
+    errk = np.abs(trs - tro).reshape(len(sel), steps, -1).max(axis=2)
+    print("  recorded trajectories of 512 instances: max over all knots |state - oracle| = %.3g (at step %d)" % (errk.max(), int(errk.max(axis=0).argmax()) + 1))
+    assert errk.max() < 1e-8
+    del trs, tro
     # the measured-error Newton option (cclqr_rollout_opts.newton_mode = 1, stop on ||f|| < 1e-12 alone) against the same oracle run: reported
     # next to the exact rule's own distance from the oracle -- both are round-off amplified by 1000 closed-loop steps
     zT1, _, st1 = capi.rollout(mech, ctrl, z0, steps, newton_mode=1, newton_eps_alone=1e-12)
