@@ -453,6 +453,7 @@ def other_configs(pkg, capi, torch, dev):
         _timed_rollout(capi, torch, dev, mh, bl, z0b, 2000, False), batched_lqr_construct_s=setup_b, gain_table_bytes_in_hbm=int(n) * 7 * 84 * 8,
         riccati_kbreak_min_max=[int(kb.min()), int(kb.max())], riccati_not_converged=int((kb <= 1).sum()), riccati_backward_steps_total=steps_run,
         riccati_tflops_lower_bound_incl_linearize_and_copies=f_ric * steps_run / setup_b / 1e12,
+        riccati_gains_per_s=int(n) / setup_b,      # LQR constructions (linearsystem + dlqr to convergence) per second, whole call
         workload="8192 Sawyer arms, each regulated about its OWN pose (joint angles ~ U(-0.8, 0.8) rad) by its own LQR{T,Inf}: "
                  "cclqr_ctrl_create_lqr_batch(infinite_horizon) = 8192 linearsystem + 8192 dlqr (mx 84, mu 7, ml 35, <= 1999 steps, fp64 MFMA), "
                  "starts within 0.002 rad of the setpoint, 2000 steps")
