@@ -55,6 +55,25 @@ void orc_newton_stats(double *out, int reset) {
     (void)out; (void)reset;
 #endif
 }
+/* Residual at the START of every Newton iteration, binned by floor(-log10 ||f||) (bin 0: >= 1 ... bin 31): [0..31] iterations AFTER which
+ * ||f|| < eps for the first time in their solve, [32..63] iterations after which it still is not, [64..95] iterations entered with ||f|| < eps
+ * already (they only serve the step-size half of the rule).  Calibrates the device's "this factorisation is the last one" predictor. */
+#ifdef ORC_COUNT_FLOPS
+static double g_nhist[96];
+#pragma omp threadprivate(g_nhist)
+#endif
+void orc_newton_hist(double *out, int reset) {
+#ifdef ORC_COUNT_FLOPS
+    for (int i = 0; i < 96; i++) { out[i] = g_nhist[i]; if (reset) g_nhist[i] = 0.0; }
+#else
+    (void)out; (void)reset;
+#endif
+}
+/* MODEL of a device option, not the reference's rule (default 0 = the rule of SURVEY 8a-bis, the only one parity is claimed against):
+ * 1 = once ||f|| < eps the Jacobians are frozen (chord iterations: only the residual is re-evaluated), as cclqr_rollout's kernels do
+ * for the iterations that only serve the step-size test.  Set before a rollout; read-only while one runs. */
+static int g_newton_variant = 0;
+void orc_set_newton_variant(int v) { g_newton_variant = v; }
 
 /* ------------------------------------------------------------------ small dense helpers (row major) */
 /* C(m x n) = beta*C + alpha * op(A) * op(B);  ta/tb: 0 = as is, 1 = transposed. lda/ldb/ldc = row strides */
@@ -582,7 +601,8 @@ static int newton(const mech_t *M, const double *z, double *s, double *lam, work
     double ds[6 * MAXB], dl[5 * MAXB], st[6 * MAXB], lt[5 * MAXB];
     double normf0 = residual(M, z, s, lam, W, 0);
     for (int it = 1; it <= NEWTON_MAXIT; it++) {
-        residual(M, z, s, lam, W, 1);
+        const int chord = g_newton_variant == 1 && it > 1 && normf0 < NEWTON_EPS;      /* model of the device's frozen-Jacobian iterations */
+        residual(M, z, s, lam, W, chord ? 0 : 1);
         if (tree_ldu_solve(M, W, ds, dl)) return -it;
         double alpha = 1.0, normf1 = 0.0;
         int halvings = 0;
@@ -601,7 +621,9 @@ static int newton(const mech_t *M, const double *z, double *s, double *lam, work
         memcpy(lam, lt, sizeof(double) * 5 * ne);
 #ifdef ORC_COUNT_FLOPS
         { int ii = it < 16 ? it - 1 : 15; g_nstat[ii] += halvings; g_nstat[16 + ii] += 1.0;
-          if (normf1 < NEWTON_EPS && nd < NEWTON_EPS) { int b = nd > 0 ? (int)floor(-log10(nd)) : 15; if (b < 0) b = 0; if (b > 15) b = 15; g_nstat[32 + b] += 1.0; g_nstat[48 + halvings] += 1.0; } }
+          if (normf1 < NEWTON_EPS && nd < NEWTON_EPS) { int b = nd > 0 ? (int)floor(-log10(nd)) : 15; if (b < 0) b = 0; if (b > 15) b = 15; g_nstat[32 + b] += 1.0; g_nstat[48 + halvings] += 1.0; }
+          int hb = normf0 > 0 ? (int)floor(-log10(normf0)) : 31; if (hb < 0) hb = 0; if (hb > 31) hb = 31;
+          g_nhist[(normf0 < NEWTON_EPS ? 64 : (normf1 < NEWTON_EPS ? 0 : 32)) + hb] += 1.0; }
 #else
         (void)halvings;
 #endif

@@ -121,6 +121,10 @@ double orc_flops_get(void);
 void orc_flops_reset(void);
 /* Newton / line-search statistics of the calling thread (instrumented build only; layout documented at the definition) */
 void orc_newton_stats(double *out64, int reset);
+/* residual at the start of every Newton iteration, binned (instrumented build only; layout at the definition) */
+void orc_newton_hist(double *out96, int reset);
+/* 0 (default) = the reference's rule; 1 = MODEL of the device's frozen-Jacobian iterations once ||f|| < eps (not a parity mode) */
+void orc_set_newton_variant(int v);
 
 #ifdef __cplusplus
 }

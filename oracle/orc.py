@@ -237,6 +237,20 @@ def newton_stats(reset=True):
     return v[0:16], v[16:32], v[32:48], v[48:59]
 
 
+def newton_hist(reset=True):
+    """instrumented build only: residual at the start of every Newton iteration, binned by floor(-log10 ||f||): (iterations after which
+    ||f|| < eps for the first time, iterations after which it still is not, iterations entered with ||f|| < eps already)"""
+    out = (C.c_double * 96)()
+    lib(True).orc_newton_hist(out, C.c_int(1 if reset else 0))
+    v = np.array(list(out))
+    return v[0:32], v[32:64], v[64:96]
+
+
+def set_newton_variant(v, flops=False):
+    """0 = the reference's rule (default); 1 = MODEL of the device's frozen-Jacobian iterations (not a parity mode)"""
+    lib(flops).orc_set_newton_variant(C.c_int(v))
+
+
 def flops_reset():
     lib(True).orc_flops_reset()
 
