@@ -351,13 +351,11 @@ HD void ck_next_pose(const double* z, const double* s, double dt, double* xq) {
 //   S_jp = W_a[j] Gk_b[p]'                      -> SJP[j]      (p = j-1, when has_a)
 //   S_jc = W_b[j] Gk_a[c]'                      -> SPJ[c]      (c = j+1, when has_c: "S_{parent,child}" of the child's slot)
 //   r_j  = g_j - W_b d_b - W_a d_a              -> R[j]        (pd = residual of the parent body, from the parent lane)
-// One column q of the three blocks at a time.  `blocks` false: the right-hand side only -- the instance's block slots hold a
-// factorisation that the next iteration reuses (frozen-factorisation iterations, rollout_chain.hip), nothing may be written there.
-HD void ck_schur_rows(const LinkC& c, int j, bool store, bool blocks, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3],
-                      const double (*wPA)[3], const double* g, const double* d, const double* pd, double* rout) {
+// One column q of the three blocks at a time.
+HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3],
+                      const double (*wPA)[3], const double* g, const double* d, const double* pd) {
     const double sx = c.sxb + c.sxa;
     const int jp = c.has_a() ? j - 1 : j, jc = c.has_c() ? j + 1 : j;
-    if (blocks) {
 #pragma unroll
     for (int q = 0; q < 5; q++) {
         const int o = gk_row(q), ob = q < 3 ? 3 : 0;   // offset of PB inside the row
@@ -396,7 +394,6 @@ HD void ck_schur_rows(const LinkC& c, int j, bool store, bool blocks, const Lay&
         }
         SCHED_FENCE();     // keep the next column's loads behind this column's arithmetic: hoisting all five columns' loads costs ~90 registers
     }
-    }
     if (store) {
 #pragma unroll
         for (int r = 0; r < 5; r++) {
@@ -409,26 +406,10 @@ HD void ck_schur_rows(const LinkC& c, int j, bool store, bool blocks, const Lay&
                 rr = g[r] - (c.sxb * xd + bd) - (ad - c.sxa * xa);
             }
             L[Y.R + 5 * j + r] = rr;
-            rout[r] = rr;
         }
     }
 }
-// W_b v (own-body side) and W_a v (parent-body side) of the owned joint's W = G_v D^-1 for a body-space 6-vector v: the products the
-// right-hand side r = g - W_b d_b - W_a d_a is made of (ck_schur_rows), for another vector
-HD void w_apply_b(const LinkC& c, const double (*wXT)[3], const double (*wPB)[3], const double* v, double* out) {
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const double bd = wPB[r][0] * v[3] + wPB[r][1] * v[4] + wPB[r][2] * v[5];
-        out[r] = r < 3 ? c.sxb * (wXT[r][0] * v[0] + wXT[r][1] * v[1] + wXT[r][2] * v[2]) + bd : bd;
-    }
-}
-HD void w_apply_a(const LinkC& c, const double (*wXT)[3], const double (*wPA)[3], const double* v, double* out) {
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const double ad = wPA[r][0] * v[3] + wPA[r][1] * v[4] + wPA[r][2] * v[5];
-        out[r] = r < 3 ? ad - c.sxa * (wXT[r][0] * v[0] + wXT[r][1] * v[1] + wXT[r][2] * v[2]) : ad;
-    }
-}
+
 // G_k of the owned joint into its LDS slot / B' y against the slot's rows (own[6] child side, par[6] parent side)
 HD void gk_store(int j, const Lay& Y, double* L, const double (*XT)[3], const double (*PB)[3], const double (*PA)[3]) {
 #pragma unroll
@@ -456,37 +437,6 @@ HD void gk_t_apply(const LinkC& c, int j, const Lay& Y, const double* L, const d
     for (int i = 0; i < 3; i++) { own[i] = x[i]; own[3 + i] = pb[i]; par[i] = c.has_a() ? -x[i] : 0.0; par[3 + i] = pa[i]; }
 }
 
-// Frozen-factorisation iterations on a chain with the reduction level: the level's work on the RIGHT-HAND SIDE -- r_p -= S_pl y_l,
-// r_nx -= S_nx,l y_l with y_l = S_ll^-1 r_l for every odd link l -- done inside the evaluation that produces r, matrix-free: the level's own
-// factor pass overwrote S_pl and S_nx,l with its fill blocks, but S_pl y = W_b[p] (Gk_a[l]' y) and S_nx,l y = W_a[nx] (Gk_b[l]' y) with the W that
-// the evaluation holds in registers anyway (W of the evaluated point instead of the factorised one: a quasi-Newton step either way) and the
-// G_k of the slots.  Odd lane: y_l from the LU that cr_phase_a left in S_ll's slot (keep) -> R[l]; its two force-map vectors travel to the
-// neighbour lanes by the caller's wave shifts (cr_rhs_even).
-HD void cr_rhs_odd(const LinkC& c, int l, bool odd, const Lay& Y, double* L, const double* r, double* own6, double* par6) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) { own6[i] = 0.0; par6[i] = 0.0; }
-    if (!odd) return;
-    double lu[25], y[5];
-#pragma unroll
-    for (int e = 0; e < 25; e++) lu[e] = L[Y.SJJ + 25 * l + e];
-#pragma unroll
-    for (int q = 0; q < 5; q++) y[q] = r[q];
-    lu5_solve(lu, y);
-    gk_t_apply(c, l, Y, L, y, own6, par6);
-#pragma unroll
-    for (int q = 0; q < 5; q++) L[Y.R + 5 * l + q] = y[q];
-}
-// even lane: fn = Gk_a' y of the child link (from the next lane, zero when that is no eliminated link), fp = Gk_b' y of the parent link
-HD void cr_rhs_even(const LinkC& c, int e, bool even, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3], const double (*wPA)[3],
-                    const double* r, const double* fn, const double* fp) {
-    if (!even) return;
-    double ub[5], ua[5];
-    w_apply_b(c, wXT, wPB, fn, ub);
-    w_apply_a(c, wXT, wPA, fp, ua);
-#pragma unroll
-    for (int q = 0; q < 5; q++) L[Y.R + 5 * e + q] = r[q] - ub[q] - ua[q];
-}
-
 // ---- body solve: ds = D^-1 (d + cd) with cd = Gk_b(own joint)' dl + Gk_a(child joint)' dl_child (the latter arrives from the child lane)
 HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const double* DINV, double* ds) {
     double tv[6];
@@ -508,9 +458,7 @@ HD void ck_body_solve(const LinkC& c, const double* d, const double* cd, const d
 // Plan of the chain kernel: like tri_plan, but with BALANCED fronts when the chain has an odd number of links (17: 8 + 8 steps
 // instead of 7 + 9).  Both fronts then fold into the middle link in the same (last) step; front 1 writes its contribution
 // -S_ql Z, -S_ql y to a scratch block instead of the middle link's own blocks (`merge`), and the middle solve adds it.  The
-// scratch is the (SJP, SPJ) pair of the chain's FIRST link: a chain hangs off the origin, so its first link has no S_{l,l-1} /
-// S_{l-1,l} and nothing else ever uses the two slots (round 4; until then the pair of the second link, which front 1 consumes in its
-// first step -- but the frozen-factorisation iterations need that S_ql again).
+// scratch is the (SJP, SPJ) pair of the chain's second link, which front 1 consumed in its first step.
 // The swept chain may be a REDUCED one (every second link of the original, after cr_level below): its links are cs + st i,
 // i < cn, and the coupling blocks of neighbours x < x' = x + st sit where the level below left them: S_{x',x} in SJP[x']
 // ("lower" block of x'), S_{x,x'} in SPJ[x + 1] ("upper" block of x) -- for st = 1 the plain layout.
@@ -527,12 +475,11 @@ HD TriPlanB tri_plan_balanced(int cs, int cn, int st = 1, int fronts = 2) {
     B.P.cs = cs; B.P.mid = cs + st * B.P.nB; B.st = st;
     return B;
 }
-HD int tri_scratch_S(const TriPlanB& B, const Lay& Y) { return Y.SJP + 25 * B.P.cs; }
-HD int tri_scratch_R(const TriPlanB& B, const Lay& Y) { return Y.SPJ + 25 * B.P.cs; }
+HD int tri_scratch_S(const TriPlanB& B, const Lay& Y) { return Y.SJP + 25 * (B.P.cs + B.st); }
+HD int tri_scratch_R(const TriPlanB& B, const Lay& Y) { return Y.SPJ + 25 * (B.P.cs + 1); }
 struct TriCur {
     int oLL, oQL, oRhs, oTgt, oOut;   // LDS offsets at the current step: S_ll, S_ql, this lane's right-hand side (column c of S_lq, or
                                       // r_l), its target (column c of S_qq, or r_q) and where its solution goes (column c of S_ll, or r_l)
-    int oLU;                          // the block S_lq, dead once its columns have been read: a sweep that is to be reused keeps S_ll's packed LU there
     int dblk, dvec;                   // per-step increments of the block offsets / of this lane's vector offsets
     int n;                            // steps of this lane's front (0: the lane takes no part)
     int imerge, oScr;                 // front 1 of a balanced plan: in step imerge the target is the scratch block (-1: never)
@@ -552,8 +499,7 @@ HD TriCur tri_cursor(int t, const TriPlanB& B, const Lay& Y) {
     K.dvec = K.isy ? (front ? 5 * st : -5 * st) : K.dblk;
     K.oLL = Y.SJJ + 25 * l;
     K.oQL = front ? Y.SJP + 25 * q : Y.SPJ + 25 * (q + 1);                                  // S_ql: lower block of q / upper block of q
-    K.oLU = front ? Y.SPJ + 25 * (l + 1) : Y.SJP + 25 * l;                                  // S_lq: upper / lower block of l
-    K.oRhs = K.isy ? Y.R + 5 * l : K.oLU + 5 * cc;
+    K.oRhs = K.isy ? Y.R + 5 * l : (front ? Y.SPJ + 25 * (l + 1) : Y.SJP + 25 * l) + 5 * cc;   // S_lq: upper / lower block of l
     K.oTgt = K.isy ? Y.R + 5 * q : Y.SJJ + 25 * q + 5 * cc;
     K.oOut = K.isy ? Y.R + 5 * l : Y.SJJ + 25 * l + 5 * cc;
     K.imerge = (front && B.merge) ? P.nB - 1 : -1;
@@ -580,24 +526,7 @@ HD void lu5_factor(double* A) {
 // Load order = order of need: S_ll (the LU starts as soon as it has arrived), the right-hand side, the target, and S_ql last
 // (only the final update reads it), so that most of the loads' latency hides under the pivot chain of the factorisation.
 // Returns false (and touches nothing) when the lane has no work in step i.
-// solve t A = s for the row vector t (A = the packed LU of lu5_factor: unit-lower L, U with its diagonal stored as reciprocals), in place
-HD void lu5_solve_t(const double* A, double* b) {
-#pragma unroll
-    for (int i = 0; i < 5; i++) {          // U' w = s
-#pragma unroll
-        for (int k = 0; k < i; k++) b[i] -= A[k * 5 + i] * b[k];
-        b[i] *= A[i * 5 + i];
-    }
-#pragma unroll
-    for (int i = 3; i >= 0; i--) {         // L' t = w
-#pragma unroll
-        for (int k = i + 1; k < 5; k++) b[i] -= A[k * 5 + i] * b[k];
-    }
-}
-// keep (per instance): a sweep whose factorisation is to be reused (frozen-factorisation iterations, rollout_chain.hip): the front's y lane --
-// it factorises S_ll like the column lanes -- leaves the packed LU in the block S_lq, whose columns every lane has read by then (the store sits
-// behind those loads in the wavefront's instruction stream; S_ql is fetched behind it, under the solve).  tri_keep_T finishes the job after the sweep.
-HD bool tri_step(TriCur& K, int i, double* L, double* tg, double* zy, int* otg, int* oout, bool keep) {
+HD bool tri_step(TriCur& K, int i, const double* L, double* tg, double* zy, int* otg, int* oout) {
     if (i >= K.n) return false;
     double lu[25], sql[25];
 #pragma unroll
@@ -613,114 +542,33 @@ HD bool tri_step(TriCur& K, int i, double* L, double* tg, double* zy, int* otg, 
     for (int r = 0; r < 5; r++) tl[r] = L[K.oTgt + r];
 #pragma unroll
     for (int r = 0; r < 5; r++) tg[r] = mstep ? 0.0 : tl[r];
-    lu5_factor(lu);
-    if (keep && K.isy) {
-#pragma unroll
-        for (int e = 0; e < 25; e++) L[K.oLU + e] = lu[e];
-    }
 #pragma unroll
     for (int e = 0; e < 25; e++) sql[e] = L[K.oQL + e];
+    lu5_factor(lu);
     lu5_solve(lu, zy);
 #pragma unroll
     for (int r = 0; r < 5; r++) tg[r] -= sql[r] * zy[0] + sql[5 + r] * zy[1] + sql[10 + r] * zy[2] + sql[15 + r] * zy[3] + sql[20 + r] * zy[4];
     *otg = mstep ? K.oScr : K.oTgt; *oout = K.oOut;
-    K.oLL += K.dblk; K.oQL += K.dblk; K.oLU += K.dblk; K.oRhs += K.dvec; K.oTgt += K.dvec; K.oOut += K.dvec;
+    K.oLL += K.dblk; K.oQL += K.dblk; K.oRhs += K.dvec; K.oTgt += K.dvec; K.oOut += K.dvec;
     return true;
 }
 HD void tri_step_store(double* L, int otg, int oout, const double* tg, const double* zy) {
 #pragma unroll
     for (int r = 0; r < 5; r++) { L[otg + r] = tg[r]; L[oout + r] = zy[r]; }
 }
-// The idx-th link a plan's sweep eliminates (front 0's links first, in the order it takes them), the block that holds its kept LU (S_lq) and the
-// block S_ql the right-hand-side sweep multiplies with
-struct TriElim { int l, oLU, oQL; };
-HD TriElim tri_elim(int idx, const TriPlanB& B, const Lay& Y) {
-    const TriPlan& P = B.P;
-    const int st = B.st;
-    const bool f1 = idx >= P.nA;
-    const int k = f1 ? idx - P.nA : idx;
-    TriElim E;
-    E.l = f1 ? P.cs + st * k : P.cs + st * (P.cn - 1 - k);
-    const int q = f1 ? E.l + st : E.l - st;
-    E.oLU = f1 ? Y.SPJ + 25 * (E.l + 1) : Y.SJP + 25 * E.l;
-    E.oQL = f1 ? Y.SJP + 25 * q : Y.SPJ + 25 * (q + 1);
-    return E;
-}
-// After a kept sweep: T = S_ql S_ll^-1 over S_ql for every eliminated link, so that the right-hand-side sweep of the frozen iterations is
-// r_q -= T r_l, ONE 5x5 product per step.  Row by row (t A = s with the kept LU), the 5 (nA + nB) rows dealt to the instance's G lanes.
-HD void tri_keep_T(int t, int G, const TriPlanB& B, const Lay& Y, double* L, bool on) {
-    const int nrows = 5 * (B.P.nA + B.P.nB);
-    for (int task = t; task < nrows; task += G) {
-        if (!on) continue;
-        const int idx = task / 5, row = task - 5 * idx;
-        const TriElim E = tri_elim(idx, B, Y);
-        double lu[25], x[5];
-#pragma unroll
-        for (int e = 0; e < 25; e++) lu[e] = L[E.oLU + e];
-#pragma unroll
-        for (int k = 0; k < 5; k++) x[k] = L[E.oQL + 5 * k + row];
-        lu5_solve_t(lu, x);
-#pragma unroll
-        for (int k = 0; k < 5; k++) L[E.oQL + 5 * k + row] = x[k];
-    }
-}
-// One step of the right-hand-side sweep of a frozen-factorisation iteration: r~_q = r_q - T r~_l with the T the kept sweep left over S_ql.
-// The front's y lane alone; r~_l travels from step to step in its registers (r[5] = R[l] of the front's first link before the first step)
-// and every R[q] it passes is left holding r~_q.
-HD void tri_rhs_step(TriCur& K, int i, double* L, double* r) {
-    if (!K.isy || i >= K.n) return;
-    double T[25], tl[5], tg[5];
-#pragma unroll
-    for (int e = 0; e < 25; e++) T[e] = L[K.oQL + e];
-#pragma unroll
-    for (int q = 0; q < 5; q++) tl[q] = L[K.oTgt + q];
-    const bool mstep = i == K.imerge;
-#pragma unroll
-    for (int q = 0; q < 5; q++) tg[q] = (mstep ? 0.0 : tl[q]) - (T[q] * r[0] + T[5 + q] * r[1] + T[10 + q] * r[2] + T[15 + q] * r[3] + T[20 + q] * r[4]);
-    const int otg = mstep ? K.oScr : K.oTgt;
-#pragma unroll
-    for (int q = 0; q < 5; q++) { L[otg + q] = tg[q]; r[q] = tg[q]; }
-    K.oQL += K.dblk; K.oTgt += K.dvec;
-}
-// y_l = S_ll^-1 r~_l for every link the sweep eliminated, all at once (the back substitution reads them from R[l]); links dealt to the G lanes
-HD void tri_rhs_y(int t, int G, const TriPlanB& B, const Lay& Y, double* L, bool on) {
-    const int n = B.P.nA + B.P.nB;
-    for (int idx = t; idx < n; idx += G) {
-        if (!on) continue;
-        const TriElim E = tri_elim(idx, B, Y);
-        double lu[25], y[5];
-#pragma unroll
-        for (int e = 0; e < 25; e++) lu[e] = L[E.oLU + e];
-#pragma unroll
-        for (int q = 0; q < 5; q++) y[q] = L[Y.R + 5 * E.l + q];
-        lu5_solve(lu, y);
-#pragma unroll
-        for (int q = 0; q < 5; q++) L[Y.R + 5 * E.l + q] = y[q];
-    }
-}
 // middle link: both sides have been folded in (a balanced plan: front 1's share is added from the scratch block here); one lane
 // factorises and solves
-// keep: the packed LU is left in S_mid,mid's slot (nothing reads that block afterwards); frozen: it is taken from there
-HD void ck_tri_mid(int t, const TriPlanB& B, const Lay& Y, double* L, bool keep = false, bool frozen = false) {
+HD void ck_tri_mid(int t, const TriPlanB& B, const Lay& Y, double* L) {
     if (t != 0) return;
     const TriPlan& P = B.P;
     double A[25], b[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) b[i] = L[Y.R + 5 * P.mid + i] + (B.merge ? L[tri_scratch_R(B, Y) + i] : 0.0);
-    if (frozen) {
 #pragma unroll
-        for (int e = 0; e < 25; e++) A[e] = L[Y.SJJ + 25 * P.mid + e];
-    } else {
+    for (int cI = 0; cI < 5; cI++)
 #pragma unroll
-        for (int cI = 0; cI < 5; cI++)
-#pragma unroll
-            for (int r = 0; r < 5; r++) A[r * 5 + cI] = L[Y.SJJ + 25 * P.mid + 5 * cI + r] + (B.merge ? L[tri_scratch_S(B, Y) + 5 * cI + r] : 0.0);
-        lu5_factor(A);
-        if (keep) {
-#pragma unroll
-            for (int e = 0; e < 25; e++) L[Y.SJJ + 25 * P.mid + e] = A[e];
-        }
-    }
+        for (int r = 0; r < 5; r++) A[r * 5 + cI] = L[Y.SJJ + 25 * P.mid + 5 * cI + r] + (B.merge ? L[tri_scratch_S(B, Y) + 5 * cI + r] : 0.0);
+    lu5_factor(A);
     lu5_solve(A, b);
 #pragma unroll
     for (int i = 0; i < 5; i++) L[Y.DL + 5 * P.mid + i] = b[i];
@@ -799,10 +647,8 @@ HD void cr_setup(CrLane<W>& K, int t, int cs, int n, int st, const Lay& Y, bool 
 // phase A, loads and arithmetic: the lane's solutions z (kept for phase B) and its p-side columns tA; cr_store_a writes them AFTER
 // every lane has loaded (the caller puts the store behind this call in the wavefront's instruction stream).  A fill column
 // (S_p,nx, S_nx,p) replaces what its slot held: the old value enters with factor 0.
-// keep (per instance; frozen-factorisation iterations): the link's first lane leaves the packed LU of S_ll in S_ll's own slot, which nothing reads
-// after this pass (its four lanes have loaded it by then)
 template <int W>
-HD void cr_phase_a(CrLane<W>& K, double* L, double (*tA)[5], bool keep = false) {
+HD void cr_phase_a(CrLane<W>& K, const double* L, double (*tA)[5]) {
     if (!K.act()) return;
     double lu[25], blk[25];
 #pragma unroll
@@ -814,10 +660,6 @@ HD void cr_phase_a(CrLane<W>& K, double* L, double (*tA)[5], bool keep = false) 
 #pragma unroll
         for (int r = 0; r < 5; r++) K.z[s][r] = L[K.oRhs[s] + r];
     lu5_factor(lu);
-    if (keep && K.w == 0) {
-#pragma unroll
-        for (int e = 0; e < 25; e++) L[K.oLL + e] = lu[e];
-    }
 #pragma unroll
     for (int s = 0; s < CrLane<W>::NS; s++) lu5_solve(lu, K.z[s]);
     SCHED_FENCE();      // the factorisation is dead here: the neighbour block and the targets take its registers (fetching them

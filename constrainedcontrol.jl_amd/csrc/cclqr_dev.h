@@ -23,15 +23,6 @@
 #define CCLQR_MAXI 8           // joints around one body of a closed-loop mechanism
 #define HD __host__ __device__ __forceinline__
 
-// Newton rule of the rollout kernels: stop when ||f|| < eps and alpha |step| < eps; <= 100 iterations, <= 10 halvings
-#define NEWTON_EPS 1e-10
-#define NEWTON_MAXIT 100
-#define LINE_MAXIT 10
-// chain kernel: a full iteration that starts with ||f|| below this is predicted to end below NEWTON_EPS (quadratic convergence), i.e. to be
-// the last one that needs a new factorisation (rollout_chain.hip; calibrated with tools/cpu_chord_model.py).  A cost
-// heuristic only: a wrong prediction costs one evaluation, never a result.
-#define NEWTON_PRED_LAST 1e-5
-
 namespace cclqr {
 
 // ---- mechanism tables in device memory (internal link order = chain by chain, root to leaf) ----

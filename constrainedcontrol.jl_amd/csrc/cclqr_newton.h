@@ -8,8 +8,7 @@ namespace cclqr {
 // ---- optional in-kernel phase stamps (diagnostic build only: -DCCLQR_PROFILE; the shipped library contains none) ----
 #ifdef CCLQR_PROFILE
 enum { PF_CONTROL, PF_FORCES, PF_EVAL_BODY, PF_EVAL_JOINT, PF_EVAL_MAP, PF_SCHUR_W, PF_SCHUR_S, PF_TRI_FWD, PF_TRI_BWD, PF_BODY_SOLVE, PF_TRIAL,
-       PF_ACCEPT, PF_IO, PF_NEWTON_ITERS, PF_EVALS, PF_STEPS,
-       PF_PASS0, PF_PASS1, PF_PASS2, PF_REEVAL, PF_REEVAL_BLOCKS, PF_N };   // (chain kernel: solve passes by kind, evaluations at the accepted point)
+       PF_ACCEPT, PF_IO, PF_NEWTON_ITERS, PF_EVALS, PF_STEPS, PF_N };
 static __device__ unsigned long long g_prof[PF_N];
 struct Prof {
     unsigned long long t0, acc[PF_N];
@@ -29,7 +28,9 @@ struct Prof {
 #define PCOUNT(c)
 #endif
 
-// (NEWTON_EPS, NEWTON_PRED_LAST, NEWTON_MAXIT, LINE_MAXIT: cclqr_chain.h / cclqr_dev.h -- the CPU emulation of the phase functions needs them too)
+#define NEWTON_EPS 1e-10
+#define NEWTON_MAXIT 100
+#define LINE_MAXIT 10
 
 // 16-lane row rotation through the DPP crossbar (no LDS round trip)
 template <int N>

@@ -47,12 +47,8 @@ struct LinkS {
 // With JAC the Schur complement rows of the point go straight to LDS: W = G_v D^-1 only lives inside this function.
 // (The full-step trial is evaluated with JAC on the speculation that it is accepted; if it is not, the accepted point is
 // evaluated again, which overwrites these rows.)
-// blocks (with JAC): also the Schur blocks; false = the right-hand side and D_R^-1 only -- the instance's block slots hold a factorisation that is
-// reused (frozen-factorisation iterations); on the chain that has the reduction level (links crs .. crs + crn - 1, crn = 0: none) the level's share
-// of the right-hand-side sweep is then done here, where W still is in registers (cr_rhs_odd / cr_rhs_even, cclqr_chain.h).
-template <int G, bool JAC, bool CRK = false>
-__device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, bool blocks, double dt PROF_ARG,
-                                             int crs = 0, int crn = 0) {
+template <int G, bool JAC>
+__device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, double dt PROF_ARG) {
     double part = 0.0;
     double NB[9], g[5], xq[7];
     LINK_FLAGS_FRESH(c);
@@ -85,21 +81,9 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
     STAMP(PF_EVAL_JOINT);
     LINK_FLAGS_FRESH(c);
     if (JAC) {
-        double pd[6], rr[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        double pd[6];
         from_prev<6>(S.d, pd);
-        ck_schur_rows(c, t, active, active && blocks, Y, L, wXT, wPB, wPA, g, S.d, pd, rr);
-        if (CRK) {
-            const bool lite = active && !blocks;
-            if (crn > 0 && __any(lite)) {
-                const int i = t - crs;
-                const bool in = lite && i >= 0 && i < crn;
-                double own6[6], par6[6], fn[6], fp[6];
-                cr_rhs_odd(c, t, in && (i & 1), Y, L, rr, own6, par6);
-                from_next<6>(par6, fn);
-                from_prev<6>(own6, fp);
-                cr_rhs_even(c, t, in && !(i & 1), Y, L, wXT, wPB, wPA, rr, fn, fp);
-            }
-        }
+        ck_schur_rows(c, t, active, Y, L, wXT, wPB, wPA, g, S.d, pd);
         STAMP(PF_SCHUR_S);
     }
     const double nrm = sqrt(group_sum<G>(part));
@@ -223,10 +207,11 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     // used, through a pointer the optimiser cannot see through, instead of sitting in scalar registers for the whole launch.
     typedef const __attribute__((address_space(4))) RolloutArgs* KernArgs;
     KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int k0 = a.k0;
     int nsteps = a.steps;
     for (int kk = 0; kk < nsteps; kk++) {
+        const int k = k0 + kk;
         asm volatile("" : "+s"(ap));
-        const int k = ap->k0 + kk;
         LINK_FLAGS_FRESH(c);
         double* const traj_out = ap->traj;
         if (traj_out) {     // Storage row of this step, staged through LDS in user body order so that the HBM stores coalesce
@@ -331,118 +316,65 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         const bool go = c.valid() && !c.dead();
-        // Newton state of the instance, one vector register like the lane flags (NS_FRESH: the tests are re-made where they are needed instead of
-        // five 64-bit lane masks living in scalar registers through the iteration): bit 0 done, 1 failed, 2 cok (below), 3 / 4 = mode 1 / 2 (below)
-        enum { NS_DONE = 1, NS_FAILED = 2, NS_COK = 4, NS_M1 = 8, NS_M2 = 16, NS_MODE = 24 };
-#define NS_FRESH() asm volatile("" : "+v"(ns))
-        int ns = go ? 0 : NS_DONE;
+        bool done = !go, failed = false;
         int its = 0;
-        // Frozen-factorisation iterations.  Once ||f|| < eps an iteration only serves the step-size half of the stopping rule: its
-        // step is J^-1 (round-off), and the factorisation of the last full iteration gives that step as well as a new one (it differs from the
-        // Newton step by O(|dJ| |step|), far below the round-off the step consists of).  Such an iteration evaluates the residual, D_R^-1 and the
-        // right-hand side at its point, sweeps the RIGHT-HAND SIDE through the stored factors (tri_rhs_step) and goes on as any other: same body
-        // solve, same line search, same two tests.  Everything is decided PER INSTANCE (uniform over its lanes) from the instance's own
-        // residual, and the three kinds of iteration run one after the other when the instances of a wavefront disagree (they rarely do): an
-        // instance's arithmetic never depends on who shares its wavefront.
-        //   mode 0: full iteration; the full-step trial speculates on another full iteration (it evaluates the Schur blocks)
-        //   mode 1: full iteration that is predicted to be the last (||f|| < NEWTON_PRED_LAST at its start: quadratic convergence takes that
-        //           below eps): the same solve, but the LUs of its pivots are kept in slots that are dead by then (reduction level: S_ll's own
-        //           slot; sweep: the block S_lq; middle link: S_mid,mid), and the trial evaluates NO blocks (they would overwrite the factorisation)
-        //   mode 2: frozen iteration (the slots hold a reusable factorisation -- cok -- and ||f|| < eps)
-        // A wrong prediction costs one more evaluation (the blocks are evaluated at the accepted point when the next iteration needs them), never a result.
-        constexpr bool CR = G == 32 && NBP <= 17;    // instantiations with the reduction level: 4 lanes for each of up to 8 odd links
-        double normf0 = chain_eval<G, true, CR>(c, S, t, Y, L, 0.0, c.live() && !(ns & NS_DONE), true, dt PROF_PASS);
+        double normf0 = chain_eval<G, true>(c, S, t, Y, L, 0.0, c.live() && !done, dt PROF_PASS);
         __syncthreads();
         const int nchains = M->nchains;
-        int crs = 0, crn = 0;            // the chain that gets the reduction level (at most one chain of a <= 17-link mechanism has CR_MIN_LINKS links)
-        if (CR) {
-            for (int ci = 0; ci < nchains; ci++)
-                if (M->chain_len[ci] >= CR_MIN_LINKS) { crs = M->chain_start[ci]; crn = M->chain_len[ci]; }
-        }
         for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
-            NS_FRESH();
-            if (!__any(!(ns & NS_DONE))) break;
+            if (!__any(!done)) break;
             PCOUNT(PF_NEWTON_ITERS);
-            ns = (ns & ~NS_MODE) | (((ns & NS_COK) && normf0 < NEWTON_EPS) ? NS_M2 : (normf0 < NEWTON_PRED_LAST ? NS_M1 : 0));
-            // block-tridiagonal solve along each chain, swept from both ends (cclqr_chain.h): the instances in a full iteration first, then those
-            // in a frozen one (usually a wavefront's instances agree and there is one pass)
+            const bool active = c.live() && !done;
+            // block-tridiagonal solve along each chain, swept from both ends (cclqr_chain.h)
             for (int ci = 0; ci < nchains; ci++) {
                 const int cs = M->chain_start[ci], cn = M->chain_len[ci];
-                // long chains: every second link is eliminated first, all at once (cr_level, cclqr_chain.h), and the two-front sweep runs over the
-                // half that is left; a frozen iteration has done the level's share of the right-hand side in its evaluation (chain_eval)
+                // long chains: every second link is eliminated first, all at once (cr_level, cclqr_chain.h), and the two-front sweep
+                // runs over the half that is left
                 constexpr int CRW = 4;
+                constexpr bool CR = G == 32 && NBP <= 17;    // 4 lanes for each of up to 8 odd links
                 const bool cr = CR && cn >= CR_MIN_LINKS;
-#pragma unroll 1
-                for (int m = 0; m < 2; m++) {
-#define NS_MINE() ((ns & (NS_DONE | NS_M2)) == (m << 4))        /* not done and (m = 0: full iteration, m = 1: frozen) */
-                    NS_FRESH();
-                    if (!__any(NS_MINE())) continue;
-                    PCOUNT(PF_PASS0 + m);
-                    if (CR && cr && m == 0) {
-                        CrLane<CRW> CK;
-                        double tc[CrLane<CRW>::NS][5];
-                        cr_setup<CRW>(CK, t, cs, cn, 1, Y, !NS_MINE());
-                        CR_FLAGS_FRESH(CK);
-                        cr_phase_a<CRW>(CK, L, tc, (ns & NS_M1) != 0);
-                        CR_FLAGS_FRESH(CK);
-                        cr_store_a<CRW>(CK, L, tc);
-                        __syncthreads();
-                        CR_FLAGS_FRESH(CK);
-                        cr_phase_b<CRW>(CK, L, tc);
-                        CR_FLAGS_FRESH(CK);
-                        cr_store_b<CRW>(CK, L, tc);
-                        __syncthreads();
-                    }
-                    STAMP(PF_SCHUR_W);
-                    const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1, G >= 16 ? 2 : 1);
-                    const TriPlan& P = PB.P;
-                    TriCur K = tri_cursor(t, PB, Y);
-                    NS_FRESH();
-                    if (!NS_MINE()) K.n = 0;
-                    if (m == 1) {      // frozen: the right-hand side through the kept factors (one lane per front, nothing crosses lanes: no barrier between the steps)
-                        double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-                        if (K.isy && K.n > 0) {
-#pragma unroll
-                            for (int q = 0; q < 5; q++) r[q] = L[K.oRhs + q];
-                        }
-                        for (int i = 0; i < P.steps; i++) tri_rhs_step(K, i, L, r);
-                        __syncthreads();
-                        NS_FRESH();
-                        tri_rhs_y(t, G, PB, Y, L, NS_MINE());
-                    } else {
-                        for (int i = 0; i < P.steps; i++) {
-                            double tg[5], zy[5];
-                            int otg = 0, oout = 0;
-                            if (tri_step(K, i, L, tg, zy, &otg, &oout, (ns & NS_M1) != 0)) tri_step_store(L, otg, oout, tg, zy);
-                            __syncthreads();
-                        }
-                        NS_FRESH();
-                        if (__any(NS_MINE() && (ns & NS_M1))) {       // kept factorisation: S_ql -> S_ql S_ll^-1 (the frozen iterations' sweep operator)
-                            tri_keep_T(t, G, PB, Y, L, NS_MINE() && (ns & NS_M1));
-                            __syncthreads();
-                        }
-                    }
-                    STAMP(PF_TRI_FWD);
-                    NS_FRESH();
-                    if (NS_MINE()) ck_tri_mid(t, PB, Y, L, (ns & NS_M1) != 0, m == 1);
+                if (CR && cr) {
+                    CrLane<CRW> CK;
+                    double tc[CrLane<CRW>::NS][5];
+                    cr_setup<CRW>(CK, t, cs, cn, 1, Y, done);
+                    CR_FLAGS_FRESH(CK);
+                    cr_phase_a<CRW>(CK, L, tc);
+                    CR_FLAGS_FRESH(CK);
+                    cr_store_a<CRW>(CK, L, tc);
                     __syncthreads();
-                    for (int j = 0; j < P.steps; j++) {
-                        if (NS_MINE()) ck_tri_back(t, j, PB, Y, L);
-                        __syncthreads();
-                    }
-                    if (CR && cr) {
-                        NS_FRESH();
-                        cr_back<CRW>(t, cs, cn, 1, Y, L, !NS_MINE());
-                        __syncthreads();
-                    }
-                    STAMP(PF_TRI_BWD);
+                    CR_FLAGS_FRESH(CK);
+                    cr_phase_b<CRW>(CK, L, tc);
+                    CR_FLAGS_FRESH(CK);
+                    cr_store_b<CRW>(CK, L, tc);
+                    __syncthreads();
                 }
+                STAMP(PF_SCHUR_W);
+                const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1, G >= 16 ? 2 : 1);
+                const TriPlan& P = PB.P;
+                TriCur K = tri_cursor(t, PB, Y);
+                if (done) K.n = 0;
+                for (int i = 0; i < P.steps; i++) {
+                    double tg[5], zy[5];
+                    int otg = 0, oout = 0;
+                    if (tri_step(K, i, L, tg, zy, &otg, &oout)) tri_step_store(L, otg, oout, tg, zy);
+                    __syncthreads();
+                }
+                STAMP(PF_TRI_FWD);
+                if (!done) ck_tri_mid(t, PB, Y, L);
+                __syncthreads();
+                for (int j = 0; j < P.steps; j++) {
+                    if (!done) ck_tri_back(t, j, PB, Y, L);
+                    __syncthreads();
+                }
+                if (CR && cr) {
+                    cr_back<CRW>(t, cs, cn, 1, Y, L, done);
+                    __syncthreads();
+                }
+                STAMP(PF_TRI_BWD);
             }
             double nd;
             LINK_FLAGS_FRESH(c);
-            NS_FRESH();
             {   // multiplier step from LDS, body solve
-                const bool active = c.live() && !(ns & NS_DONE);
                 double own[6], par[6], cpar[6], dl[5], pdn = 0.0;
 #pragma unroll
                 for (int r = 0; r < 5; r++) dl[r] = L[Y.DL + 5 * t + r];
@@ -464,14 +396,13 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             }
             __syncthreads();
             STAMP(PF_BODY_SOLVE);
-            // line search: halve while ||f|| grows.  The first (full-step) trial also evaluates the Jacobians -- and, when another full iteration is
-            // expected (mode 0), the Schur blocks --, speculating that it is accepted; later trials evaluate the residual only.
+            // line search: halve while ||f|| grows.  The first (full-step) trial also evaluates the Jacobians and the Schur blocks,
+            // speculating that it is accepted; later trials evaluate the residual only.  (Speculating the other way round once
+            // ||f|| < eps -- residual only, Jacobians afterwards if the instance goes on -- was measured: no gain.)
             double alpha = 1.0, normf1 = 0.0;
-            NS_FRESH();
-            const bool active = c.live() && !(ns & NS_DONE);
-            bool ls_done = (ns & NS_DONE) != 0, jac_ok = true;
+            bool ls_done = done, jac_ok = true;
             {
-                const double nf = chain_eval<G, true, CR>(c, S, t, Y, L, 1.0, active, (ns & NS_MODE) == 0, dt PROF_PASS, crs, crn);
+                const double nf = chain_eval<G, true>(c, S, t, Y, L, 1.0, active, dt PROF_PASS);
                 if (!ls_done) {
                     normf1 = nf;
                     if (!(normf1 > normf0)) ls_done = true;
@@ -520,16 +451,15 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 for (int lv = 1; lv <= LINE_MAXIT; lv++) {
                     if (!__any(!ls_done)) break;
                     const double a_l = ldexp(1.0, -lv);
-                    const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, c.live() && !ls_done, false, dt PROF_PASS);
+                    const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, c.live() && !ls_done, dt PROF_PASS);
                     if (!ls_done) {
                         normf1 = nf; alpha = a_l; jac_ok = false;
                         if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
                     }
                 }
             }
-            bool need_eval = false, eval_blocks = true;
-            NS_FRESH();
-            if (!(ns & NS_DONE)) {
+            bool need_jac = false;
+            if (!done) {
                 if (c.live()) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) { S.s[i] -= alpha * S.ds[i]; L[Y.C + 6 * t + i] -= alpha * S.cd[i]; S.cd[i] = 0.0; S.ds[i] = 0.0; }
@@ -537,32 +467,18 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] -= alpha * L[Y.DL + 5 * t + i];
                 }
                 its = iter;
-                if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) ns |= NS_DONE;
-                if (RELAX && normf1 < ap->eps_alone) ns |= NS_DONE;      // measured-error mode: the residual alone
-                if (!(normf1 < 1e300)) ns |= NS_DONE | NS_FAILED;        // non-finite residual: the instance has left the domain of the integrator
+                if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
+                if (RELAX && normf1 < ap->eps_alone) done = true;      // measured-error mode: the residual alone
+                if (!(normf1 < 1e300)) { done = true; failed = true; }   // non-finite residual: the instance has left the domain of the integrator
                 normf0 = normf1;
-                // what the next iteration finds: a reusable factorisation (this one kept its LUs -- or reused them -- and the trial wrote no
-                // blocks) serves it if the residual is below eps; otherwise it needs the blocks of the accepted point
-                const bool kept = (ns & NS_MODE) != 0;
-                eval_blocks = !(kept && normf1 < NEWTON_EPS);
-                need_eval = !(ns & NS_DONE) && (!jac_ok || (kept && eval_blocks));
-                ns = (ns & ~NS_COK) | ((kept && !(need_eval && eval_blocks)) ? NS_COK : 0);
+                need_jac = !done && !jac_ok;
             }
             STAMP(PF_ACCEPT);
-            if (__any(need_eval)) {
-                PCOUNT(PF_REEVAL);
-#ifdef CCLQR_PROFILE
-                if (__any(need_eval && eval_blocks)) PCOUNT(PF_REEVAL_BLOCKS);
-#endif
-                chain_eval<G, true, CR>(c, S, t, Y, L, 0.0, c.live() && need_eval, eval_blocks, dt PROF_PASS, crs, crn);
-            }
+            if (__any(need_jac)) chain_eval<G, true>(c, S, t, Y, L, 0.0, c.live() && need_jac, dt PROF_PASS);
             __syncthreads();
         }
-        const bool conv = (ns & NS_DONE) && !(ns & NS_FAILED);
-#undef NS_FRESH
-#undef NS_MINE
-        LINK_FLAGS_FRESH(c);
-        if (c.valid() && !c.dead()) {      // (= go, re-made: a lane mask does not have to survive the Newton loop)
+        const bool conv = done && !failed;
+        if (go) {
             if (!conv) c.flags |= LinkC::BAD;
             if (its > worst) worst = its;
             if (!conv && its < NEWTON_MAXIT) {   // stopped early on a non-finite residual: freeze the instance at its last pose, at rest

@@ -18,14 +18,12 @@ using namespace cclqr;
 namespace {
 // one cyclic-reduction level as the kernel runs it: every lane's loads and arithmetic of a pass, then every lane's stores
 template <int W>
-static void cr_level_emu(int G, int cs, int cn, const cclqr::Lay& Y, double* L, bool keep) {
+static void cr_level_emu(int G, int cs, int cn, const cclqr::Lay& Y, double* L) {
     using namespace cclqr;
     std::vector<CrLane<W>> K(G);
     std::vector<std::array<std::array<double, 5>, CrLane<W>::NS>> tc(G);
     for (int t = 0; t < G; t++) cr_setup<W>(K[t], t, cs, cn, 1, Y, false);
-    // (the kept LU goes to S_ll's own slot after the link's four lanes have loaded it: the lanes of a link run last-to-first here so that lane
-    // w = 0, which stores, comes after the other three)
-    for (int t = G - 1; t >= 0; t--) cr_phase_a<W>(K[t], L, reinterpret_cast<double(*)[5]>(tc[t].data()), keep);
+    for (int t = 0; t < G; t++) cr_phase_a<W>(K[t], L, reinterpret_cast<double(*)[5]>(tc[t].data()));
     for (int t = 0; t < G; t++) if (K[t].act()) cr_store_a<W>(K[t], L, reinterpret_cast<const double(*)[5]>(tc[t].data()));
     for (int t = 0; t < G; t++) cr_phase_b<W>(K[t], L, reinterpret_cast<double(*)[5]>(tc[t].data()));
     for (int t = 0; t < G; t++) if (K[t].act()) cr_store_b<W>(K[t], L, reinterpret_cast<const double(*)[5]>(tc[t].data()));
@@ -48,7 +46,7 @@ struct Inst {
 const double ORIGIN13[13] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 template <bool JAC>
-double chain_eval(Inst& I, double alpha, bool active, bool blocks = true, int crs = 0, int crn = 0) {
+double chain_eval(Inst& I, double alpha, bool active) {
     const int G = I.G;
     double* L = I.L;
     const Lay& Y = I.Y;
@@ -72,29 +70,13 @@ double chain_eval(Inst& I, double alpha, bool active, bool blocks = true, int cr
         joint_eval_sparse<JAC>(c, pxq, pxq + 3, T.xq, T.xq + 3, pNB, T.NB, T.g, T.wXT, T.wPB, T.wPA);
         for (int i = 0; i < 5; i++) T.part += T.g[i] * T.g[i];
     }
-    if (JAC) {
-        std::vector<std::array<double, 5>> rr(G);
+    if (JAC)
         for (int t = 0; t < G; t++) {
             const LinkC& c = I.c[t];
             if (!(active && c.on())) continue;
             const double* pd = c.has_a() ? I.S[t - 1].d : I.S[t].d;
-            ck_schur_rows(c, t, true, blocks, Y, L, I.T[t].wXT, I.T[t].wPB, I.T[t].wPA, I.T[t].g, I.S[t].d, pd, rr[t].data());
+            ck_schur_rows(c, t, true, Y, L, I.T[t].wXT, I.T[t].wPB, I.T[t].wPA, I.T[t].g, I.S[t].d, pd);
         }
-        if (active && !blocks && crn > 0) {      // the reduction level's share of the right-hand-side sweep (chain_eval of rollout_chain.hip)
-            std::vector<std::array<double, 6>> own(G), par(G);
-            const std::array<double, 6> zero6 = {0, 0, 0, 0, 0, 0};
-            for (int t = 0; t < G; t++) {
-                const int i = t - crs;
-                cr_rhs_odd(I.c[t], t, I.c[t].on() && i >= 0 && i < crn && (i & 1), Y, L, rr[t].data(), own[t].data(), par[t].data());
-            }
-            for (int t = 0; t < G; t++) {
-                const int i = t - crs;
-                const double* fn = t + 1 < G ? par[t + 1].data() : zero6.data();
-                const double* fp = t > 0 ? own[t - 1].data() : zero6.data();
-                cr_rhs_even(I.c[t], t, I.c[t].on() && i >= 0 && i < crn && !(i & 1), Y, L, I.T[t].wXT, I.T[t].wPB, I.T[t].wPA, rr[t].data(), fn, fp);
-            }
-        }
-    }
     double acc = 0.0;
     for (int t = 0; t < G; t++) acc += I.T[t].part;
     return sqrt(acc);
@@ -208,44 +190,32 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                 for (int t = 0; t < nb; t++)
                     for (int i = 0; i < 6; i++) { L[Y.C + 6 * t + i] = own[6 * t + i] + (I.c[t].has_c() ? par[6 * (t + 1) + i] : 0.0); I.S[t].cd[i] = 0.0; }
             }
-            // ---- newton (the kernel's three kinds of iteration -- full / full and predicted to be the last (its LUs are kept) / frozen
-            // factorisation -- decided as in rollout_chain.hip from the instance's own residual)
-            bool done = dead, failed = false, cok = false;
+            // ---- newton
+            bool done = dead, failed = false;
             int its = 0;
-            int crs = 0, crn = 0;
-            if (G == 32 && nb <= 17)
-                for (int ci = 0; ci < M->nchains; ci++)
-                    if (M->chain_len[ci] >= CR_MIN_LINKS) { crs = M->chain_start[ci]; crn = M->chain_len[ci]; }
             double normf0 = chain_eval<true>(I, 0.0, !done);
             for (int iter = 1; iter <= 100 && !done; iter++) {
-                const int m = (cok && normf0 < NEWTON_EPS) ? 2 : (normf0 < NEWTON_PRED_LAST ? 1 : 0);
                 for (int ci = 0; ci < M->nchains; ci++) {
                     const int cs = M->chain_start[ci], cn = M->chain_len[ci];
                     const bool cr = G == 32 && nb <= 17 && cn >= CR_MIN_LINKS;     // = CR && cr of the kernel
-                    if (cr && m != 2) cr_level_emu<4>(G, cs, cn, Y, L, m == 1);
+                    const bool w2 = false;
+                    if (cr) {
+                        if (w2) cr_level_emu<2>(G, cs, cn, Y, L); else cr_level_emu<4>(G, cs, cn, Y, L);
+                    }
                     const TriPlanB PB = cr ? tri_plan_balanced(cs, (cn + 1) / 2, 2) : tri_plan_balanced(cs, cn, 1, G >= 16 ? 2 : 1);
                     const TriPlan& P = PB.P;
                     std::vector<TriCur> K(G);
                     for (int t = 0; t < G; t++) K[t] = tri_cursor(t, PB, Y);
-                    if (m == 2) {
-                        double r[64][5];
-                        for (int t = 0; t < G; t++) if (K[t].isy && K[t].n > 0) for (int q = 0; q < 5; q++) r[t][q] = L[K[t].oRhs + q];
-                        for (int i = 0; i < P.steps; i++) for (int t = 0; t < G; t++) tri_rhs_step(K[t], i, L, r[t]);
-                        for (int t = 0; t < G; t++) tri_rhs_y(t, G, PB, Y, L, true);
-                    } else {
-                        for (int i = 0; i < P.steps; i++) {
-                            double tg[64][5], zy[64][5];
-                            int otg[64], oout[64];
-                            bool act[64];
-                            // every lane's loads come before any lane's stores (the y lane's LU store sits behind the column lanes' loads: lanes run in order)
-                            for (int t = 0; t < G; t++) act[t] = tri_step(K[t], i, L, tg[t], zy[t], &otg[t], &oout[t], m == 1);
-                            for (int t = 0; t < G; t++) if (act[t]) tri_step_store(L, otg[t], oout[t], tg[t], zy[t]);
-                        }
-                        if (m == 1) for (int t = 0; t < G; t++) tri_keep_T(t, G, PB, Y, L, true);
+                    for (int i = 0; i < P.steps; i++) {
+                        double tg[64][5], zy[64][5];
+                        int otg[64], oout[64];
+                        bool act[64];
+                        for (int t = 0; t < G; t++) act[t] = tri_step(K[t], i, L, tg[t], zy[t], &otg[t], &oout[t]);     // every lane's loads come before any lane's stores
+                        for (int t = 0; t < G; t++) if (act[t]) tri_step_store(L, otg[t], oout[t], tg[t], zy[t]);
                     }
-                    for (int t = 0; t < G; t++) ck_tri_mid(t, PB, Y, L, m == 1, m == 2);
+                    for (int t = 0; t < G; t++) ck_tri_mid(t, PB, Y, L);
                     for (int j = 0; j < P.steps; j++) for (int t = 0; t < G; t++) ck_tri_back(t, j, PB, Y, L);
-                    if (cr) for (int t = 0; t < G; t++) cr_back<4>(t, cs, cn, 1, Y, L, false);
+                    if (cr) for (int t = 0; t < G; t++) { if (w2) cr_back<2>(t, cs, cn, 1, Y, L, false); else cr_back<4>(t, cs, cn, 1, Y, L, false); }
                 }
                 double pdn = 0.0;
                 {
@@ -261,7 +231,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                     }
                 }
                 const double nd = sqrt(pdn);
-                double alpha = 1.0, normf1 = chain_eval<true>(I, 1.0, true, m == 0, crs, crn);
+                double alpha = 1.0, normf1 = chain_eval<true>(I, 1.0, true);
                 bool jac_ok = true;
                 if (normf1 > normf0)
                     for (int lv = 1; lv <= 10; lv++) {
@@ -278,11 +248,7 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
                 if (normf1 < 1e-10 && alpha * nd < 1e-10) done = true;
                 if (!(normf1 < 1e300)) { done = true; failed = true; }
                 normf0 = normf1;
-                cok = m != 0;
-                const bool eval_blocks = !(cok && normf1 < NEWTON_EPS);
-                const bool need_eval = !done && (!jac_ok || (m != 0 && eval_blocks));
-                if (need_eval && eval_blocks) cok = false;
-                if (need_eval) chain_eval<true>(I, 0.0, true, eval_blocks, crs, crn);
+                if (!done && !jac_ok) chain_eval<true>(I, 0.0, true);
             }
             if (!dead) {
                 const bool conv = done && !failed;

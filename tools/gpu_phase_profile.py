@@ -18,7 +18,7 @@ mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, [0], K=K, N=1000, zd=zd)
 names = ["control", "forces+knotjac", "eval_body", "eval_joint", "eval_map+norm", "schur_w", "schur_s", "tri_fwd", "tri_bwd", "body_solve", "trial", "accept", "io"]
 _nchild = np.bincount(np.asarray(t.parent)[np.asarray(t.parent) >= 0], minlength=t.nb)
 read = capi.lib().cclqr_prof_read if (_nchild > 1).any() else capi.lib().cclqr_prof_read_chain
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 16)()
 read(buf, 1)
 t0 = time.time(); zT, _, st = capi.rollout(mh, ctrl, z0, steps); dt = time.time() - t0
 read(buf, 1)
@@ -28,6 +28,3 @@ print("n_links %d inst %d steps %d: %.3fs %s; newton iters/step %.2f evals/step 
 for i, n in enumerate(names):
     print("  %-16s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / v[15]))
 print("  total cycles/step (per wave) %.0f" % (tot / v[15]))
-if len(v) > 20 and v[16:21].sum() > 0:
-    print("  solve passes per wavefront-step: full %.3f, full + predicted last (LUs kept) %.3f, frozen %.3f; evaluations at the accepted point %.3f (with Schur blocks %.3f)"
-          % tuple(v[16:21] / v[15]))
