@@ -117,6 +117,7 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     cclqr_ctrl* c = new cclqr_ctrl();
     memset(c, 0, sizeof(*c));
     c->nb = m->nb;
+    c->device = m->device;
     hipError_t e = hipMalloc((void**)&c->zd_dev, T.zd.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(c->zd_dev, T.zd.data(), T.zd.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && !T.K.empty()) {
@@ -167,6 +168,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     cclqr_ctrl* c = new cclqr_ctrl();
     memset(c, 0, sizeof(*c));
     c->nb = nb;
+    c->device = m->device;
     CtrlDev& H = c->host;
     // LQR{T,Inf} (lqr.jl:25-27, 40-43): the recursion runs its N = Ntemp steps, only Ku[1] is kept and the feedback is never gated
     const size_t nKtab = inf ? 1 : (size_t)(N - 1);
@@ -338,6 +340,11 @@ extern "C" int cclqr_ctrl_reserve_noise(cclqr_ctrl* c, int64_t n_inst, int32_t s
     if (!c || n_inst < 0 || steps < 0) return fail(CCLQR_EINVAL, "bad argument");
     const size_t need = (size_t)n_inst * steps;
     if (c->noise_ws_cap >= need) return CCLQR_OK;
+    {   // the block lives on the handle's device: growing it from a thread that is on another one would drain and allocate there
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return fail(CCLQR_EHIP, "hipGetDevice failed");
+        if (dev != c->device) return fail(CCLQR_EINVAL, "the controller was created on device " + std::to_string(c->device) + ", the calling thread is on device " + std::to_string(dev));
+    }
     // a launch that still reads the old block may be in flight on some stream: the device is drained before the block is replaced
     HIPCHK(hipDeviceSynchronize());
     if (c->noise_ws) HIPCHK(hipFree(c->noise_ws));
@@ -470,7 +477,7 @@ static int linearize_projected_analytic(const cclqr_mech* m, int32_t nk, const d
     const int nb = m->nb, nj = m->host.loop ? m->nj : nb, mx = 12 * nb, ml = 5 * nj;
     const size_t nz = 13 * (size_t)nb;
     if (!m->host.loop && linearize_lds_bytes(nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
-    if (project_model_lds_bytes(mx, mu, ml) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "the projection of this model does not fit LDS (use h > 0)");
+    if (!project_model_fits(mx, mu, ml)) return fail(CCLQR_EUNSUPPORTED, "the projection of this model does not fit LDS (use h > 0)");
     LinArgs a;
     memset(&a, 0, sizeof(a));
     a.M = m->dev; a.nk = nk; a.mu = mu;
@@ -519,8 +526,16 @@ extern "C" int cclqr_linearize_projected(const cclqr_mech* m, int32_t nk, const 
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
     if (nk < 0 || mu < 0 || mu > m->nj) return fail(CCLQR_EINVAL, "Missmatched length for constraints");
     if (nk == 0) return CCLQR_OK;
-    if (!(h > 0.0)) return linearize_projected_analytic(m, nk, zd, mu, ctrl_joint, Fd, Ap, D);
     const int nb = m->nb, mx = 12 * nb;
+    if (!(h > 0.0)) {
+        // the analytic projection keeps [G Bl | G A | G Bu] of a knot in one CU's LDS (project_model_kernel): 175 KB for a 16-body tree, 198 KB for
+        // the 17-body headline chain.  What does not fit is differenced instead (the h > 0 form with its documented step), so that the default
+        // call is defined for every mechanism cclqr_mech_create takes
+        const int nj = m->host.loop ? m->nj : nb;
+        const bool fits = project_model_fits(mx, mu, 5 * nj) && (m->host.loop || linearize_lds_bytes(nb, m->host.tree, m->host.npairs) <= 160 * 1024);
+        if (fits) return linearize_projected_analytic(m, nk, zd, mu, ctrl_joint, Fd, Ap, D);
+        h = 1e-6;
+    }
     const size_t nz = 13 * (size_t)nb;
     const int per = 1 + 2 * mx + 2 * mu;            // nominal, +-h in every state error coordinate, +-h in every input
     const size_t n = (size_t)nk * per;

@@ -762,6 +762,8 @@ HD Lay make_chain_layout(int nb) {
     L.DINV = o; o += 9 * nb;
     L.D = o; o += 6 * nb;
     L.C = o; o += 6 * nb;
+    // (cr_back and the clamped operand loads of the sweep read up to one link PAST a chain's last -- DL[nb], R[nb] -- and discard the value:
+    // DL and R must therefore not be the image's last arrays; launch_rollout_chain checks DL + 5 (nb + 1) <= total and R + 5 (nb + 1) <= total)
     L.Z = L.SJJ;               // 13 nb staging
     L.DZ = L.SJJ + 13 * nb;    // 12 nb control error
     L.total = o | 1;

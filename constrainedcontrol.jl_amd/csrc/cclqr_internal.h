@@ -57,6 +57,7 @@ size_t linearize_lds_bytes(int nb, int tree, int npairs);
 size_t linearize_loop_lds_bytes(int nb, int nj);
 hipError_t launch_linearize_loop(const LinArgs& a, int nb, int nj, hipStream_t stream);
 size_t project_model_lds_bytes(int mx, int mu, int ml);
+bool project_model_fits(int mx, int mu, int ml);      // dynamic + static LDS of project_model_kernel within one CU's 160 KB
 hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A, const double* Bu, const double* Bl, const double* G, double* Ap, double* D,
                                 double* res, int* rank, hipStream_t stream);
 hipError_t launch_linearize(const LinArgs& a, int nb, int tree, int npairs, hipStream_t stream);
@@ -95,6 +96,7 @@ struct cclqr_ctrl {
     cclqr::CtrlDev* dev;
     double *K_dev, *zd_dev, *Fd_dev;
     int nb;
+    int device;           // the device the tables (and the noise workspace) live on = the mechanism's
     // workspace of the counter-based noise of one launch (noise_philox), grown on demand and kept with the handle
     double* noise_ws;
     size_t noise_ws_cap;

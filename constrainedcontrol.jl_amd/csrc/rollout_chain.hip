@@ -567,6 +567,12 @@ hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int new
     const size_t lds = chain_lds_bytes(nb);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
+    {   // the reduction level's back substitution reads DL / R of one link past the chain and selects the value away (cclqr_chain.h cr_back): that
+        // read must stay inside the instance's image whatever order a later re-cut of the layout puts the arrays in
+        const int nbp = chain_layout_links(nb);
+        const Lay Y = make_chain_layout(nbp);
+        if (Y.DL + 5 * (nbp + 1) > Y.total || Y.R + 5 * (nbp + 1) > Y.total) return hipErrorInvalidValue;
+    }
     switch (chain_layout_links(nb)) {
         case 4: return launch_chain_one<8, 4>(a, extra, newton_mode, grid, lds, stream);
         case 8: return launch_chain_one<16, 8>(a, extra, newton_mode, grid, lds, stream);

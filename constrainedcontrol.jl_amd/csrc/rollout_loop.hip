@@ -348,7 +348,12 @@ hipError_t launch_linearize_loop(const LinArgs& a, int nb, int nj, hipStream_t s
     hipLaunchKernelGGL(linearize_loop_kernel, dim3(a.nk), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
+// dynamic LDS of project_model_kernel; project_model_fits adds the kernel's static LDS (red_v, red_i, four scalars) before comparing with a CU's 160 KB
 size_t project_model_lds_bytes(int mx, int mu, int ml) { return ((size_t)ml * (ml + mx + mu) + ml) * sizeof(double) + 2 * (size_t)ml * sizeof(int) + 16; }
+bool project_model_fits(int mx, int mu, int ml) {
+    const size_t stat = PROJ_THREADS * (sizeof(double) + sizeof(int)) + 3 * sizeof(int) + sizeof(double) + 64;      // (+ alignment slack)
+    return project_model_lds_bytes(mx, mu, ml) + stat <= 160 * 1024;
+}
 hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A, const double* Bu, const double* Bl, const double* G, double* Ap, double* D,
                                 double* res, int* rank, hipStream_t stream) {
     if (nk <= 0) return hipSuccess;

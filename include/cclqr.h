@@ -127,7 +127,9 @@ int cclqr_linearize(const cclqr_mech *m, int32_t nk, const double *zd, int32_t m
  * mechanisms (examples/lqr_deltabot.jl:47-53), where G Bλ is singular (redundant constraint rows) but A', D are still unique; feed them to
  * cclqr_riccati with ml = 0.
  *   h <= 0: ANALYTIC -- the exact Jacobians of the one-step map on the device (linearsystem of lqr.jl:63 with the multipliers exogenous, for
- *           loops in their own bookkeeping), then G Bλ eliminated with complete pivoting up to its numerical rank;
+ *           loops in their own bookkeeping), then G Bλ eliminated with complete pivoting up to its numerical rank.  The elimination keeps
+ *           [G Bλ | G A | G Bu] of a knot in one compute unit's 160 KB of LDS; a mechanism it does not fit (from about 15 bodies: the 17-body
+ *           chain needs 198 KB) is differenced with h = 1e-6 instead, so the call is defined for every mechanism either way;
  *   h > 0:  central differences (step h in every error coordinate x, v, q~, ω of lqr.jl:92-103 and every input) of the DEVICE's own constrained
  *           one-step map, one launch of nk (1 + 24 nb + 2 mu) single-step rollouts: an independent cross-check of the analytic form.
  * Ap [nk][mx][mx], D [nk][mx][mu]. Host pointers. */
@@ -240,7 +242,10 @@ int cclqr_rollout_host_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_in
 
 /* Sizes the controller handle's Philox noise workspace for launches of up to n_inst * steps samples (the `randn()` stream of
  * examples/trackingLQR_triple_cartpole.jl:98,125 as generated by noise_philox).  Synchronises the device when it has to re-allocate.
- * Call it before capturing step-per-launch rollouts of a noise_philox controller into a hipGraph (BASELINE configs[4]). */
+ * Call it before capturing step-per-launch rollouts of a noise_philox controller into a hipGraph (BASELINE configs[4]), from a thread that is on
+ * the controller's device (CCLQR_EINVAL otherwise), and never while ANY stream of that device is being captured in the global capture mode (the
+ * re-allocation is a device synchronisation plus an allocation, which such a capture does not survive; a launch on the capturing stream itself
+ * that would have to grow the workspace is refused with CCLQR_EINVAL before anything is touched: cclqr_rollout_ex). */
 int cclqr_ctrl_reserve_noise(cclqr_ctrl *c, int64_t n_inst, int32_t steps);
 
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py; no counterpart in the reference's simulate!,

@@ -544,6 +544,12 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
         for k in range(1, 21):
             capi.rollout_dev(mech, ctrl2, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
             src, dst = dst, src
+            if k == 10:
+                # a launch that would have to GROW the handle's workspace while its stream is being captured comes back as CCLQR_EINVAL before
+                # anything synchronises or allocates (the capture stays valid: the replays below are still bit-identical to the fused launch)
+                with pytest.raises(capi.CclqrError) as err:
+                    capi.rollout_dev(mech, ctrl2, n, 7, k + 1, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
+                assert err.value.code == capi.EINVAL
         graph.capture_end()
     torch.cuda.current_stream().wait_stream(side)
     for _ in range(2):                                  # the second replay runs on fresh inputs through the same captured buffers

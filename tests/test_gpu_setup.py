@@ -292,6 +292,26 @@ def test_projected_linear_model_and_lqr_on_the_deltabot(cclqr, orc):
     assert free.status[0] < 0 or np.abs(free.zT[0] - z0).max() > 20 * np.abs(res.zT[0] - z0).max()      # the holding inputs alone do not bring it back
 
 
+@pytest.mark.parametrize("n_links", [15, 16])
+def test_projected_linear_model_default_call_on_the_long_chains(cclqr, n_links):
+    """cclqr_linearize_projected(h <= 0) keeps [G Bλ | G A | G Bu] of a knot in one CU's LDS -- 175 KB for a 16-body mechanism, 198 KB for
+    the 17-body headline chain -- so the default call used to come back with CCLQR_EUNSUPPORTED on exactly those; it now differences what does
+    not fit (h = 1e-6) and is defined for every mechanism.  Checked against the numpy elimination of the multipliers from cclqr_linearize's
+    four matrices (the reference's own D and A' of lqr.jl:151)."""
+    capi = cclqr._capi
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    mh = capi.MechHandle(t)
+    A, Bu, Bl, G = (M[0] for M in capi.linearize(mh, zd[None], [0], np.zeros((1, 1))))
+    AD = np.hstack([A, Bu]) - Bl @ np.linalg.solve(G @ Bl, G @ np.hstack([A, Bu]))
+    mx = 12 * t.nb
+    Ap, D = capi.linearize_projected(mh, zd[None], [0], np.zeros((1, 1)))          # default h = 0
+    scale = np.abs(AD).max()
+    assert scale > 100
+    assert np.abs(Ap[0] - AD[:, :mx]).max() < 1e-8 * scale and np.abs(D[0] - AD[:, mx:]).max() < 1e-8 * scale
+
+
 def test_tracking_lqr_on_the_deltabot(cclqr, orc):
     """TrackingLQR (lqr_tracking.jl:17-43) on a closed-loop mechanism: per-knot projected models from the device (cclqr_linearize_projected,
     119 knots linearised analytically in one launch), the time-varying recursion on them (cclqr_riccati_tv, no multipliers left).
