@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances of the CPU baseline sample (0 = auto)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="launches per rollout (trajectory collected chunk by chunk); 0 = 1 on one GPU, 8 on several")
+    ap.add_argument("--collect", choices=("trajectory", "final"), default="trajectory",
+                    help="what rank 0 collects inside the timed region of a multi-GPU run: 'trajectory' = the recorded trajectories of ALL ranks, "
+                         "assembled in the Storage layout (116 GB on rank 0 at 8 x 8192 x 1000 steps, gathered chunk by chunk behind the compute) + the "
+                         "final states; 'final' = the final states only, every rank keeps its own recorded trajectory in its HBM -- the fallback "
+                         "if the root buffer or the overlap misbehaves on a node (the mode is written into the JSON line)")
     ap.add_argument("--allow-gloo", action="store_true", help="accept the gloo backend for --gpus > 1 (never a scaling measurement)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collective runs over gloo "
@@ -154,15 +159,36 @@ def main():
     ctrl = lqr._ctrl_handle(mh)
     lanes, lds_bytes = mh.geometry()
 
-    chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 8)
+    gather_traj = record and args.collect == "trajectory"
+    chunks = args.chunks if args.chunks > 0 else (8 if (world > 1 and gather_traj) else 1)
     assert T % chunks == 0, "--sim-steps must be a multiple of --chunks"
     Tc = T // chunks
+    # ---- allocation plan of this rank, checked against the free HBM BEFORE anything large is allocated: a run that cannot fit ends here, on
+    # every rank, with a sentence and exit code 3 (rank 0 of an 8-GPU trajectory collection holds ~150 GB: DESIGN.md 5)
+    plan = pkg.dist.collection_plan(rank, world, n_inst, T, nb, chunks, record, args.collect)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    fits = plan["total"] <= 0.92 * free_b
+    all_fit = pkg.dist.max_over_ranks(0.0 if fits else 1.0, dev) == 0.0
+    if rank == 0 or not fits:
+        print("[bench rank %d] allocation plan (--collect %s, %d chunk(s)): %.2f GB of %.2f GB free (%.0f GB HBM)%s" %
+              (rank, args.collect, chunks, plan["total"] / 1e9, free_b / 1e9, total_b / 1e9, "" if fits else "  -- DOES NOT FIT"), file=sys.stderr)
+        for k, v in plan.items():
+            if k != "total":
+                print("[bench rank %d]   %-92s %9.3f GB" % (rank, k, v / 1e9), file=sys.stderr)
+    if not all_fit:
+        if rank == 0:
+            print("[bench] refusing to start: the collection buffers of at least one rank exceed its free HBM; use --collect final (every rank keeps "
+                  "its own trajectory, only final states travel), fewer --instances, or --no-record", file=sys.stderr)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
     z0_d = torch.from_numpy(z0).to(dev)
     zT_d = torch.empty_like(z0_d)
     st_d = torch.zeros((chunks, n_inst), dtype=torch.int32, device=dev)
     lam_d = torch.zeros((n_inst, ml), dtype=torch.float64, device=dev) if chunks > 1 else None
-    collect = world > 1 or chunks > 1          # trajectories leave the rank (or are re-assembled) chunk by chunk
-    tg = pkg.dist.TrajectoryGather(rank, world, n_inst, T, nb, chunks, dev) if (record and collect) else None
+    collect = gather_traj and (world > 1 or chunks > 1)          # trajectories leave the rank (or are re-assembled) chunk by chunk
+    tg = pkg.dist.TrajectoryGather(rank, world, n_inst, T, nb, chunks, dev) if collect else None
     traj_d = torch.empty((n_inst, T, nb, 13), dtype=torch.float64, device=dev) if (record and not collect) else None
     stream = torch.cuda.current_stream().cuda_stream
     kern_ev = []
@@ -175,7 +201,8 @@ def main():
             if tg is not None:
                 tg.wait_slab_free(c)
                 traj_ptr = tg.slab(c).data_ptr()
-            else:
+            else:       # the rank's own trajectory buffer (chunk c writes its T/chunks steps of every instance: row stride = the launch's steps)
+                assert chunks == 1 or not record, "a rank-local trajectory is written by ONE launch per rollout (use --chunks 1 with --collect final)"
                 traj_ptr = traj_d.data_ptr() if record else 0
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -249,7 +276,9 @@ def main():
                      "traffic": traffic, "kernel": "rollout_chain_kernel<%d, %d, 0, false>" % (lanes, mh.layout_links()),
                      "kernel_ms": kern_ms_launch, "launches_per_rollout": chunks, "algorithmic_bytes_per_instance_step": bs,
                      "kernel_source_sha": kernel_source_sha()},
-        "collection": {"trajectory_bytes_gathered_to_rank0_per_rollout": gathered, "chunks": chunks,
+        "collection": {"mode": (args.collect if world > 1 else "single GPU: nothing leaves the device"),
+                       "trajectory_bytes_gathered_to_rank0_per_rollout": gathered, "chunks": chunks,
+                       "rank0_allocation_plan_gb": round(plan["total"] / 1e9, 3),
                        "exposed_ms_per_rollout": 1e3 * elapsed / max(1, args.steps) - kern_ms},
         "newton": {"max_iters_mean": float(status.mean()), "max_iters_max": int(status.max()), "failed_instances": n_bad},
         "setup": {"lqr_construct_s": setup_s, "lqr_construct_warm_s": setup_warm_s, "riccati_kbreak": int(lqr.kbreak)},

@@ -105,29 +105,39 @@ class TrajectoryGather:
     24 M instance-steps/s and nb = 17 that is 42 GB/s per GPU = 27 % of a link, so the transfer hides behind compute except
     for the last chunk: exposed time ~ (bytes of one chunk) / link rate + the root's copies."""
 
-    def __init__(self, rank, world, n_local, T, nb, chunks, device, dtype=None, force_collective=False):
+    def __init__(self, rank, world, n_local, T, nb, chunks, device, dtype=None, force_collective=False, n_total=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         assert T % chunks == 0, "sim steps must be a multiple of the number of trajectory chunks"
         self.rank, self.world, self.n, self.T, self.nb, self.H, self.Tc = rank, world, n_local, T, nb, chunks, T // chunks
+        # shards: equal blocks of n_local (bench.py: weak scaling), or the contiguous blocks of shard_bounds(n_total) -- sizes then differ by at
+        # most one and every slab is padded to the largest, so that ONE fixed-size gather per chunk still moves everything
+        self.n_total = int(n_total) if n_total is not None else n_local * world
+        self.sizes = [n_local] * world if n_total is None else [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+        assert self.sizes[rank] == n_local, "n_local does not match this rank's shard of n_total"
+        self.nmax = max(self.sizes)
         self.device = device
         dtype = dtype or torch.float64
         self.cuda = device is not None and torch.device(device).type == "cuda"
         # force_collective: a single rank (world_size 1, process group initialised) really calls dist.gather -- the RCCL smoke test
         self.collective = world > 1 or force_collective
         self.gloo_on_gpu = self.cuda and self.collective and dist.get_backend() == "gloo"
-        self.slabs = [torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=device) for _ in range(2)]
-        self.out = torch.empty((n_local * world, T, nb, 13), dtype=dtype, device=device) if rank == 0 else None
+        self.slabs = [torch.empty((self.nmax, self.Tc, nb, 13), dtype=dtype, device=device) for _ in range(2)]
+        if self.nmax > n_local:
+            for sl in self.slabs:
+                sl[n_local:].zero_()          # the padding rows travel with every gather: defined bits, written once
+        self.out = torch.empty((self.n_total, T, nb, 13), dtype=dtype, device=device) if rank == 0 else None
         self.recv = None
         if rank == 0 and self.collective:
             rdev = "cpu" if self.gloo_on_gpu else device
-            self.recv = [[torch.empty((n_local, self.Tc, nb, 13), dtype=dtype, device=rdev) for _ in range(world)] for _ in range(2)]
+            self.recv = [[torch.empty((self.nmax, self.Tc, nb, 13), dtype=dtype, device=rdev) for _ in range(world)] for _ in range(2)]
         self.comm = torch.cuda.Stream(device=device) if self.cuda else None
         self.free_ev = [None, None]
         self.bytes_gathered = 0
 
     def slab(self, c):
+        """chunk c's slab: rows [0, n_local) are this rank's instances (the rollout launch writes them), the rest is padding"""
         return self.slabs[c % 2]
 
     def wait_slab_free(self, c):
@@ -151,15 +161,17 @@ class TrajectoryGather:
             ctx = contextlib.nullcontext()
         with ctx:
             if not self.collective:
-                self.out[:, t0:t1].copy_(slab)
+                self.out[:, t0:t1].copy_(slab[:self.n])
             else:
                 send = slab.cpu() if self.gloo_on_gpu else slab
                 bufs = self.recv[c % 2] if self.rank == 0 else None
                 dist.gather(send, bufs, dst=0)
                 self.bytes_gathered += slab.numel() * slab.element_size() * (self.world - 1) if self.rank == 0 else 0
                 if self.rank == 0:
+                    lo = 0
                     for r in range(self.world):
-                        self.out[r * self.n:(r + 1) * self.n, t0:t1].copy_(bufs[r], non_blocking=True)
+                        self.out[lo:lo + self.sizes[r], t0:t1].copy_(bufs[r][:self.sizes[r]], non_blocking=True)
+                        lo += self.sizes[r]
             if self.cuda:
                 ev = torch.cuda.Event()
                 ev.record(self.comm)
@@ -170,6 +182,33 @@ class TrajectoryGather:
         if self.cuda:
             self.torch.cuda.current_stream(self.device).wait_stream(self.comm)
         return self.out
+
+
+def collection_plan(rank, world, n_local, T, nb, chunks, record, collect, n_total=None, itemsize=8):
+    """Device bytes this rank allocates for one bench rollout and its collection, by purpose (bench.py prints rank 0's plan and refuses to
+    start when it exceeds the free HBM: the first 8-GPU run must fail with a sentence, not with an allocator error inside the timed region).
+    collect: "trajectory" = the recorded trajectories of all ranks are assembled on rank 0 (TrajectoryGather), "final" = only the final
+    states travel (RootGather) and every rank keeps its own trajectory."""
+    n_total = n_local * world if n_total is None else int(n_total)
+    sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+    nmax = max(sizes) if sizes else 0
+    row = nb * 13 * itemsize
+    plan = {"initial + final states, status, multipliers": (2 * n_local * row + 4 * chunks * n_local + (5 * nb * itemsize * n_local if chunks > 1 else 0))}
+    gathering = record and collect == "trajectory" and (world > 1 or chunks > 1)
+    if record and not gathering:
+        plan["own recorded trajectory [n_local][T][nb][13]"] = n_local * T * row
+    if gathering:
+        Tc = T // chunks
+        plan["two chunk slabs [nmax][T/chunks][nb][13]"] = 2 * nmax * Tc * row
+        if rank == 0:
+            plan["assembled Storage layout out[n_total][T][nb][13] (rank 0)"] = n_total * T * row
+            if world > 1:
+                plan["2 x world receive slabs (rank 0)"] = 2 * world * nmax * Tc * row
+    if world > 1:
+        plan["final-state gather: padded send block" + (", world receive blocks, assembled result (rank 0)" if rank == 0 else "")] = \
+            nmax * row + ((world * nmax + n_total) * row if rank == 0 else 0)
+    plan["total"] = sum(plan.values())
+    return plan
 
 
 def max_over_ranks(value, device=None):

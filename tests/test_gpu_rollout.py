@@ -444,6 +444,21 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert d["config"]["launches_per_rollout"] == 8 and d["newton"]["failed_instances"] == 0
     assert abs(d["value"] - 2 * 256 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["collection"]["trajectory_bytes_gathered_to_rank0_per_rollout"] == 256 * 64 * 17 * 13 * 8
+    assert d["collection"]["mode"] == "trajectory"
+    # the fallback collection mode -- only final states travel, every rank keeps its own trajectory, one launch per rollout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--collect", "final", "--instances", "256",
+                        "--sim-steps", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    f = json.loads([x for x in r.stdout.splitlines() if x.strip().startswith("{")][0])
+    assert f["n_gpus"] == 2 and f["collection"]["mode"] == "final" and f["collection"]["trajectory_bytes_gathered_to_rank0_per_rollout"] == 0
+    assert f["config"]["launches_per_rollout"] == 1 and f["config"]["record"] and f["newton"]["failed_instances"] == 0
+    assert "allocation plan (--collect final" in r.stderr
+    # item 4b: a run whose collection buffers cannot fit the free HBM is refused on every rank with a sentence and exit code 3, before any large
+    # allocation (2 x 65536 instances x 4000 steps x 17 bodies: 927 GB of assembled trajectories on rank 0)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--instances", "65536", "--sim-steps", "4000",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0 and "refusing to start" in r.stderr and "--collect final" in r.stderr, r.stderr[-3000:]
+    assert not [x for x in r.stdout.splitlines() if x.strip().startswith("{")]
 
 
 _RCCL_WORKER = r"""
