@@ -331,7 +331,7 @@ def newton_mode1_line(capi, torch, dev, mh, ctrl, z0_d, traj_exact, n_inst, T, n
                         "the headline value above is the exact stopping rule" % eps}
 
 
-def chain_rate(pkg, capi, torch, dev, n_links, n_inst, T):
+def chain_rate(pkg, capi, torch, dev, n_links, n_inst, T, count=True):
     """the headline workload's recipe for another chain length (north_star: "16-body chain mechanisms" = N = 15 links)"""
     ex, mech, zd, z0 = build_workload(pkg, n_links, n_inst, 0, 0)
     t = mech.tables()
@@ -341,69 +341,85 @@ def chain_rate(pkg, capi, torch, dev, n_links, n_inst, T):
     setup = time.time() - t0
     mh = mech._cclqr_handle
     ctrl = lq._ctrl_handle(mh)
-    lanes, _ = mh.geometry()
-    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, T, True, reps=2), lqr_construct_s=setup, riccati_kbreak=int(lq.kbreak),
-               kernel="rollout_chain_kernel<%d, %d, 0, false>" % (lanes, mh.layout_links()),
+    f = flops_per_instance_step(t, dict(ctrl_joint=lq.ctrl_joints, K=lq.K, N=lq.N, zd=lq.zd), z0, T) if count else None
+    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, T, True, reps=2, f_step=f, kernel=kernel_name(mh)), lqr_construct_s=setup, riccati_kbreak=int(lq.kbreak),
                workload="lqr_cartpole_n_pendulum N=%d links (%d bodies), hanging-equilibrium LQR, Q=I R=1 horizon %gs, y0~U(-0.5,0.5) phi_i~U(-0.2,0.2), "
                         "%d instances, record=true" % (n_links, t.nb, T * t.dt, n_inst))
     ctrl.close()
     return out
 
 
-def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
-    """not the headline: configs[1] (lqr_cartpole.jl, 4096 random-init instances, 1000 steps, record=true) through the same kernel,
-    and the rate of the setup path (linearsystem + Riccati recursion on fp64 MFMA) measured while building the headline LQR"""
+def cartpole_cfg2_workload(pkg, n=4096):
+    """configs[1]: lqr_cartpole.jl, n random-init instances, the LQR of the script; -> (mech, lqr, z0, seconds the construction took)"""
     ex = pkg.examples.cartpole_n(1)
     mech = ex["mech"]
     t0 = time.time()
     lq = pkg.LQR(mech, [1, 2], [3], ex["Q"], ex["R"], 10.0, xd=ex["xd"])
-    setup2 = time.time() - t0
+    setup = time.time() - t0
     rng = np.random.default_rng(0xC0FFEE)
-    n = 4096
-    z0 = pkg.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, n), rng.uniform(0, 1 / 3, (n, 1)))
+    z0 = pkg.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, 4096), rng.uniform(0, 1 / 3, (4096, 1)))
+    if n != 4096:
+        z0 = np.tile(z0, ((n + 4095) // 4096, 1, 1))[:n]
+    return mech, lq, z0, setup
+
+
+def sawyer_cfg4_workload(pkg, spread, n=8192):
+    """configs[3]: lqr_sawyer.jl, n arms with joint angles ~ U(-spread, spread) about the zero pose, the script's LQR"""
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "sawyer_arm_tables.json")))
+    ex = pkg.examples.sawyer(tab)
+    mech = ex["mech"]
+    t0 = time.time()
+    lq = pkg.LQR(mech, [pkg.getid(b) for b in mech.bodies], [pkg.getid(e) for e in mech.eqconstraints], ex["Q"], ex["R"], 20.0, xd=ex["xd"], qd=ex["qd"])
+    setup = time.time() - t0
+    rng = np.random.default_rng(4)
+    z_script = pkg.joint_position_states(mech, rng.uniform(-0.05, 0.05, (n, 7)))
+    z_in = pkg.joint_position_states(mech, rng.uniform(-0.002, 0.002, (n, 7)))
+    return mech, lq, (z_script if spread >= 0.05 else z_in), setup, rng
+
+
+def tracking_cfg5_workload(pkg):
+    """configs[4]: trackingLQR_triple_cartpole.jl -- swing-up replay of the script's U, TrackingLQR about it, friction + Philox noise"""
+    U = np.load(os.path.join(ROOT, "tests", "golden", "triple_cartpole_U.npy"))
+    ex = pkg.examples.triple_cartpole()
+    mech = ex["mech"]
+    j1 = ex["ctrl"][0]
+    z00 = mech.state()          # the zero pose every instance starts from (taken BEFORE the swing-up replay moves the mechanism)
+    t0 = time.time()
+    s0 = pkg.simulate(mech, pkg.Storage(1000, 4), pkg.OpenLoop(mech, [j1.id], U.reshape(1000, 1)))
+    tl = pkg.TrackingLQR(mech, s0, [[[U[k]]] for k in range(1000)], [j1.id], ex["Q"], ex["R"])
+    setup = time.time() - t0
+    octrl = dict(ctrl_joint=tl.ctrl_joints, K=tl.K, N=tl.N, zd=tl.zd, Fd=tl.Fd, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+    return mech, tl, ex, octrl, setup, z00
+
+
+def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
+    """not the headline: the other BASELINE configs through the same C-ABI, each with its workload string, its kernel, the kernel's duration by
+    HIP events and -- unless --no-cpu-baseline -- the fp64 roofline fraction from flops counted by the instrumented oracle on that workload
+    (VERDICT r3 item 2); and the rate of the setup path measured while building the headline LQR"""
+    count = not args.no_cpu_baseline
+    mech, lq, z0, setup2 = cartpole_cfg2_workload(pkg)
+    t = mech.tables()
     mh = mech._cclqr_handle
     ctrl = lq._ctrl_handle(mh)
-    z0_d = torch.from_numpy(z0).to(dev)
-    zT_d = torch.empty_like(z0_d)
-    st_d = torch.zeros(n, dtype=torch.int32, device=dev)
-    traj_d = torch.empty((n, 1000, 2, 13), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    run = lambda: capi.rollout_dev(mh, ctrl, n, 1000, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr(), zT_d.data_ptr(), st_d.data_ptr(), stream)
-    run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
-    dt2 = (time.perf_counter() - t0) / 5
+    f2 = flops_per_instance_step(t, dict(ctrl_joint=lq.ctrl_joints, K=lq.K, N=lq.N, zd=lq.zd), z0, 1000, n_sample=16) if count else None
+    n = len(z0)
+    c2 = _timed_rollout(capi, torch, dev, mh, ctrl, z0, 1000, True, reps=5, f_step=f2, kernel=kernel_name(mh))
     # the same mechanism with the device filled (4096 instances at eight per wavefront are 512 wavefronts on 1024 SIMDs)
-    n16 = 16 * n
-    z16_d = z0_d.repeat(16, 1, 1)
-    zT16_d = torch.empty_like(z16_d)
-    st16_d = torch.zeros(n16, dtype=torch.int32, device=dev)
-    run16 = lambda: capi.rollout_dev(mh, ctrl, n16, 1000, 1, z16_d.data_ptr(), 0, 0, 0, 0, zT16_d.data_ptr(), st16_d.data_ptr(), stream)
-    run16()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        run16()
-    torch.cuda.synchronize()
-    dt16 = (time.perf_counter() - t0) / 3
-    ok16 = bool((st16_d > 0).all().item())
+    c2f = _timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z0, (16, 1, 1)), 1000, False, reps=3, f_step=f2, kernel=kernel_name(mh))
+    ctrl.close()
     more = {}
     try:
         if args.links == 16 and args.instances >= 1024:     # the default headline run: the 16-BODY chain (N = 15) next to the 17-body one
-            more["chain_16_bodies_N15"] = chain_rate(pkg, capi, torch, dev, 15, args.instances, args.sim_steps)
-        more.update(other_configs(pkg, capi, torch, dev))
+            more["chain_16_bodies_N15"] = chain_rate(pkg, capi, torch, dev, 15, args.instances, args.sim_steps, count)
+        more.update(other_configs(pkg, capi, torch, dev, count))
     except Exception as e:        # the extra lines never take the headline line down with them
         more["other_configs_error"] = repr(e)
     m = mu + ml
     f_ric = 4 * mx ** 3 + 4 * mx ** 2 * m + 2 * mx * (ml ** 2 + m ** 2) + 2 / 3 * m ** 3 + 2 / 3 * ml ** 3    # SURVEY 8a row a5
     nsteps = T - max(int(lqr.kbreak), 1)
-    return {"cartpole_cfg2": {"workload": "lqr_cartpole.jl (configs[1]): 4096 cartpoles, y0~U(-0.5,0.5) phi0~U(0,1/3), Q=I R=1 horizon 10 s, record=true",
-                              "instances": n, "sim_steps": 1000, "value": n * 1000 / dt2, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt2,
-                              "lqr_construct_s": setup2, "riccati_kbreak": int(lq.kbreak),
-                              "device_filled": {"instances": n16, "record": False, "value": (n16 * 1000 / dt16) if ok16 else None, "ms_per_rollout": 1e3 * dt16}},
+    return {"cartpole_cfg2": dict(c2, workload="lqr_cartpole.jl (configs[1]): 4096 cartpoles, y0~U(-0.5,0.5) phi0~U(0,1/3), Q=I R=1 horizon 10 s, record=true",
+                                  lqr_construct_s=setup2, riccati_kbreak=int(lq.kbreak),
+                                  device_filled=dict(c2f, workload="the same 4096 starts tiled 16 times: 65536 instances, record=false")),
             **more,
             "riccati_setup": {"mx": mx, "backward_steps": nsteps, "flops_per_step": f_ric,
                               "note": "LQR construction of the headline workload = linearize + %d-step recursion (projected form, tiled over the device, fp64 MFMA); "
@@ -411,7 +427,30 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
                               "gflops_lower_bound": f_ric * nsteps / setup_s / 1e9, "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}}
 
 
-def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_failed=False):
+def kernel_name(mh, extra=0):
+    """the instantiation a mechanism's rollouts run (extra: 0 plain LQR / TrackingLQR law, 1 + friction and noise, 2 + PID)"""
+    lanes, _ = mh.geometry()
+    return "rollout_chain_kernel<%d, %d, %d, false>" % (lanes, mh.layout_links(), extra)
+
+
+def flops_per_instance_step(t, octrl_kw, z0, steps, n_sample=4):
+    """fp64 flops of one instance-step of a workload, counted by the instrumented build of the oracle (the checker, never the product) on an
+    n_sample-instance x <= 200-step sample of the same inputs (F_step is counted, not estimated)"""
+    from oracle import orc
+    sample_steps = min(steps, 200)
+    orc.flops_reset()
+    orc.rollout(t, orc.ctrl_desc(t.nb, **octrl_kw), z0[:n_sample], sample_steps, nthreads=1, flops=True)
+    return orc.flops_get() / (float(min(n_sample, len(z0))) * sample_steps)
+
+
+def roofline_fp64(f_step, n, steps, kernel_ms, kernel):
+    """the binding roofline of the rollout kernels (fp64 vector ALU): counted flops per launch / the launch's duration by HIP events"""
+    tf = f_step * float(n) * steps / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+            "flops_per_instance_step_counted_by_oracle": f_step, "kernel": kernel, "kernel_ms": kernel_ms}
+
+
+def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_failed=False, f_step=None, kernel=None):
     n, nb = z0.shape[0], z0.shape[1]
     z0_d = torch.from_numpy(np.ascontiguousarray(z0)).to(dev)
     zT_d = torch.empty_like(z0_d)
@@ -421,20 +460,26 @@ def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_
     run = lambda: capi.rollout_dev(mh, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(), st_d.data_ptr(), stream)
     run()
     torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
+    for a, b in ev:
+        a.record(); run(); b.record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # (a noise_philox controller's launch includes its Philox fill kernel)
     bad = int((st_d <= 0).sum().item())
     out = {"instances": n, "sim_steps": steps, "record": bool(record), "value": (n * steps / dt) if bad == 0 else None, "unit": "instance-steps/s",
-           "ms_per_rollout": 1e3 * dt, "failed_instances": bad}
+           "ms_per_rollout": 1e3 * dt, "failed_instances": bad, "kernel_ms": kernel_ms}
+    if kernel:
+        out["kernel"] = kernel
+    if f_step is not None and bad == 0:
+        out["roofline_fp64_valu"] = roofline_fp64(f_step, n, steps, kernel_ms, kernel)
     if bad and allow_failed:      # a rate over rollouts that partly left the integrator's domain is NOT a throughput: labelled, never `value`
         out["attempted_instance_steps_per_s_incl_failed"] = n * steps / dt
     return out
 
 
-def other_configs(pkg, capi, torch, dev):
+def other_configs(pkg, capi, torch, dev, count=True):
     """BASELINE configs[3] and configs[4] at their full sizes through the same C-ABI (not the headline; one entry each, every entry names
     its workload).  lqr_sawyer.jl: 8192 seven-joint arms, horizon 20 s, (a) at SURVEY 8d's joint angles ~ U(-0.05, 0.05) about the zero
     pose -- about 30 % of these starts leave the script controller's region of attraction ("Currently somewhat broken",
@@ -442,25 +487,21 @@ def other_configs(pkg, capi, torch, dev):
     start converges; (c) with a setpoint PER INSTANCE: 8192 distinct infinite-horizon LQRs built on the device in one call.
     trackingLQR_triple_cartpole.jl: 16384 instances, TrackingLQR about the swing-up of the script's own input U, friction + Philox cart noise."""
     out = {}
-    gold = os.path.join(ROOT, "tests", "golden")
-    tab = json.load(open(os.path.join(gold, "sawyer_arm_tables.json")))
-    ex = pkg.examples.sawyer(tab)
-    mech = ex["mech"]
-    t0 = time.time()
-    lq = pkg.LQR(mech, [pkg.getid(b) for b in mech.bodies], [pkg.getid(e) for e in mech.eqconstraints], ex["Q"], ex["R"], 20.0, xd=ex["xd"], qd=ex["qd"])
-    setup = time.time() - t0
+    n = 8192
+    mech, lq, z_script, setup, rng = sawyer_cfg4_workload(pkg, 0.05, n)
+    z_in = pkg.joint_position_states(mech, rng.uniform(-0.002, 0.002, (n, 7)))
+    t = mech.tables()
     mh = mech._cclqr_handle
     ctrl = lq._ctrl_handle(mh)
-    n = 8192
-    rng = np.random.default_rng(4)
-    z_script = pkg.joint_position_states(mech, rng.uniform(-0.05, 0.05, (n, 7)))
-    out["sawyer_cfg4"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z_script, 2000, False, allow_failed=True), lqr_construct_s=setup,
+    kern = kernel_name(mh)
+    f4 = flops_per_instance_step(t, dict(ctrl_joint=lq.ctrl_joints, K=lq.K, N=lq.N, zd=lq.zd), z_in, 2000) if count else None
+    out["sawyer_cfg4"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z_script, 2000, False, allow_failed=True, kernel=kern), lqr_construct_s=setup,
                               riccati_kbreak=int(lq.kbreak),
                               workload="lqr_sawyer.jl (configs[3]): 8192 Sawyer arms, joint angles ~ U(-0.05, 0.05) rad about the zero pose (SURVEY 8d), "
                                        "Q=1000 I R=1 g=0 horizon 20 s, 2000 steps; starts outside the script controller's region of attraction are frozen "
                                        "and flagged (the oracle loses the same set: tests/test_gpu_fullsize.py)")
-    z_in = pkg.joint_position_states(mech, rng.uniform(-0.002, 0.002, (n, 7)))
-    out["sawyer_cfg4_inside_region_of_attraction"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z_in, 2000, False), workload="the same with joint angles ~ U(-0.002, 0.002) rad: every start converges")
+    out["sawyer_cfg4_inside_region_of_attraction"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z_in, 2000, False, f_step=f4, kernel=kern),
+                                                          workload="the same with joint angles ~ U(-0.002, 0.002) rad: every start converges")
     ctrl.close()
     # the same arm with a setpoint PER INSTANCE (SURVEY 8d configs[3]: "Riccati run per instance on distinct setpoints"): 8192 poses, ONE
     # batched infinite-horizon LQR construction on the device (linearsystem + dlqr of up to 999 backward steps each + per-instance tables;
@@ -479,7 +520,7 @@ def other_configs(pkg, capi, torch, dev):
     m = 7 + 35
     f_ric = 4 * 84 ** 3 + 4 * 84 ** 2 * m + 2 * 84 * (35 ** 2 + m ** 2) + 2 / 3 * m ** 3 + 2 / 3 * 35 ** 3
     out["sawyer_cfg4_setpoint_per_instance"] = dict(
-        _timed_rollout(capi, torch, dev, mh, bl, z0b, 2000, False), batched_lqr_construct_s=setup_b, gain_table_bytes_in_hbm=int(n) * 7 * 84 * 8,
+        _timed_rollout(capi, torch, dev, mh, bl, z0b, 2000, False, f_step=f4, kernel=kern), batched_lqr_construct_s=setup_b, gain_table_bytes_in_hbm=int(n) * 7 * 84 * 8,
         riccati_kbreak_min_max=[int(kb.min()), int(kb.max())], riccati_not_converged=int((kb <= 1).sum()), riccati_backward_steps_total=steps_run,
         riccati_tflops_lower_bound_incl_linearize_and_copies=f_ric * steps_run / setup_b / 1e12,
         riccati_gains_per_s=int(n) / setup_b,      # LQR constructions (linearsystem + dlqr to convergence) per second, whole call
@@ -487,18 +528,11 @@ def other_configs(pkg, capi, torch, dev):
                  "cclqr_ctrl_create_lqr_batch(infinite_horizon) = 8192 linearsystem + 8192 dlqr (mx 84, mu 7, ml 35, <= 1999 steps, fp64 MFMA), "
                  "starts within 0.002 rad of the setpoint, 2000 steps")
     bl.close()
-    U = np.load(os.path.join(gold, "triple_cartpole_U.npy"))
-    ex = pkg.examples.triple_cartpole()
-    mech = ex["mech"]
-    j1 = ex["ctrl"][0]
-    z00 = mech.state()
-    t0 = time.time()
-    s0 = pkg.simulate(mech, pkg.Storage(1000, 4), pkg.OpenLoop(mech, [j1.id], U.reshape(1000, 1)))
-    tl = pkg.TrackingLQR(mech, s0, [[[U[k]]] for k in range(1000)], [j1.id], ex["Q"], ex["R"])
-    setup = time.time() - t0
+    mech, tl, ex, octrl5, setup, z00 = tracking_cfg5_workload(pkg)
     mh = mech._cclqr_handle
     ctrl = tl._ctrl_handle(mh, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
-    out["triple_cartpole_tracking_cfg5"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z00, (16384, 1, 1)), 1000, True),
+    f5 = flops_per_instance_step(mech.tables(), octrl5, np.tile(z00, (4, 1, 1)), 1000) if count else None
+    out["triple_cartpole_tracking_cfg5"] = dict(_timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z00, (16384, 1, 1)), 1000, True, f_step=f5, kernel=kernel_name(mh, 1)),
                                                 swingup_plus_trackinglqr_construct_s=setup,
                                                 workload="trackingLQR_triple_cartpole.jl (configs[4]): 16384 triple cartpoles from the zero pose, TrackingLQR about the "
                                                          "swing-up of the script's input U (999 knots linearised + time-varying dlqr on the device), friction 0.1 + "
@@ -573,14 +607,8 @@ def build_native_oracle():
 
 
 def count_flops(pkg, t, lqr, z0, T):
-    """fp64 flops of one instance-step of this workload, counted by the instrumented build of the oracle (the checker, never the
-    product) on a 4-instance x 200-step sample of the same inputs"""
-    from oracle import orc
-    octrl = orc.ctrl_desc(t.nb, lqr.ctrl_joints, K=lqr.K, N=lqr.N, zd=lqr.zd)
-    sample_steps = min(T, 200)
-    orc.flops_reset()
-    orc.rollout(t, octrl, z0[:4], sample_steps, nthreads=1, flops=True)
-    return orc.flops_get() / (4.0 * sample_steps)
+    """fp64 flops of one instance-step of the headline workload (flops_per_instance_step on its LQR)"""
+    return flops_per_instance_step(t, dict(ctrl_joint=lqr.ctrl_joints, K=lqr.K, N=lqr.N, zd=lqr.zd), z0, T)
 
 
 def cpu_baseline(pkg, t, lqr, z0, T):
