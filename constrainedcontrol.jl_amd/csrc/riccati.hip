@@ -207,6 +207,8 @@ struct RicGrid {
                        // lqr.jl:179-181 = the one gain LQR{T,Inf} keeps, lqr.jl:40-43); 0: the whole table K [nprob][N-1][mu][mx]
     int bf16_terms;    // 0: fp64 MFMA (parity mode); 1..3: the two mx^3 products of a backward step on bf16 MFMA with fp32 accumulation,
                        // every fp64 operand split into that many bf16 terms (measured-error mode, BASELINE configs[3]; tiled path only)
+    unsigned char pp_mask[8];   // resident kernel, register-fragment form: bit ct of pp_mask[w] = wavefront w computes the 16x16 tile (its own
+                                // row strip, column tile ct) of the SYMMETRIC Pkp1 and mirrors it (ric_pp_assign)
 };
 
 template <bool LDSM>
@@ -685,9 +687,13 @@ __device__ inline void ric_wave_tiles(int wave, int C, int T, int* col, int* lo,
     }
 }
 
+// the (inputs, states) shapes that have a register-fragment instantiation of riccati_resident_kernel (launch_riccati picks it): the BASELINE mechanisms
+static bool ric_resident_is_frag(int mx, int mu) { return (mu == 1 && (mx == 12 || mx == 24 || mx == 48)) || (mu == 7 && mx == 84); }
+#define RIC_YB 128      // doubles of a wavefront's private transposition buffer for Y = Abar' W_D (16 rows x 8 inputs), register-fragment form only
 size_t ric_resident_lds_bytes(int mx, int mu) {
     const size_t na = (size_t)mx + mu;
-    return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2) * sizeof(double) + (mu + 2) * sizeof(int);
+    return ((size_t)mx * mx + mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2 +
+            (ric_resident_is_frag(mx, mu) ? (size_t)RIC_WAVES * RIC_YB : 0)) * sizeof(double) + (mu + 2) * sizeof(int);
 }
 
 // MUT: the number of inputs as a compile-time constant (1 .. RIC_MU_REG: the mu x mu system is solved in registers, gain_in_registers), or 0:
@@ -761,7 +767,10 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
     lds_double* S = TS + (size_t)mu * na;
     lds_double* Rl = S + (size_t)mu * mu;
     lds_double* red = Rl + (size_t)mu * mu;
-    int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2));
+    lds_double* Yb = red + 2 * RIC_WAVES + 2 + (size_t)wave * RIC_YB;      // (register-fragment form) this wavefront's transposition buffer
+    int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2 +
+                            (NGT > 0 ? (size_t)RIC_WAVES * RIC_YB : 0)));
+    static_assert(NGT == 0 || (MUT >= 1 && MUT <= 8), "the register-fragment form keeps Y = Abar' W_D of a row strip as 16 x 8 doubles");
     double* Kout = a.K + (size_t)prob * (a.keep_last ? 1 : (N > 1 ? N - 1 : 0)) * mu * mx;
     if (tid == 0) sing = 0;
     for (int e = tid; e < mx * mx; e += RIC_THREADS) P[e] = a.Q[e];       // Pk = Q                                  lqr.jl:147
@@ -783,13 +792,22 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
     RicBf16Frag<BF, NGF> fsplit;         // the fragment's bf16 terms (BF > 0 only)
     double* Abar = a.Abar + (size_t)prob * mx * mx;      // scratch of the streaming form (NGT = 0)
     int k = 0, status = 0;
-    for (k = N - 1; k >= 1; k--) {                                        // for outer k=N-1:-1:1                    lqr.jl:150
-        const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
-        for (int e = tid; e < mx * mu; e += RIC_THREADS) Dl[e] = AD[(size_t)(e / mu) * na + mx + e % mu];
+    // the step's operands from L2 -- D into LDS, the wavefront's [A'|D] fragment into registers -- are fetched at the END of the step before (as soon
+    // as the Pkp1 tiles have consumed the Abar the fragment registers held), so that their round trip runs under the norm reduction and the barriers
+    auto fetch_operands = [&](int kk) {
+        const double* ADk = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? kk - 1 : 0)) * mx * na;
+        for (int e = tid; e < mx * mu; e += RIC_THREADS) Dl[e] = ADk[(size_t)(e / mu) * na + mx + e % mu];
         if (NGT > 0) {
 #pragma unroll
-            for (int g = 0; g < NGF; g++) frag[g] = col >= 0 ? AD[(size_t)(4 * g + lk) * na + cjc] : 0.0;
-            if (BF > 0) fsplit.split(frag);
+            for (int g = 0; g < NGF; g++) frag[g] = col >= 0 ? ADk[(size_t)(4 * g + lk) * na + cjc] : 0.0;
+        }
+    };
+    if (N - 1 >= 1 && BF == 0) fetch_operands(N - 1);
+    for (k = N - 1; k >= 1; k--) {                                        // for outer k=N-1:-1:1                    lqr.jl:150
+        const double* AD = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? k - 1 : 0)) * mx * na;
+        if (BF > 0) {                    // (the bf16 measured-error modes fetch at the top of the step: no registers to carry the fragment across the norm)
+            fetch_operands(k);
+            if (NGT > 0) fsplit.split(frag);
         }
         if (NGT > 0) {
             // W = Pk [A' | D]   (Pk symmetric): the wavefront's column block, its share of the row tiles; A operand from LDS, B from registers
@@ -897,7 +915,10 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         if (NGT > 0) {
             // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169): the wavefront's column strip of it, as the
             // MFMA fragment Abar[4 g + lk][cj], from the A' fragment it already holds (never written to memory)
-            // W_A' -= W_D Ku on the matrix core: a rank-mu update, ceil(mu / 4) MFMAs per 16x16 tile with the tile itself as the accumulator
+            // W_A' -= W_D Ku on the matrix core: a rank-mu update, ceil(mu / 4) MFMAs per 16x16 tile with the tile itself as the accumulator.
+            // fp64 form (BF = 0): NOT done -- the Pkp1 tiles below take Abar'(Pk Abar) = Abar' W_A' - (Abar' W_D) Ku with Y = Abar' W_D of the wavefront's
+            // own row strip (21 MFMAs, no other wavefront's data), which removes this read-modify-write of all of W_A' and the barrier behind it
+            if (BF > 0)
             for (int tile = wave; tile < t16m * t16m; tile += RIC_WAVES) {
                 const int i0 = (tile / t16m) << 4, j0 = (tile % t16m) << 4;
                 const bool iok = i0 + li < mx, jok = j0 + li < mx;
@@ -924,7 +945,9 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                     v4d acc;
 #pragma unroll
                     for (int r = 0; r < 4; r++) acc[r] = (4 * T + r) < NGF ? frag[(4 * T + r) < NGF ? 4 * T + r : 0] : 0.0;
-                    const int dr = (16 * T + li < mx) ? 16 * T + li : mx - 1;
+                    // (row 16 T + li of D, unclamped: the rows past mx of the last tile read on into Ku's region of the image and feed accumulator rows
+                    // that belong to no fragment element -- one base address + immediate offsets instead of a clamped address per tile)
+                    const int dr = 16 * T + li;
                     for (int q0 = 0; q0 < mu; q0 += 4) {
                         const int q = q0 + lk;
                         const double av = q < mu ? -Dl[dr * mu + q] : 0.0, bv = q < mu ? Ku[q * mx + cic] : 0.0;
@@ -934,6 +957,16 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                     for (int r = 0; r < 4; r++) if ((4 * T + r) < NGF) frag[4 * T + r] = acc[r];
                 }
                 if (BF > 0) fsplit.split(frag);
+                if (BF == 0) {       // Y = Abar' W_D of this row strip, through the wavefront's own buffer into A-operand layout: Yb[i][q], i < 16, q < 8
+                    v4d yacc = {0.0, 0.0, 0.0, 0.0};
+                    const lds_double* pwd = W + lk * na + mx + (li < mu ? li : mu - 1);
+#pragma unroll
+                    for (int g = 0; g < NGF; g++) yacc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[g], pwd[g * 4 * na], yacc, 0, 0, 0);
+                    if (li < 8) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Yb[(lk + 4 * r) * 8 + li] = yacc[r];
+                    }
+                }
             }
         } else {
             // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169) -> global scratch
@@ -956,24 +989,34 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
         }
-        __syncthreads();
+        if (!(NGT > 0 && BF == 0)) __syncthreads();      // (fp64 register-fragment form: everything since the gain has been the wavefront's own)
         RSTAMP(RP_UPD);
         // Pkp1 = Q + Kuk'*R*Kuk + Abar'*(Pk*Abar), over Pk; |Pk - Pkp1|^2 on the way                                lqr.jl:170-176
         double nacc = 0.0;
         if (NGT > 0) {
-            if (pp_col) {        // row strip i0 = col * 16 of Pkp1: A operand from registers (Abar fragment), B operand Pk Abar from LDS
+            if (pp_col) {        // tiles (row strip i0 = col * 16, column tile ct) of the SYMMETRIC Pkp1 that ric_pp_assign dealt to this wavefront, each
+                                 // mirrored into (ct, col): A operand from registers (Abar fragment), B operand Pk Abar from LDS
                 const int i0 = col << 4;
-                for (int ct = tlo; ct < thi; ct++) {
+                // (the bf16 measured-error modes keep the whole strip, unmirrored: they sit at exactly 256 registers)
+                const unsigned ppm = BF > 0 ? (((1u << thi) - 1u) & ~((1u << tlo) - 1u)) : a.pp_mask[wave];
+#pragma unroll 1
+                for (int ct = 0; ct < t16m; ct++) {      // (not unrolled: six tiles' worth of hoisted LDS addresses cost the kernel its 256-register budget)
+                    if (!((ppm >> ct) & 1u)) continue;
                     const int j0 = ct << 4;
-                    const bool jok = j0 + li < mx;
+                    const bool jok = j0 + li < mx, offdiag = BF == 0 && ct != col;
                     const int jc = jok ? j0 + li : mx - 1;
                     const lds_double* pb = W + lk * na + jc;
                     double qv[4];                     // Q of the tile's outputs, fetched BEFORE the MFMAs: its L2 round trip hides under them
+                    if (BF == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const int i = i0 + (BF > 0 ? 4 * lk + r : lk + 4 * r); qv[r] = a.Q[(size_t)(i < mx ? i : mx - 1) * mx + jc]; }
+                        for (int r = 0; r < 4; r++) { const int i = i0 + lk + 4 * r; qv[r] = a.Q[(size_t)(i < mx ? i : mx - 1) * mx + jc]; }
+                    }
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
-                    if (BF > 0) acc = ric_tile_bf16<BF, NGF, true>(fsplit, pb, 4 * na);
-                    else {
+                    if (BF > 0) {                     // (measured-error mode: Q is fetched behind the tile -- the split fragments leave no registers to hold it)
+                        acc = ric_tile_bf16<BF, NGF, true>(fsplit, pb, 4 * na);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { const int i = i0 + 4 * lk + r; qv[r] = a.Q[(size_t)(i < mx ? i : mx - 1) * mx + jc]; }
+                    } else {
                         // Q + Kuk'*(R*Kuk) + Abar'*(Pk*Abar) in ONE accumulation chain: Q is the initial accumulator, the rank-mu term
                         // ceil(mu / 4) more k-groups (A = Ku[q][i], B = (R Ku)[q][j])
 #pragma unroll
@@ -982,6 +1025,11 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                         for (int q0 = 0; q0 < mu; q0 += 4) {
                             const int q = q0 + lk;
                             const double av = q < mu ? Ku[q * mx + ia] : 0.0, bv = q < mu ? KRK[q * mx + jc] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                        }
+                        for (int q0 = 0; q0 < mu; q0 += 4) {      // - (Abar' W_D) Ku: the rank-mu part of Abar'(Pk Abar), W_A' itself is the B operand below
+                            const int q = q0 + lk;
+                            const double av = q < mu ? -Yb[li * 8 + q] : 0.0, bv = q < mu ? Ku[q * mx + jc] : 0.0;
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                         }
 #pragma unroll
@@ -998,6 +1046,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                                 const double d = P[i * mx + j] - v;
                                 nacc += d * d;
                                 P[i * mx + j] = v;     // Pk = Pkp1 (lqr.jl:176); after a break nothing reads Pk again
+                                if (offdiag) { const double dm = P[j * mx + i] - v; nacc += dm * dm; P[j * mx + i] = v; }      // the mirrored entry
                             }
                         }
                     }
@@ -1025,6 +1074,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
         }
+        if (k > 1 && BF == 0) fetch_operands(k - 1);      // (D's LDS copy was last read by the update phase, the fragment by the tiles above)
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_xor(nacc, o, 64);
         if (lane == 0) red[wave] = nacc;
         __syncthreads();
@@ -1097,9 +1147,46 @@ static bool ric_use_tiled(const RicArgs& a) {
 
 size_t ric_total_work_doubles(const RicArgs& a) { return ric_grid_work_doubles(a.nprob, a.mx, a.mu, a.ml, a.N, a.time_varying); }
 
+// Pkp1 = Q + Ku'RKu + Abar'(Pk Abar) is symmetric, so of its T x T tiles of 16 x 16 only the T (T + 1) / 2 with column tile >= row tile are
+// computed (and mirrored): 21 instead of 36 for the Sawyer's 84 states.  A tile's A operand is the Abar fragment of the wavefront that owns the
+// tile's ROW strip (ric_wave_tiles), so the pair {a, b} can go to an owner of strip a (as tile (a, b)) or of strip b (as (b, a)): dealt greedily so
+// that the four SIMDs (wavefronts w and w + 4 share one) carry equal numbers of tiles -- Sawyer: 5 / 5 / 6 / 5 tiles per SIMD instead of 9 each.
+static void ric_pp_assign(int T, int C, unsigned char* mask) {
+    const int Wv = RIC_WAVES;
+    int first[16], cnt[16], wl[RIC_WAVES] = {0};
+    for (int w = 0; w < Wv; w++) mask[w] = 0;
+    if (C > Wv || C > 16 || T > 8 || T > C) return;
+    {
+        const int base = Wv / C, extra = Wv % C;       // = ric_wave_tiles: the LAST `extra` column blocks get one wavefront more
+        int w = 0;
+        for (int c = 0; c < C; c++) { cnt[c] = base + (c >= C - extra ? 1 : 0); first[c] = w; w += cnt[c]; }
+    }
+    struct Item { int a, b, owners; } items[36];
+    int n = 0;
+    for (int a = 0; a < T; a++)
+        for (int b = a; b < T; b++) items[n++] = {a, b, cnt[a] + (b != a ? cnt[b] : 0)};
+    for (int i = 1; i < n; i++)                         // stable insertion sort: the pairs with the fewest possible owners first
+        for (int j = i; j > 0 && items[j].owners < items[j - 1].owners; j--) { const Item t = items[j]; items[j] = items[j - 1]; items[j - 1] = t; }
+    for (int i = 0; i < n; i++) {
+        int bw = -1, bc = 0, bs = 1 << 30, bl = 1 << 30;
+        for (int side = 0; side < (items[i].b != items[i].a ? 2 : 1); side++) {
+            const int strip = side ? items[i].b : items[i].a, colt = side ? items[i].a : items[i].b;
+            for (int w = first[strip]; w < first[strip] + cnt[strip]; w++) {
+                int sl = 1;
+                for (int x = w % 4; x < Wv; x += 4) sl += wl[x];          // tiles on the wavefront's SIMD if it takes this one
+                const int l = wl[w] + 1;
+                if (sl < bs || (sl == bs && l < bl)) { bs = sl; bl = l; bw = w; bc = colt; }
+            }
+        }
+        wl[bw]++;
+        mask[bw] |= (unsigned char)(1u << bc);
+    }
+}
+
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     if (a.nprob <= 0) return hipSuccess;
     RicGrid g;
+    ric_pp_assign((a.mx + 15) / 16, (a.mx + a.mu + 15) / 16, g.pp_mask);
     g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
     g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms; g.keep_last = a.keep_last;
     g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = a.stop;
