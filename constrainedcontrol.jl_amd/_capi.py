@@ -171,7 +171,7 @@ class CtrlHandle:
         nsp = zd.shape[0] // nc
         Fd = f64(np.zeros((nc * nsp, mu)) if Fd is None else Fd).reshape(nc * nsp, mu)
         K = None if K is None else f64(K).reshape(-1, mu, 12 * nb)
-        fric = None if fric is None else f64(fric).reshape(nb)
+        fric = None if fric is None else f64(fric).reshape(mech.tables.ne)          # one entry per joint (ne == nb on a tree)
         pj = pP = pI = pD = pg = None
         if pid is not None:
             pj, pP, pI, pD, pg = i32(pid["joint"]).reshape(-1), f64(pid["P"]).reshape(-1), f64(pid["I"]).reshape(-1), f64(pid["D"]).reshape(-1), f64(pid["goal"]).reshape(-1)

@@ -319,13 +319,13 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     const int newton_mode = opts ? opts->newton_mode : 0;
     a.eps_alone = (opts && opts->newton_eps_alone > 0.0) ? opts->newton_eps_alone : 1e-10;
     if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");
-    if (newton_mode != 0 && (m->host.loop || m->host.tree || extra != 0))
-        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists for forests of chains under the plain LQR / TrackingLQR law only");
-    if (m->host.loop) {      // closed loops: plain LQR law only (build_ctrl_tables refuses the others)
-        if (extra != 0 || noise) return fail(CCLQR_EUNSUPPORTED, "closed-loop mechanisms take the plain LQR law only");
-        HIPCHK(launch_rollout_loop(a, m->nb, m->nj, (hipStream_t)stream));
+    if (m->host.loop) {      // closed loops: LQR / TrackingLQR law, friction, noise, newton_mode 1; no PID (build_ctrl_tables refuses it)
+        if (extra == 2) return fail(CCLQR_EUNSUPPORTED, "closed-loop mechanisms take no PID law");
+        HIPCHK(launch_rollout_loop(a, m->nb, m->nj, newton_mode, (hipStream_t)stream));
         return CCLQR_OK;
     }
+    if (newton_mode != 0 && (m->host.tree || extra != 0))
+        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists for forests of chains under the plain LQR / TrackingLQR law (and for closed-loop mechanisms) only");
     HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, newton_mode, (hipStream_t)stream));
     return CCLQR_OK;
 }

@@ -41,7 +41,7 @@ size_t chain_lds_bytes(int nb);
 hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream);
 // closed-loop mechanisms (rollout_loop.hip)
 size_t loop_lds_bytes(int nb, int nj);
-hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, hipStream_t stream);
+hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, int newton_mode, hipStream_t stream);
 
 struct LinArgs {
     const MechDev* M;

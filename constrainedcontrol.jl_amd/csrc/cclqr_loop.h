@@ -53,6 +53,26 @@ HD void loop_load_consts(LaneRegs& r, const MechDev* M, int t) {
     r.pid_int = 0.0; r.pid_last = 0.0;
 }
 
+// passive friction of joint t (examples/trackingLQR_triple_cartpole.jl:93-101: -fric * relative joint velocity along the axis), the law of
+// ck_friction / ph_control_error on a mechanism whose joints and bodies are separate index sets; a FixedOrientation constraint has none
+HD double lp_friction(int t, const Lay& Y, const double* L, const LaneRegs& r, const MechDev* M, double fric) {
+    if (t >= M->nj || r.type > 1 || fric == 0.0) return 0.0;
+    const int a = r.parent, b = r.childl;
+    const double* zb = L + Y.Z + 13 * b;
+    double rel;
+    if (r.type == 0) {
+        rel = r.axis[0] * zb[10] + r.axis[1] * zb[11] + r.axis[2] * zb[12];
+        if (a >= 0) { const double* za = L + Y.Z + 13 * a; rel -= r.axis[0] * za[10] + r.axis[1] * za[11] + r.axis[2] * za[12]; }
+    } else {
+        double dv[3], dva[3], Ra[9];
+        for (int i = 0; i < 3; i++) dv[i] = zb[7 + i] - (a >= 0 ? L[Y.Z + 13 * a + 7 + i] : 0.0);
+        rotmat(a >= 0 ? L + Y.Z + 13 * a + 3 : QID_, Ra);
+        mtv3(Ra, dv, dva);
+        rel = r.axis[0] * dva[0] + r.axis[1] * dva[1] + r.axis[2] * dva[2];
+    }
+    return -fric * rel;
+}
+
 // F1: joint inputs -> force / torque on body t (SURVEY 8a-bis 'Joint input': a revolute applies +-u axis as a torque, a prismatic
 // +-u axis as a force at the joint's vertices; a FixedOrientation constraint takes no input), per-step invariants, solution guess
 HD void lp_forces(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M) {

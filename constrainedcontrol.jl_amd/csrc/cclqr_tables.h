@@ -255,9 +255,11 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
         if (j < 0 || j >= nj) { err = "controlled joint out of range"; return CCLQR_EINVAL; }
         H.cj[i] = m->link_of_joint[j];
     }
-    if (m->host.loop && (d->fric || d->npid > 0 || d->noise_scale != 0.0)) { err = "closed-loop mechanisms take the plain LQR law only (no friction, noise or PID)"; return CCLQR_EUNSUPPORTED; }
+    // closed loops: the friction / noise law of examples/trackingLQR_triple_cartpole.jl:93-111 is accepted (round 4; per joint in the caller's joint
+    // order), PID is not (its joint coordinate is read off a tree's relative pose)
+    if (m->host.loop && d->npid > 0) { err = "closed-loop mechanisms take the LQR / TrackingLQR law with friction and noise, not PID"; return CCLQR_EUNSUPPORTED; }
     if (d->fric)
-        for (int j = 0; j < nb; j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
+        for (int j = 0; j < (m->host.loop ? nj : nb); j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
     H.noise_philox = d->noise_philox ? 1 : 0;
     H.noise_key0 = (unsigned)(d->noise_seed & 0xffffffffu) ^ (unsigned)(d->noise_seed >> 32);
     for (int i = 0; i < d->npid; i++) {

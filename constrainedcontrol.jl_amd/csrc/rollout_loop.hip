@@ -78,7 +78,8 @@ __device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const
 
 // newton! on the instance held in LDS (S / LAM = guess in, solution out), the rules of the tree kernels: returns the
 // iterations used; *failed = a non-finite residual (the instance has left the integrator's domain) or no convergence in NEWTON_MAXIT
-__device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, bool* failed PROF_ARG) {
+// eps_alone > 0: the measured-error mode of cclqr_rollout_opts.newton_mode = 1 (a solve also stops on ||f|| < eps_alone, whatever the step)
+__device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, bool* failed, double eps_alone PROF_ARG) {
     bool done = false, fail = false;
     int its = 0;
     double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);
@@ -104,6 +105,7 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
         STAMP(PF_ACCEPT);
         its = iter;
         if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
+        if (normf1 < eps_alone) done = true;
         if (!(normf1 < 1e300)) { done = true; fail = true; }
         if (!done) normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);     // Jacobians at the accepted point
     }
@@ -111,7 +113,8 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
     return its;
 }
 
-__global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
+// relax: 0 = the reference's stopping rule, 1 = newton_mode 1 (a.eps_alone)
+__global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int relax) {
     extern __shared__ double lds[];
     const int t = threadIdx.x;
     const int64_t inst = blockIdx.x;
@@ -148,14 +151,19 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
         if (t < nj) L[Y.UJ + t] = 0.0;
         if (gate) ph_control_error(t, nb, Y, L, r, C, C->zd + ginst * C->zd_stride + (size_t)ksp * nz);
         __syncthreads();
-        if (t < nj) L[Y.UJ + t] = 0.0;          // ph_control_error leaves the (absent) friction term of joint t < nb there
+        // joint friction in the loop's own bookkeeping (ph_control_error's friction term assumes link t = body t = joint t and is overwritten here)
+        if (t < nj) L[Y.UJ + t] = (gate && C->has_fric) ? lp_friction(t, Y, L, r, M, C->fric[t]) : 0.0;
         __syncthreads();
         if (gate) {
             for (int i = 0; i < C->mu; i++) {
                 double part = 0.0;
                 if (C->K) part = ph_gain_partial(t, 64, nb, Y, L, C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb);
                 const double s = group_sum<64>(part);
-                if (t == 0) L[Y.UJ + C->cj[i]] += (C->Fd ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
+                if (t == 0) {
+                    double u = (C->Fd ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
+                    if (C->noise_scale != 0.0 && a.noise) u += C->noise_scale * a.noise[(size_t)inst * a.noise_stride + (k - 1)];     // injected, or this launch's Philox samples
+                    L[Y.UJ + C->cj[i]] += u;
+                }
                 __syncthreads();
             }
         }
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a) {
         PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool failed = false;
-        const int its = dead ? 0 : loop_newton(t, Y, L, r, M, &failed PROF_PASS);
+        const int its = dead ? 0 : loop_newton(t, Y, L, r, M, &failed, relax ? a.eps_alone : 0.0 PROF_PASS);
         const bool done = true;
         if (!dead) {
             const bool conv = done && !failed;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(64) void linearize_loop_kernel(LinArgs a) {
     prof.start();
 #endif
     bool failed = false;
-    const int its = loop_newton(t, Y, L, r, M, &failed PROF_PASS);
+    const int its = loop_newton(t, Y, L, r, M, &failed, 0.0 PROF_PASS);
     loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);      // D_R^-1, N D_R^-1 and the next pose at the converged solution
     __syncthreads();
     lp_lin_joint(t, Y, JB, L, r, M);
@@ -366,12 +374,12 @@ hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A,
 
 size_t loop_lds_bytes(int nb, int nj) { return (size_t)make_loop_layout(nb, nj).total * sizeof(double); }
 
-hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, hipStream_t stream) {
+hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, int newton_mode, hipStream_t stream) {
     if (a.n_inst <= 0) return hipSuccess;
     const size_t lds = loop_lds_bytes(nb, nj);
     hipError_t e = set_max_dynamic_lds_once((const void*)rollout_loop_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rollout_loop_kernel, dim3((unsigned)a.n_inst), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL(rollout_loop_kernel, dim3((unsigned)a.n_inst), dim3(64), lds, stream, a, newton_mode != 0 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ extern "C" {
 #define CCLQR_ESINGULAR -2    /* G*Bl or M singular        (LAPACK exception from lqr.jl:151,160) */
 #define CCLQR_ENOCONV -3      /* soft: Newton / Riccati did not converge (lqr.jl:41 `@info`) */
 #define CCLQR_EHIP -4         /* HIP runtime error; cclqr_last_error() has the text */
-#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (> 4 child joints on a body, nb > 32, friction / noise / PID laws on closed loops) */
+#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (> 4 child joints on a body, nb > 32, the PID law on closed loops) */
 
 /* ABI version = cclqr_version().  A shim built against another header must refuse to run: the structs below are passed by pointer and
  * read in full.  200: cclqr_ctrl_desc.n_ctrl, cclqr_rollout_opts {noise_ws_dev, noise_ws_len, newton_mode}, cclqr_riccati_opts.keep_last,
@@ -41,7 +41,7 @@ extern "C" {
 /* Mechanism(origin, bodies, eqconstraints; g, Δt) -- examples/lqr_cartpole.jl:32.
  * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
  * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
- * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (plain LQR law, one instance per wavefront, multipliers lam
+ * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (LQR / TrackingLQR law with joint friction and noise, no PID; one instance per wavefront, multipliers lam
  * [n_inst][5*ne]); cclqr_linearize returns their A, Bu, Bλ, G (ml = 5*ne rows, a FixedOrientation contributing two null rows), but G*Bλ
  * is singular for a loop, so LQR / TrackingLQR construction goes through cclqr_linearize_projected + cclqr_riccati / cclqr_riccati_tv with
  * ml = 0 (cclqr_riccati_tracking, which divides by G*Bλ at every knot, returns CCLQR_EUNSUPPORTED for them). */
@@ -217,8 +217,8 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *   newton_mode     0 = the reference's stopping rule, ||f|| < eps AND ||step taken|| < eps (the PARITY mode).
  *                   1 = measured-error mode: a Newton solve ALSO stops as soon as ||f|| < newton_eps_alone, whatever the step size.
  *                   Saves the iterations the exact rule spends halving steps on round-off noise; the state deviation from mode 0
- *                   is reported, not promised.  Forests of chains under the plain LQR / TrackingLQR law only
- *                   (CCLQR_EUNSUPPORTED otherwise);
+ *                   is reported, not promised.  Forests of chains under the plain LQR / TrackingLQR law, and
+ *                   closed-loop mechanisms (CCLQR_EUNSUPPORTED on branching trees and with the friction / noise / PID laws on chains);
  *   newton_eps_alone  threshold of mode 1 (<= 0: 1e-10, the rule's own eps: stop on the residual alone). */
 typedef struct {
     int64_t first_instance;

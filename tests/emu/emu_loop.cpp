@@ -96,7 +96,7 @@ extern "C" int emu_loop_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc
             const int ksp = (C->nsp > 1) ? ((k - 1 < C->nsp) ? k - 1 : C->nsp - 1) : 0;
             const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
             if (gate) for (int t = 0; t < 64; t++) ph_control_error(t, nb, Y, L, I.r[t], C, C->zd + inst * C->zd_stride + (size_t)ksp * nz);
-            for (int t = 0; t < nj; t++) L[Y.UJ + t] = 0.0;
+            for (int t = 0; t < nj; t++) L[Y.UJ + t] = (gate && C->has_fric) ? lp_friction(t, Y, L, I.r[t], M, C->fric[t]) : 0.0;      // (noise: GPU tests only)
             if (gate)
                 for (int i = 0; i < C->mu; i++) {
                     double s = 0.0;

@@ -306,22 +306,32 @@ def emu_loop_rollout(emu, orc, t, ctrl, z0, steps):
     return zT, traj, st
 
 
-def loop_feedback_reference(lm, z, Fd, K, zd, steps):
+def loop_feedback_reference(lm, z, Fd, K, zd, steps, fric=None, noise=None, noise_scale=0.0):
     """oracle side of a closed-loop rollout: u = Fd - K dz (lqr.jl:92-111, error order x, v, q~, w per body) on the controlled joints
-    0, 1 of oracle/loops.py's deltabot, stepped by its dense-KKT minimum-norm Newton"""
+    0, 1 of oracle/loops.py's deltabot, stepped by its dense-KKT minimum-norm Newton; fric [njoints]: viscous friction -fric * (axis . relative
+    angular velocity, each body's in its own frame) on every revolute joint and noise [steps] * noise_scale on the controlled ones
+    (examples/trackingLQR_triple_cartpole.jl:93-111 as ck_friction / lp_friction state it)"""
     from oracle import loops
     traj, lam = [], np.zeros(lm.nrows)
-    for _ in range(steps):
+    for k in range(steps):
         traj.append(z.copy())
         u = np.zeros(len(lm.joints))
+        if fric is not None:
+            for ji, j in enumerate(lm.joints):
+                if j.kind == loops.REVOLUTE and fric[ji] != 0.0:
+                    ax = j.axis / np.linalg.norm(j.axis)
+                    rel = ax @ z[j.child, 10:13] - (ax @ z[j.parent, 10:13] if j.parent >= 0 else 0.0)
+                    u[ji] += -fric[ji] * rel
+        if noise is not None:
+            u[:2] += noise_scale * noise[k]
         if K is None:
-            u[:2] = Fd
+            u[:2] += Fd
         else:
             dz = np.zeros((lm.nb, 12))
             for b in range(lm.nb):
                 qe = loops.qmul(np.concatenate([[zd[b, 3]], -zd[b, 4:7]]), z[b, 3:7])
                 dz[b] = np.concatenate([z[b, 0:3] - zd[b, 0:3], z[b, 7:10] - zd[b, 7:10], qe[1:], z[b, 10:13] - zd[b, 10:13]])
-            u[:2] = Fd - K @ dz.ravel()
+            u[:2] += Fd - K @ dz.ravel()
         z, lam, _ = lm.step(z, lam, u)
     return np.array(traj), z
 
@@ -356,6 +366,13 @@ def test_emulated_closed_loop_deltabot(cclqr, orc, emu):
     zT, traj, st = emu_loop_rollout(emu, orc, t, fb, z0, steps)
     ref, zref = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], K[0], zd[0], steps)
     assert st[0] > 0 and np.abs(traj[0] - ref).max() < 1e-9 and np.abs(zT[0] - zref).max() < 1e-9
+    # joint friction on a loop mechanism (round 4: lp_friction, the law of trackingLQR_triple_cartpole.jl:93-101 per joint in the caller's order)
+    fric = np.array([0.5, 0.3, 0.4, 0.2, 0.6, 0.0, 0.0])
+    fr = orc.ctrl_desc(t.nb, cj, K=K, N=0, zd=zd, Fd=0.8 * ex["Fd"].reshape(1, 2), fric=fric)
+    zTf, trajf, st = emu_loop_rollout(emu, orc, t, fr, z0, steps)
+    reff, zreff = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], K[0], zd[0], steps, fric=fric)
+    assert st[0] > 0 and np.abs(trajf[0] - reff).max() < 1e-9 and np.abs(zTf[0] - zreff).max() < 1e-9
+    assert np.abs(zTf[0] - zT[0]).max() > 1e-3                      # (the friction did something)
 
 
 def emu_loop_linearize(emu, orc, t, zd, cj, Fd, force_loop):

@@ -362,6 +362,23 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     with pytest.raises(capi.CclqrError) as e:
         capi.riccati(A, Bu, Bl, G, np.eye(60) * 0.01, np.eye(len(cj)) * 0.01, 20)      # the reference's own form divides by the singular G Bλ (lqr.jl:151)
     assert e.value.code == capi.ESINGULAR
+    # round 4: the friction / noise law and newton_mode 1 on a loop mechanism.  Friction per joint in the caller's joint order,
+    # noise injected per (instance, step) on the controlled joints: every instance's trajectory equals the dense-KKT reference under the same law
+    fric = np.array([0.5, 0.3, 0.4, 0.2, 0.6, 0.0, 0.0])
+    noise = np.random.default_rng(8).normal(size=(n, steps))
+    fn = capi.CtrlHandle(mech, cj, K=K, N=0, zd=np.repeat(zd[None], n, 0), Fd=Fd, n_ctrl=n, fric=fric, noise_scale=0.7)
+    zTf, trajf, stf = capi.rollout(mech, fn, zb, steps, record=True, noise=noise)
+    assert (stf > 0).all()
+    for i in (0, 2, 4):
+        ref, zref = loop_feedback_reference(lm, z.copy(), Fd[i, 0], None if i == 0 else K[i, 0], zd[0], steps, fric=fric, noise=noise[i], noise_scale=0.7)
+        assert np.abs(trajf[i] - ref).max() < TOL and np.abs(zTf[i] - zref).max() < TOL, i
+    assert np.abs(zTf - zT).max() > 1e-3
+    zT1, _, st1 = capi.rollout(mech, ctrl, zb, steps, newton_mode=1, newton_eps_alone=1e-12)      # the measured-error stop on the loop kernel
+    assert (st1 > 0).all() and (st1 <= st).all() and 0.0 <= np.abs(zT1 - zT).max() < 1e-8
+    pid = capi.CtrlHandle                                                                      # PID stays refused on loops (its joint coordinate is a tree's)
+    with pytest.raises(capi.CclqrError) as e:
+        pid(mech, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2), pid=dict(joint=[0], P=[1.0], I=[0.0], D=[0.0], goal=[0.0]))
+    assert e.value.code == capi.EUNSUPPORTED
 
 
 
