@@ -187,8 +187,8 @@ def check_tracking_fixture(cclqr, orc, fx, rollout_open=None):
     K, _ = orc.riccati_tracking(t, [0], z_all, U.reshape(-1, 1), fx["Q"], fx["R"], len(U))
     rep["tracking_gains"] = float(np.abs(K - fx["K_all"]).max() / np.abs(fx["K_all"]).max())
     assert rep["tracking_gains"] < 1e-6, rep
-    # the tracked run under the script's law with zero noise
-    oc = orc.ctrl_desc(t.nb, [0], K=fx["K_all"], N=len(U), zd=z_all, Fd=U.reshape(-1, 1), fric=ex["fric"])
+    # the tracked run under the package's own law control_trackinglqr! (lqr_tracking.jl:46-71: no friction, no noise)
+    oc = orc.ctrl_desc(t.nb, [0], K=fx["K_all"], N=len(U), zd=z_all, Fd=U.reshape(-1, 1))
     zT, traj, st = orc.rollout(t, oc, fx["z0"][None], len(U), record=True)
     rep["tracked_knot_readings"] = knot_readings(traj[0], zT[0], _storage(fx), ks)
     assert rep["tracked_knot_readings"]["A"] < 1e-6, rep

@@ -14,8 +14,9 @@
 #     zd[nb][13], Fd[mu], Q[12nb][12nb] (already times Δt), R[mu][mu], N, dt, g
 #     k_list, storage_x[len(k_list)][nb][3], storage_q[..][4], storage_v[..][3], storage_w[..][3]
 #                                      storage.{x,q,v,ω}[body][k] of simulate!(mech, tend, lqr, record = true) at k in {1, 2, 10, 100, last}
-#     (config 5) U[1000], storage0_* of the open-loop swing-up, K_all of the TrackingLQR, storage_* of the run under the script's law
-#                                      owncontrol_trackinglqr! with its randn() REPLACED BY ZERO (friction kept) -- noise cannot be reproduced
+#     (config 5) U[1000], storage0_* of the open-loop swing-up, K_all of the TrackingLQR, storage_* of the run under the PACKAGE's law
+#                                      control_trackinglqr! (lqr_tracking.jl:46-71): the script's own law adds friction and randn() noise,
+#                                      which cannot be reproduced; the friction / noise option of this repository is checked against its oracle
 #
 # tests/test_reference_fixtures.py consumes these directories when they exist (on the CPU oracle and on the HIP path) and answers, the moment a
 # file appears: do the gains agree, does the linear model agree, does the integrator agree, and WHICH KNOT does Storage record (DESIGN.md 2).
@@ -200,30 +201,9 @@ let
     Q = [diagm(ones(12)) * 0.0 for i = 1:4]
     Q[1][2, 2] = 10; Q[1][5, 5] = 1; Q[2][7, 7] = 40; Q[2][10, 10] = 1; Q[3][7, 7] = 40; Q[3][10, 10] = 1; Q[4][7, 7] = 40; Q[4][10, 10] = 1   # :62-70
     R = [ones(1, 1) * 0.1]
-    # the script's law (:76-115) with randn() * 2 replaced by 0 -- Julia's stream cannot be reproduced; friction 0.1 kept
-    function law!(mechanism::Mechanism{T,Nn,Nb}, lqr::TrackingLQR{T,N}, k) where {T,Nn,Nb,N}
-        Δz = zeros(T, Nb * 12)
-        for (id, body) in pairs(mechanism.bodies)
-            c = (id - 1) * 12
-            state = body.state
-            Δz[c+1:c+3] = state.xsol[2] - lqr.xd[k][id]; Δz[c+4:c+6] = state.vsol[2] - lqr.vd[k][id]
-            Δz[c+7:c+9] = ConstrainedDynamics.imag(lqr.qd[k][id] \ state.qsol[2]); Δz[c+10:c+12] = state.ωsol[2] - lqr.ωd[k][id]
-        end
-        v1 = mechanism.bodies[1].state.vc[2]
-        ω2 = mechanism.bodies[2].state.ωc[1]; ω3 = mechanism.bodies[3].state.ωc[1] - ω2; ω4 = mechanism.bodies[4].state.ωc[1] - ω2 - ω3
-        ucart = -sign(v1) * 0.1 * abs(v1)
-        if k < N
-            for (i, id) in enumerate(lqr.eqcids)
-                setForce!(mechanism, geteqconstraint(mechanism, id), lqr.Fτd[k][i] - lqr.K[k][i] * Δz .+ ucart)
-            end
-            setForce!(mechanism, geteqconstraint(mechanism, 6), [-sign(ω2) * 0.1 * abs(ω2)])
-            setForce!(mechanism, geteqconstraint(mechanism, 7), [-sign(ω3) * 0.1 * abs(ω3)])
-            setForce!(mechanism, geteqconstraint(mechanism, 8), [-sign(ω4) * 0.1 * abs(ω4)])
-        end
-        return
-    end
     zero_pose!()
-    lqr = TrackingLQR(mech, storage0, [[[U[k]]] for k = 1:1000], [joint1.id], Q, R, controlfunction = law!)   # :117
+    lqr = TrackingLQR(mech, storage0, [[[U[k]]] for k = 1:1000], [joint1.id], Q, R)      # :117 without the script-local controlfunction:
+                                                                                          # the package's own control_trackinglqr! (lqr_tracking.jl:46-71), no friction, no noise
     save(dir, "K_all", gains(lqr.K)); save(dir, "K_distinct_from", [distinct_from(lqr.K)])
     save(dir, "Q", cat(Q..., dims = (1, 2)) * mech.Δt); save(dir, "R", cat(R..., dims = (1, 2)) * mech.Δt)
     zero_pose!()
