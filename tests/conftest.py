@@ -45,9 +45,9 @@ def emu():
     import ctypes as C
     d = os.path.join(ROOT, "tests", "emu")
     so = os.path.join(d, "libemu.so")
-    srcs = [os.path.join(d, "emu_rollout.cpp"), os.path.join(d, "emu_chain.cpp"), os.path.join(d, "emu_loop.cpp")]
+    srcs = [os.path.join(d, "emu_rollout.cpp"), os.path.join(d, "emu_chain.cpp"), os.path.join(d, "emu_loop.cpp"), os.path.join(d, "emu_treereg.cpp")]
     csrc = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc")
-    deps = srcs + [os.path.join(csrc, h) for h in ("cclqr_dev.h", "cclqr_chain.h", "cclqr_loop.h", "cclqr_lin_loop.h", "cclqr_lin_dev.h", "cclqr_tables.h", "cclqr_internal.h")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("cclqr_dev.h", "cclqr_chain.h", "cclqr_loop.h", "cclqr_lin_loop.h", "cclqr_lin_dev.h", "cclqr_tables.h", "cclqr_internal.h", "cclqr_treereg.h", "cclqr_treereg_tables.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared",
                                "-o", so] + srcs)

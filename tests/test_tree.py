@@ -90,6 +90,37 @@ def test_emulated_tree_rollout_matches_oracle(cclqr, orc, emu, name):
     assert np.abs(zT - zo).max() < 1e-9
 
 
+def emu_treereg_rollout(emu, orc, t, ctrl, z0, steps):
+    """the register-resident tree kernel's phases and schedule on the CPU (tests/emu/emu_treereg.cpp)"""
+    m = orc.mech_desc(t)
+    z0 = np.ascontiguousarray(z0, dtype=np.float64).reshape(-1, t.nb, 13)
+    n = z0.shape[0]
+    traj, zT, st = np.zeros((n, steps, t.nb, 13)), np.zeros_like(z0), np.zeros(n, dtype=np.int32)
+    rc = emu.emu_treereg_rollout(C.byref(m.desc), C.byref(ctrl.desc), C.c_int64(n), C.c_int(steps), C.c_int(1), z0.ctypes.data_as(dp), None,
+                                 traj.ctypes.data_as(dp), zT.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(0))
+    assert rc == 0
+    return zT, traj, st
+
+
+@pytest.mark.parametrize("name", list(TREES))
+def test_emulated_register_resident_tree_rollout_matches_oracle(cclqr, orc, emu, name):
+    """csrc/cclqr_treereg.h: sparse sibling blocks, scheduled elimination records, child sums -- against the oracle's tree LDU, with feedback and friction"""
+    ex = build(cclqr, name)
+    t = ex["mech"].tables()
+    z0 = ex["mech"].state()[None]
+    rng = np.random.default_rng(5)
+    steps = 40
+    cj = [0, t.ne - 1]
+    K = rng.normal(size=(steps + 5, 2, 12 * t.nb)) * 0.05
+    Fd = rng.normal(size=(1, 2)) * 0.3
+    oc = orc.ctrl_desc(t.nb, cj, K=K, N=steps + 6, zd=z0[0], Fd=Fd, fric=rng.uniform(0, 0.05, t.ne))
+    zo, traj_o, st_o = orc.rollout(t, oc, z0, steps, record=True)
+    zT, traj, st = emu_treereg_rollout(emu, orc, t, oc, z0, steps)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-9
+    assert np.abs(zT - zo).max() < 1e-9
+
+
 @pytest.mark.parametrize("name", ["dual_cartpole", "y", "four_children"])
 def test_emulated_tree_linearisation_matches_oracle(cclqr, orc, emu, name):
     ex = build(cclqr, name)
@@ -160,6 +191,9 @@ def test_random_topologies_emulator_vs_oracle(cclqr, orc, emu, seed):
     zT, traj, st = emu_rollout(emu, orc, t, oc, z0, steps)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-9 and np.abs(zT - zo).max() < 1e-9
+    if any(parents.count(a) > 1 for a in set(parents) if a >= 0):     # branched: the register-resident tree kernel's phases too
+        zT2, traj2, st2 = emu_treereg_rollout(emu, orc, t, oc, z0, steps)
+        assert (st2 > 0).all() and np.abs(traj2 - traj_o).max() < 1e-9 and np.abs(zT2 - zo).max() < 1e-9
     m = orc.mech_desc(t)
     cja = np.array(cj, dtype=np.int32)
     mx, ml, mu = 12 * t.nb, 5 * t.ne, len(cj)
