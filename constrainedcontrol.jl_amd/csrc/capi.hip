@@ -4,6 +4,7 @@
 #include "../../include/cclqr.h"
 #include "cclqr_internal.h"
 #include "cclqr_tables.h"
+#include "cclqr_treereg_tables.h"
 #include "cclqr_wscache.h"
 #include <math.h>
 #include <stdio.h>
@@ -92,9 +93,17 @@ extern "C" int cclqr_mech_create(const cclqr_mech_desc* d, cclqr_mech** out) {
     std::string err;
     int rc = build_mech_tables(d, m, err);
     if (rc != CCLQR_OK) { delete m; return fail(rc, err); }
+    // branching trees: the tables of the register-resident tree kernel (sibling lists, elimination schedule) ride behind the MechDev in the
+    // same allocation (cclqr_treereg.h treereg_of)
+    std::vector<char> image(m->host.tree ? treereg_offset() + sizeof(TreeRegDev) : sizeof(MechDev), 0);
+    memcpy(image.data(), &m->host, sizeof(MechDev));
+    if (m->host.tree && !m->host.loop) {
+        TreeRegDev* R = new (image.data() + treereg_offset()) TreeRegDev;
+        if (!build_treereg_tables(m->host, *R, err)) { delete m; return fail(CCLQR_EUNSUPPORTED, err); }
+    }
     hipError_t e = hipGetDevice(&m->device);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->dev, sizeof(MechDev));
-    if (e == hipSuccess) e = hipMemcpy(m->dev, &m->host, sizeof(MechDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->dev, image.size());
+    if (e == hipSuccess) e = hipMemcpy(m->dev, image.data(), image.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete m; return fail(CCLQR_EHIP, std::string("mechanism upload: ") + hipGetErrorString(e)); }
     *out = m;
     return CCLQR_OK;
@@ -264,6 +273,11 @@ extern "C" int cclqr_rollout_layout_links(const cclqr_mech* m, int32_t* links) {
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
     if (m->host.loop) { if (lanes) *lanes = 64; if (lds_bytes) *lds_bytes = (int32_t)loop_lds_bytes(m->nb, m->nj); return CCLQR_OK; }
+    if (m->host.tree) {       // branching trees: rollout_treereg.hip
+        if (lanes) *lanes = treereg_lanes(m->nb, m->host.tree);
+        if (lds_bytes) *lds_bytes = (int32_t)treereg_lds_bytes(m->nb, m->host.tree, m->host.npairs);
+        return CCLQR_OK;
+    }
     if (lanes) *lanes = rollout_lanes_per_instance(m->nb, m->host.tree);
     if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs);
     return CCLQR_OK;
@@ -277,7 +291,8 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
-    if (!m->host.loop && rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs) > 160 * 1024) return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
+    if (!m->host.loop && (m->host.tree ? treereg_lds_bytes(m->nb, m->host.tree, m->host.npairs) : rollout_lds_bytes(m->nb, 0, 0)) > 160 * 1024)
+        return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     const int64_t first = opts ? opts->first_instance : 0;
     if (first < 0) return fail(CCLQR_EINVAL, "negative first_instance");
     if (c->host.n_ctrl > 1 && first + n_inst > c->host.n_ctrl) return fail(CCLQR_EINVAL, "more instances than per-instance controller tables");
@@ -324,9 +339,10 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
         HIPCHK(launch_rollout_loop(a, m->nb, m->nj, newton_mode, (hipStream_t)stream));
         return CCLQR_OK;
     }
-    if (newton_mode != 0 && (m->host.tree || extra != 0))
-        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists for forests of chains under the plain LQR / TrackingLQR law (and for closed-loop mechanisms) only");
-    HIPCHK(launch_rollout(a, m->nb, m->host.tree, m->host.npairs, extra, newton_mode, (hipStream_t)stream));
+    if (newton_mode != 0 && extra != 0)
+        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists under the plain LQR / TrackingLQR law only (trees and closed-loop mechanisms)");
+    if (m->host.tree) HIPCHK(launch_rollout_treereg(a, m->nb, m->host.tree, m->host.npairs, extra, newton_mode, (hipStream_t)stream));
+    else HIPCHK(launch_rollout(a, m->nb, 0, 0, extra, newton_mode, (hipStream_t)stream));
     return CCLQR_OK;
 }
 

@@ -29,7 +29,7 @@ namespace cclqr {
 //   back substitution, lane (link l, row r < 5):  dl_l[r] = y_l[r] - sum_g Z_{l,x_g}[r, :] dl_{x_g}
 //       o0 = y_l[r], o1 = dl_l[r], a[g] = row r of Z_{l,x_g}, b[g] = dl_{x_g}
 // ctl = number of neighbours nn (low byte) | stride << 8 | 1 << 16 when the lane has work in this step
-struct TrRec { int o0, o1, ctl, pad; int a[CCLQR_MAXK], b[CCLQR_MAXK]; };
+struct alignas(16) TrRec { int o0, o1, ctl, pad; int a[CCLQR_MAXK], b[CCLQR_MAXK]; };
 HD bool trrec_on(const TrRec& K) { return (K.ctl >> 16) != 0; }
 
 // tables of the register-resident tree kernel, in device memory right behind the mechanism's MechDev (capi.hip allocates both in one piece)
@@ -41,6 +41,9 @@ struct TreeRegDev {
     int ne_steps, nb_steps;
     TrRec el[TR_MAXSTEP][TR_LANES], bk[TR_MAXSTEP][TR_LANES];
 };
+// the tables sit behind the mechanism's MechDev in ONE device allocation (capi.hip cclqr_mech_create), at the next 16-byte boundary
+HD size_t treereg_offset() { return (sizeof(MechDev) + 15) & ~(size_t)15; }
+HD const TreeRegDev* treereg_of(const MechDev* M) { return (const TreeRegDev*)((const char*)M + treereg_offset()); }
 
 // LDS image: make_chain_layout + the sibling blocks.  nbp = links the image is laid out for (compile time in the kernel), nss = 2 x sibling pairs
 HD Lay make_treereg_layout(int nbp, int nss) {
@@ -133,10 +136,13 @@ HD void tr_schur_rows(const LinkC& c, const TreeL& T, int j, bool store, int max
         }
         SCHED_FENCE();
     }
-    for (int k = 0; k < maxchild; k++)
-        if (store && k < T.nchild) tr_side_block(T.child[k], -c.sxb, Y, L, wXT, wPB, Y.SPJ + 25 * T.child[k]);
-    for (int k = 0; k < maxsib; k++)
-        if (store && k < T.nsib) tr_side_block(T.sib[k], c.sxa, Y, L, wXT, wPA, T.siboff[k]);
+    // (unrolled with a wave-uniform guard: an index that is not a compile-time constant would put the lists into scratch memory)
+#pragma unroll
+    for (int k = 0; k < CCLQR_MAXK; k++)
+        if (k < maxchild) { if (store && k < T.nchild) tr_side_block(T.child[k], -c.sxb, Y, L, wXT, wPB, Y.SPJ + 25 * T.child[k]); }
+#pragma unroll
+    for (int k = 0; k < CCLQR_MAXK - 1; k++)
+        if (k < maxsib) { if (store && k < T.nsib) tr_side_block(T.sib[k], c.sxa, Y, L, wXT, wPA, T.siboff[k]); }
     if (store) {
 #pragma unroll
         for (int r = 0; r < 5; r++) {
@@ -164,7 +170,9 @@ HD void tr_elim(const TrRec& K, double* L) {
     for (int r = 0; r < 5; r++) zy[r] = L[K.o1 + st * r];
     lu5_factor(lu);
     lu5_solve(lu, zy);
-    for (int gp = 0; gp < nn; gp++) {
+#pragma unroll
+    for (int gp = 0; gp < CCLQR_MAXK; gp++) {
+        if (gp >= nn) break;
         double sxl[25], tg[5];
 #pragma unroll
         for (int i = 0; i < 25; i++) sxl[i] = L[K.a[gp] + i];
@@ -182,7 +190,9 @@ HD void tr_back(const TrRec& K, double* L) {
     if (!trrec_on(K)) return;
     const int nn = K.ctl & 0xff;
     double acc = L[K.o0];
-    for (int g = 0; g < nn; g++) {
+#pragma unroll
+    for (int g = 0; g < CCLQR_MAXK; g++) {
+        if (g >= nn) break;
         const int oz = K.a[g], od = K.b[g];
         acc -= L[oz] * L[od] + L[oz + 1] * L[od + 1] + L[oz + 2] * L[od + 2] + L[oz + 3] * L[od + 3] + L[oz + 4] * L[od + 4];
     }
@@ -192,6 +202,9 @@ HD void tr_back(const TrRec& K, double* L) {
 // lanes per instance and links of the image the kernel is instantiated for: 16 lanes when the mechanism has at most 8 links and no link
 // with more than two neighbours left at its elimination (tree8 = 8 x the largest neighbour count, MechDev::tree), else 32
 HD int treereg_lanes(int nb, int tree8) { return (nb <= 8 && tree8 <= 16) ? 16 : 32; }
-HD int treereg_layout_links(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 12 ? 12 : (nb <= 16 ? 16 : (nb <= 24 ? 24 : 32)))); }
+HD int treereg_layout_links(int nb, int tree8) {
+    const int n = nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 12 ? 12 : (nb <= 16 ? 16 : (nb <= 24 ? 24 : 32))));
+    return (treereg_lanes(nb, tree8) == 32 && n < 8) ? 8 : n;       // the instantiations of rollout_treereg.hip
+}
 
 }  // namespace cclqr

@@ -2,11 +2,16 @@
 // SCHEDULE of the no-fill elimination (which links go in the same step, which 8-lane group does what), written as per-(step, lane) records.
 #pragma once
 #include "cclqr_treereg.h"
+#include "cclqr_internal.h"
 #include <string>
 #include <vector>
 #include <string.h>
 
 namespace cclqr {
+
+// rollout_treereg.hip; a.M must point at the device image [MechDev | TreeRegDev] (treereg_of)
+size_t treereg_lds_bytes(int nb, int tree8, int npairs);
+hipError_t launch_rollout_treereg(const RolloutArgs& a, int nb, int tree8, int npairs, int extra, int newton_mode, hipStream_t stream);
 
 // R for the mechanism H (H.tree != 0: build_mech_tables, cclqr_tables.h).  Returns false with `err` set when the mechanism does not fit
 // the kernel (more than TR_LANES links).
@@ -14,7 +19,7 @@ static inline bool build_treereg_tables(const MechDev& H, TreeRegDev& R, std::st
     memset(&R, 0, sizeof(R));
     const int nb = H.nb;
     if (nb > TR_LANES) { err = "more links than lanes"; return false; }
-    const int G = treereg_lanes(nb, H.tree), nbp = treereg_layout_links(nb);
+    const int G = treereg_lanes(nb, H.tree), nbp = treereg_layout_links(nb, H.tree);
     R.lanes = G; R.nbp = nbp; R.nss = 2 * H.npairs;
     const Lay Y = make_treereg_layout(nbp, R.nss);
     auto pair_of = [&](int i, int j) { for (int q = 0; q < H.npairs; q++) if (H.pair_i[q] == i && H.pair_j[q] == j) return q; return -1; };
