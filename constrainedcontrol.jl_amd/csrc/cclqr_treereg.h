@@ -136,13 +136,22 @@ HD void tr_schur_rows(const LinkC& c, const TreeL& T, int j, bool store, int max
         }
         SCHED_FENCE();
     }
-    // (unrolled with a wave-uniform guard: an index that is not a compile-time constant would put the lists into scratch memory)
-#pragma unroll
-    for (int k = 0; k < CCLQR_MAXK; k++)
-        if (k < maxchild) { if (store && k < T.nchild) tr_side_block(T.child[k], -c.sxb, Y, L, wXT, wPB, Y.SPJ + 25 * T.child[k]); }
-#pragma unroll
-    for (int k = 0; k < CCLQR_MAXK - 1; k++)
-        if (k < maxsib) { if (store && k < T.nsib) tr_side_block(T.sib[k], c.sxa, Y, L, wXT, wPA, T.siboff[k]); }
+    // real loops (one copy of the block code) over lists that ROTATE through fixed registers: an index the compiler cannot resolve would put
+    // the lists into scratch memory
+    {
+        int c0 = T.child[0], c1 = T.child[1], c2 = T.child[2], c3 = T.child[3];
+#pragma unroll 1
+        for (int k = 0; k < maxchild; k++) {
+            if (store && k < T.nchild) tr_side_block(c0, -c.sxb, Y, L, wXT, wPB, Y.SPJ + 25 * c0);
+            c0 = c1; c1 = c2; c2 = c3;
+        }
+        int s0 = T.sib[0], s1 = T.sib[1], s2 = T.sib[2], o0 = T.siboff[0], o1 = T.siboff[1], o2 = T.siboff[2];
+#pragma unroll 1
+        for (int k = 0; k < maxsib; k++) {
+            if (store && k < T.nsib) tr_side_block(s0, c.sxa, Y, L, wXT, wPA, o0);
+            s0 = s1; s1 = s2; o0 = o1; o1 = o2;
+        }
+    }
     if (store) {
 #pragma unroll
         for (int r = 0; r < 5; r++) {
@@ -170,18 +179,19 @@ HD void tr_elim(const TrRec& K, double* L) {
     for (int r = 0; r < 5; r++) zy[r] = L[K.o1 + st * r];
     lu5_factor(lu);
     lu5_solve(lu, zy);
-#pragma unroll
-    for (int gp = 0; gp < CCLQR_MAXK; gp++) {
-        if (gp >= nn) break;
+    int a0 = K.a[0], a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3];      // rotate (see tr_schur_rows)
+#pragma unroll 1
+    for (int gp = 0; gp < nn; gp++) {
         double sxl[25], tg[5];
 #pragma unroll
-        for (int i = 0; i < 25; i++) sxl[i] = L[K.a[gp] + i];
+        for (int i = 0; i < 25; i++) sxl[i] = L[a0 + i];
 #pragma unroll
-        for (int r = 0; r < 5; r++) tg[r] = L[K.b[gp] + st * r];
+        for (int r = 0; r < 5; r++) tg[r] = L[b0 + st * r];
 #pragma unroll
         for (int r = 0; r < 5; r++) tg[r] -= sxl[5 * r] * zy[0] + sxl[5 * r + 1] * zy[1] + sxl[5 * r + 2] * zy[2] + sxl[5 * r + 3] * zy[3] + sxl[5 * r + 4] * zy[4];
 #pragma unroll
-        for (int r = 0; r < 5; r++) L[K.b[gp] + st * r] = tg[r];
+        for (int r = 0; r < 5; r++) L[b0 + st * r] = tg[r];
+        a0 = a1; a1 = a2; a2 = a3; b0 = b1; b1 = b2; b2 = b3;
     }
 #pragma unroll
     for (int r = 0; r < 5; r++) L[K.o1 + st * r] = zy[r];
@@ -190,11 +200,11 @@ HD void tr_back(const TrRec& K, double* L) {
     if (!trrec_on(K)) return;
     const int nn = K.ctl & 0xff;
     double acc = L[K.o0];
-#pragma unroll
-    for (int g = 0; g < CCLQR_MAXK; g++) {
-        if (g >= nn) break;
-        const int oz = K.a[g], od = K.b[g];
-        acc -= L[oz] * L[od] + L[oz + 1] * L[od + 1] + L[oz + 2] * L[od + 2] + L[oz + 3] * L[od + 3] + L[oz + 4] * L[od + 4];
+    int a0 = K.a[0], a1 = K.a[1], a2 = K.a[2], a3 = K.a[3], b0 = K.b[0], b1 = K.b[1], b2 = K.b[2], b3 = K.b[3];
+#pragma unroll 1
+    for (int g = 0; g < nn; g++) {
+        acc -= L[a0] * L[b0] + L[a0 + 1] * L[b0 + 1] + L[a0 + 2] * L[b0 + 2] + L[a0 + 3] * L[b0 + 3] + L[a0 + 4] * L[b0 + 4];
+        a0 = a1; a1 = a2; a2 = a3; b0 = b1; b1 = b2; b2 = b3;
     }
     L[K.o1] = acc;
 }
@@ -203,7 +213,7 @@ HD void tr_back(const TrRec& K, double* L) {
 // with more than two neighbours left at its elimination (tree8 = 8 x the largest neighbour count, MechDev::tree), else 32
 HD int treereg_lanes(int nb, int tree8) { return (nb <= 8 && tree8 <= 16) ? 16 : 32; }
 HD int treereg_layout_links(int nb, int tree8) {
-    const int n = nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 12 ? 12 : (nb <= 16 ? 16 : (nb <= 24 ? 24 : 32))));
+    const int n = nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? (nb + 1) / 2 * 2 : (nb <= 24 ? 24 : 32)));       // 10, 12, 14, 16: a 14-link image lets four workgroups share a CU
     return (treereg_lanes(nb, tree8) == 32 && n < 8) ? 8 : n;       // the instantiations of rollout_treereg.hip
 }
 

@@ -30,13 +30,14 @@ template <int N>
 __device__ __forceinline__ void child_sum(const TreeL& T, int gb4, int maxchild, const double* in, double* out) {
 #pragma unroll
     for (int i = 0; i < N; i++) out[i] = 0.0;
-#pragma unroll
-    for (int k = 0; k < CCLQR_MAXK; k++) {
-        if (k >= maxchild) break;
-        const int addr = gb4 + 4 * T.child[k];
+    int c0 = T.child[0], c1 = T.child[1], c2 = T.child[2], c3 = T.child[3];      // the list rotates through fixed registers (cclqr_treereg.h tr_schur_rows)
+#pragma unroll 1
+    for (int k = 0; k < maxchild; k++) {
+        const int addr = gb4 + 4 * c0;
         const bool has = k < T.nchild;
 #pragma unroll
         for (int i = 0; i < N; i++) { const double v = lane_read(in[i], addr); out[i] += has ? v : 0.0; }
+        c0 = c1; c1 = c2; c2 = c3;
     }
 }
 
@@ -314,23 +315,25 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
             PCOUNT(PF_NEWTON_ITERS);
             const bool active = c.live() && !done;
             // scheduled no-fill elimination (leaves towards the roots), then the multiplier steps (roots towards the leaves)
-            {
+            {   // the record of a step is fetched from the tables one step AHEAD (an L2 round trip costs as much as the step's arithmetic)
                 const TrRec* rec = &R->el[0][t];
+                TrRec K, Kn;
+                load_rec(K, rec);
                 for (int s = 0; s < ne_steps; s++) {
-                    TrRec K;
-                    load_rec(K, rec + s * TR_LANES);
+                    load_rec(Kn, s + 1 < ne_steps ? rec + (s + 1) * TR_LANES : &R->bk[0][t]);
                     if (done) K.ctl = 0;
                     tr_elim(K, L);
                     __syncthreads();
+                    K = Kn;
                 }
                 STAMP(PF_TRI_FWD);
                 rec = &R->bk[0][t];
                 for (int s = 0; s < nb_steps; s++) {
-                    TrRec K;
-                    load_rec(K, rec + s * TR_LANES);
+                    load_rec(Kn, rec + (s + 1 < nb_steps ? s + 1 : s) * TR_LANES);
                     if (done) K.ctl = 0;
                     tr_back(K, L);
                     __syncthreads();
+                    K = Kn;
                 }
                 STAMP(PF_TRI_BWD);
             }
@@ -527,7 +530,9 @@ hipError_t launch_rollout_treereg(const RolloutArgs& a, int nb, int tree8, int n
     if (G == 16) return nbp == 4 ? launch_treereg_one<16, 4>(a, extra, newton_mode, grid, lds, stream) : launch_treereg_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
     switch (nbp) {
         case 8: return launch_treereg_one<32, 8>(a, extra, newton_mode, grid, lds, stream);
+        case 10: return launch_treereg_one<32, 10>(a, extra, newton_mode, grid, lds, stream);
         case 12: return launch_treereg_one<32, 12>(a, extra, newton_mode, grid, lds, stream);
+        case 14: return launch_treereg_one<32, 14>(a, extra, newton_mode, grid, lds, stream);
         case 16: return launch_treereg_one<32, 16>(a, extra, newton_mode, grid, lds, stream);
         case 24: return launch_treereg_one<32, 24>(a, extra, newton_mode, grid, lds, stream);
         default: return launch_treereg_one<32, 32>(a, extra, newton_mode, grid, lds, stream);

@@ -255,3 +255,16 @@ extern "C" int emu_treereg_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_d
     }
     return 0;
 }
+
+// lengths of the elimination / back substitution schedules and lanes per instance (tests: the schedule is shorter than one step per link)
+extern "C" int emu_treereg_schedule(const cclqr_mech_desc* md, int* ne_steps, int* nb_steps, int* lanes) {
+    cclqr_mech m;
+    std::string err;
+    int rc = build_mech_tables(md, &m, err);
+    if (rc) return rc;
+    if (!m.host.tree) return CCLQR_EUNSUPPORTED;
+    static TreeRegDev Rt;
+    if (!build_treereg_tables(m.host, Rt, err)) return CCLQR_EUNSUPPORTED;
+    *ne_steps = Rt.ne_steps; *nb_steps = Rt.nb_steps; *lanes = Rt.lanes;
+    return 0;
+}

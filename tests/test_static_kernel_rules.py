@@ -18,13 +18,13 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "constrainedcontrol.jl_amd", "csrc")
 
-CROSS = re.compile(r"\b(wave_from_prev|wave_from_next|from_prev\s*<|from_next\s*<|group_sum\s*<|dpp_f64\s*<|dpp_row_ror\s*<|wave_max_key|key_dpp_max\s*<|other_half|__shfl\w*|"
+CROSS = re.compile(r"\b(lane_read|from_lane\s*<|child_sum\s*<|tr_other_half|wave_from_prev|wave_from_next|from_prev\s*<|from_next\s*<|group_sum\s*<|dpp_f64\s*<|dpp_row_ror\s*<|wave_max_key|key_dpp_max\s*<|other_half|__shfl\w*|"
                    r"__builtin_amdgcn_(readlane|readfirstlane|update_dpp|mov_dpp|permlane\w*|ds_bpermute|ds_swizzle)|__syncthreads|__any|__all|__ballot)\b")
 # definitions of the cross-lane helpers themselves (their bodies ARE the cross-lane instruction)
-HELPER_DEF = re.compile(r"(double|void|int|v4d|unsigned long long)\s+(wave_from_prev|wave_from_next|from_prev|from_next|group_sum|dpp_f64|dpp_row_ror|wave_max_key|key_dpp_max|other_half)\s*\(")
+HELPER_DEF = re.compile(r"(double|void|int|v4d|unsigned long long)\s+(lane_read|from_lane|child_sum|tr_other_half|wave_from_prev|wave_from_next|from_prev|from_next|group_sum|dpp_f64|dpp_row_ror|wave_max_key|key_dpp_max|other_half)\s*\(")
 
-PER_LANE_HEADERS = ["cclqr_chain.h", "cclqr_dev.h", "cclqr_lin_dev.h", "cclqr_loop.h"]
-ORCHESTRATION = ["rollout_chain.hip", "rollout.hip", "rollout_loop.hip", "linearize.hip", "cclqr_newton.h"]
+PER_LANE_HEADERS = ["cclqr_chain.h", "cclqr_dev.h", "cclqr_lin_dev.h", "cclqr_loop.h", "cclqr_treereg.h"]
+ORCHESTRATION = ["rollout_chain.hip", "rollout_treereg.hip", "rollout.hip", "rollout_loop.hip", "linearize.hip", "cclqr_newton.h"]
 
 # wavefront-uniform conditions that may enclose a cross-lane operation (regexes on the condition text, whitespace collapsed)
 UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAXIT$", r"^lv <= LINE_MAXIT", r"^ls <= LINE_MAXIT", r"^ci < nchains$", r"^c < nchains$",
@@ -35,6 +35,8 @@ UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAX
            r"^int p = 0; p < ", r"^p < ", r"^int it = ",
            # rollout_chain.hip line search: `mine` is uniform over a 32-lane group and `other` is the partner group's `mine`, so `mine != other`
            # has the same value in both groups of the wavefront
+           # rollout_treereg.hip: schedule lengths and the largest child count are mechanism constants (TreeRegDev), the same in every lane
+           r"^int s = 0; s < (ne_steps|nb_steps)", r"^s < (ne_steps|nb_steps)", r"^int k = 0; k < maxchild",
            r"^mine != other$", r"^int i = 0; i < \d+; i\+\+$",        # (compile-time unrolled component loops)
            # rollout_loop.hip project_model_kernel: tree reductions over a fixed workgroup size, pivot steps up to the kernel argument ml, and the
            # stop on s_pi -- a __shared__ word written by thread 0 and read by everyone behind a barrier
