@@ -606,7 +606,7 @@ def test_newton_mode_residual_only_is_a_measured_error_option(cclqr, orc):
     """cclqr_rollout_opts.newton_mode = 1 (stop on ||f|| < eps alone): NOT the parity mode.  The default stays the exact rule (= the
     oracle, checked here once more); the option's deviation from it is MEASURED and printed (2e-8 over these 200 steps under random
     gains -- already past the north star's 1e-8, which is why it is an option; the headline workload's figure is in DESIGN.md 4.1d);
-    its Newton iteration counts are never larger.  Refused for trees, closed loops and the friction / noise / PID laws."""
+    its Newton iteration counts are never larger.  Refused under the friction / noise / PID laws."""
     capi = cclqr._capi
     n_links, steps, n = 7, 200, 96
     ex = cclqr.examples.cartpole_n(n_links)
@@ -626,10 +626,8 @@ def test_newton_mode_residual_only_is_a_measured_error_option(cclqr, orc):
     dev = np.abs(tr1 - tr0).max()
     print("newton_mode 1: max |state - exact rule| over %d steps = %.3g; max Newton iterations %d -> %d" % (steps, dev, st0.max(), st1.max()))
     assert (st1 > 0).all() and 0.0 < dev < 1e-6 and (st1 <= st0).all() and st1.max() < st0.max()
-    ext = cclqr.examples.dual_cartpole()                     # a branching tree: the LDS-resident kernel keeps the exact rule only
-    tt = ext["mech"].tables()
-    mt = capi.MechHandle(tt)
-    ct = capi.CtrlHandle(mt, [0], K=np.zeros((5, 1, 12 * tt.nb)), N=6, zd=None)
+    # branching trees take the option since round 4 (tests/test_gpu_treereg.py); the friction / noise / PID laws keep the exact rule only
+    cf = capi.CtrlHandle(mech, [0], K=K, N=steps + 20, zd=zd, fric=np.full(t.ne, 0.01))
     with pytest.raises(capi.CclqrError) as e:
-        capi.rollout(mt, ct, ext["mech"].state()[None], 3, newton_mode=1)
+        capi.rollout(mech, cf, z0[:2], 3, newton_mode=1)
     assert e.value.code == capi.EUNSUPPORTED

@@ -1,0 +1,146 @@
+"""GPU tests of the register-resident tree kernel (csrc/rollout_treereg.hip) beyond tests/test_gpu_tree.py: the control laws that came with it
+(PID, injected and Philox noise, friction; newton_mode 1), launches chained through multipliers and PID state, every image size up to 32 links,
+and the launch geometry.  Everything goes through the C-ABI and is compared with the oracle."""
+import numpy as np
+import pytest
+
+from test_tree import TREES, build, _random_parents
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _starts(cclqr, ex, rng, n):
+    z0 = []
+    for _ in range(n):
+        for e in ex["joints"]:
+            cclqr.setJointPosition(ex["mech"], e, rng.uniform(-0.5, 0.5))
+        z0.append(ex["mech"].state())
+    return np.stack(z0)
+
+
+@pytest.mark.parametrize("name", ["dual_cartpole", "three_children", "deep"])
+def test_tree_pid_friction_and_injected_noise_match_oracle(cclqr, orc, name):
+    """PID on two joints (pid.jl:69-88) on top of the LQR law with joint friction and injected noise (trackingLQR_triple_cartpole.jl:93-111) on
+    branching mechanisms: the tree kernel's EXTRA = 2 instantiation against the oracle"""
+    capi = cclqr._capi
+    ex = build(cclqr, name)
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(17)
+    z0 = _starts(cclqr, ex, rng, 5)
+    steps = 50
+    cj = [0, t.ne - 1]
+    K = rng.normal(size=(steps + 5, 2, 12 * t.nb)) * 0.05
+    noise = rng.normal(size=(len(z0), steps))
+    pid = dict(joint=[1, t.ne - 1], P=[2.0, 1.0], I=[0.5, 0.2], D=[0.1, 0.05], goal=[0.2, -0.1])
+    kw = dict(K=K, N=steps + 6, zd=z0[0], Fd=rng.normal(size=(1, 2)) * 0.3, fric=rng.uniform(0, 0.05, t.ne), noise_scale=0.3, pid=pid)
+    zo, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, cj, noise=noise, **kw), z0, steps, record=True)
+    h = capi.MechHandle(t)
+    zT, traj, st = capi.rollout(h, capi.CtrlHandle(h, cj, **kw), z0, steps, noise=noise, record=True)
+    assert (st_o > 0).all() and np.array_equal(st > 0, st_o > 0)
+    assert np.abs(traj - traj_o).max() < TOL and np.abs(zT - zo).max() < TOL
+
+
+def test_tree_philox_noise_and_instance_offset(cclqr, orc):
+    """device-generated Philox noise on a tree == the oracle's stream per GLOBAL instance; a shard launched with first_instance reproduces its slice"""
+    capi = cclqr._capi
+    ex = build(cclqr, "y")
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(3)
+    steps, n = 40, 21
+    z0 = np.tile(ex["mech"].state(), (n, 1, 1))
+    K = rng.normal(size=(steps + 5, 1, 12 * t.nb)) * 0.05
+    kw = dict(K=K, N=steps + 6, zd=z0[0], fric=rng.uniform(0, 0.05, t.ne), noise_scale=0.5, noise_seed=0xBEEF)
+    _, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0, steps, record=True)
+    h = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(h, [0], **kw)
+    zT, traj, st = capi.rollout(h, ctrl, z0, steps, record=True)
+    assert (st > 0).all() and np.abs(traj[0] - traj[1]).max() > 1e-4
+    assert np.abs(traj - traj_o).max() < TOL
+    zT_s, _, _ = capi.rollout(h, ctrl, z0[9:16], steps, first_instance=9)
+    assert np.array_equal(zT_s, zT[9:16])
+
+
+def test_tree_chained_launches_equal_one_launch(cclqr, orc):
+    """step-per-launch use on a tree: multipliers (lam) and PID state carried between launches make 20 + 35 steps equal 55 steps in one, bit for bit"""
+    import torch
+    capi = cclqr._capi
+    ex = build(cclqr, "deep")
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(5)
+    z0 = _starts(cclqr, ex, rng, 7)
+    n, steps = len(z0), 55
+    K = rng.normal(size=(steps + 5, 1, 12 * t.nb)) * 0.05
+    pid = dict(joint=[2], P=[1.5], I=[0.4], D=[0.05], goal=[0.1])
+    h = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(h, [0], K=K, N=steps + 6, zd=z0[0], pid=pid)
+    dev = torch.device("cuda", 0)
+    z0_d = torch.from_numpy(z0).to(dev)
+    one, a, b = torch.empty_like(z0_d), torch.empty_like(z0_d), torch.empty_like(z0_d)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    capi.rollout_dev(h, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, 0, one.data_ptr(), st.data_ptr())
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+    pstate = torch.zeros((n, t.nb, 2), dtype=torch.float64, device=dev)
+    capi.rollout_dev(h, ctrl, n, 20, 1, z0_d.data_ptr(), lam.data_ptr(), 0, 0, 0, a.data_ptr(), st.data_ptr(), pid_state=pstate.data_ptr())
+    capi.rollout_dev(h, ctrl, n, 35, 21, a.data_ptr(), lam.data_ptr(), 0, 0, 0, b.data_ptr(), st.data_ptr(), pid_state=pstate.data_ptr())
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() > 0).all()
+    assert torch.equal(b, one)
+    zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=steps + 6, zd=z0[0], pid=pid), z0, steps)
+    assert np.abs(one.cpu().numpy() - zo).max() < TOL
+
+
+def test_tree_newton_mode_residual_only(cclqr, orc):
+    """newton_mode 1 on a tree (the RELAX instantiation): never more iterations than the exact rule, a small measured deviation from it"""
+    capi = cclqr._capi
+    ex = build(cclqr, "deep")
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(8)
+    z0 = _starts(cclqr, ex, rng, 24)
+    steps = 80
+    K = rng.normal(size=(steps + 5, 1, 12 * t.nb)) * 0.05
+    h = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(h, [0], K=K, N=steps + 6, zd=z0[0])
+    zT0, tr0, st0 = capi.rollout(h, ctrl, z0, steps, record=True)
+    zT1, tr1, st1 = capi.rollout(h, ctrl, z0, steps, record=True, newton_mode=1)
+    _, tro, sto = orc.rollout(t, orc.ctrl_desc(t.nb, [0], K=K, N=steps + 6, zd=z0[0]), z0[:4], steps, record=True)
+    assert np.abs(tr0[:4] - tro).max() < TOL and np.array_equal(st0[:4], sto)
+    dev = np.abs(tr1 - tr0).max()
+    print("tree, newton_mode 1: max |state - exact rule| over %d steps = %.3g; max Newton iterations %d -> %d" % (steps, dev, st0.max(), st1.max()))
+    assert (st1 > 0).all() and dev < 1e-6 and (st1 <= st0).all()
+
+
+@pytest.mark.parametrize("nb,seed", [(9, 1), (11, 2), (13, 3), (16, 4), (20, 5), (24, 6), (29, 7), (32, 8)])
+def test_every_image_size_up_to_32_links(cclqr, orc, nb, seed):
+    """random forests of 9 .. 32 bodies (up to 4 child joints per body): the 32-lane instantiations for images of 10, 12, 14, 16, 24 and 32 links"""
+    capi = cclqr._capi
+    rng = np.random.default_rng(4000 + seed)
+    parents = _random_parents(rng, nb)
+    if not any(parents.count(a) > 1 for a in set(parents) if a >= 0):
+        parents[-1] = parents[-2] if parents[-2] >= 0 else 0      # make sure it branches
+    prism = tuple(int(i) for i in range(nb) if rng.uniform() < 0.15)
+    ex = cclqr.examples.tree_mechanism(parents, seed=seed, prismatic=prism, g=-9.81 if seed % 2 else 0.0)
+    t = ex["mech"].tables()
+    z0 = _starts(cclqr, ex, rng, 5)
+    steps = 15
+    cj = sorted(set(int(j) for j in rng.integers(0, t.ne, 2)))
+    K = rng.normal(size=(steps + 3, len(cj), 12 * t.nb)) * 0.03
+    kw = dict(K=K, N=steps + 4, zd=z0[0], Fd=rng.normal(size=(1, len(cj))) * 0.2)
+    zo, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, cj, **kw), z0, steps, record=True)
+    h = capi.MechHandle(t)
+    lanes, lds = h.geometry()
+    assert lanes == 32 and lds <= 160 * 1024
+    zT, traj, st = capi.rollout(h, capi.CtrlHandle(h, cj, **kw), z0, steps, record=True)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < TOL
+
+
+def test_tree_launch_geometry(cclqr):
+    """two instances of the 14-body tree per wavefront in an image that lets four workgroups share a CU's 160 KB (the LDS-resident kernel of
+    rounds 1-3: one instance per wavefront); four instances of the dual-pole cart per wavefront"""
+    capi = cclqr._capi
+    ex = build(cclqr, "deep")
+    lanes, lds = capi.MechHandle(ex["mech"].tables()).geometry()
+    assert lanes == 32 and 4 * lds <= 160 * 1024
+    lanes, lds = capi.MechHandle(build(cclqr, "dual_cartpole")["mech"].tables()).geometry()
+    assert lanes == 16
