@@ -412,6 +412,7 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
         if args.links == 16 and args.instances >= 1024:     # the default headline run: the 16-BODY chain (N = 15) next to the 17-body one
             more["chain_16_bodies_N15"] = chain_rate(pkg, capi, torch, dev, 15, args.instances, args.sim_steps, count)
         more.update(other_configs(pkg, capi, torch, dev, count))
+        more["branching_tree_14_bodies"] = tree14_rate(pkg, capi, torch, dev, count)
     except Exception as e:        # the extra lines never take the headline line down with them
         more["other_configs_error"] = repr(e)
     m = mu + ml
@@ -430,7 +431,9 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
 def kernel_name(mh, extra=0):
     """the instantiation a mechanism's rollouts run (extra: 0 plain LQR / TrackingLQR law, 1 + friction and noise, 2 + PID)"""
     lanes, _ = mh.geometry()
-    return "rollout_chain_kernel<%d, %d, %d, false>" % (lanes, mh.layout_links(), extra)
+    par = np.asarray(mh.tables.parent)
+    branching = mh.tables.ne == mh.tables.nb and (np.bincount(par[par >= 0], minlength=1) > 1).any()
+    return "%s<%d, %d, %d, false>" % ("rollout_treereg_kernel" if branching else "rollout_chain_kernel", lanes, mh.layout_links(), extra)
 
 
 def flops_per_instance_step(t, octrl_kw, z0, steps, n_sample=4):
@@ -476,6 +479,33 @@ def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_
         out["roofline_fp64_valu"] = roofline_fp64(f_step, n, steps, kernel_ms, kernel)
     if bad and allow_failed:      # a rate over rollouts that partly left the integrator's domain is NOT a throughput: labelled, never `value`
         out["attempted_instance_steps_per_s_incl_failed"] = n * steps / dt
+    return out
+
+
+TREE14_PARENTS = [-1, 0, 1, 2, 3, 2, 5, 6, 1, 8, 8, 10, 0, 12]
+
+
+def tree14_workload(pkg, n=32768, steps=300):
+    """a BRANCHING mechanism (not a BASELINE config): 14 bodies, body i on body TREE14_PARENTS[i] by a revolute (bodies 0 and 5: prismatic)
+    joint with random axis and anchors (examples.tree_mechanism, seed 4), every instance from the placed pose, random gains of scale 0.02 on joint 0"""
+    ex = pkg.examples.tree_mechanism(TREE14_PARENTS, seed=4, prismatic=(0, 5))
+    mech = ex["mech"]
+    t, z00 = mech.tables(), mech.state()
+    K = np.random.default_rng(0).normal(size=(steps + 5, 1, 12 * t.nb)) * 0.02
+    octrl = dict(ctrl_joint=[0], K=K, N=steps + 6, zd=z00)
+    return t, octrl, np.tile(z00[None], (n, 1, 1)), steps
+
+
+def tree14_rate(pkg, capi, torch, dev, count=True):
+    t, octrl, z0, steps = tree14_workload(pkg)
+    mh = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mh, octrl["ctrl_joint"], K=octrl["K"], N=octrl["N"], zd=octrl["zd"])
+    f = flops_per_instance_step(t, octrl, z0, steps) if count else None
+    lanes, lds = mh.geometry()
+    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, False, f_step=f, kernel=kernel_name(mh)), lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
+               workload="branching tree of 14 bodies (parents %s, tools/gpu_tree_rate.py), %d instances x %d steps, record=false: the register-resident tree "
+                        "kernel of round 4 (8.0 M inst-steps/s on the LDS-resident kernel of rounds 1-3)" % (TREE14_PARENTS, len(z0), steps))
+    ctrl.close(); mh.close()
     return out
 
 

@@ -138,7 +138,7 @@ class MechHandle:
         return lanes.value, ldsb.value
 
     def layout_links(self):
-        """links the chain kernel's LDS image is laid out for (names the instantiation); 0 for tree / closed-loop mechanisms"""
+        """links the rollout kernel's LDS image is laid out for (names the instantiation of the chain / tree kernel); 0 for closed-loop mechanisms"""
         n = C.c_int32(0)
         check(lib().cclqr_rollout_layout_links(self.ptr, C.byref(n)))
         return n.value

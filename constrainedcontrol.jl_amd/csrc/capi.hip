@@ -266,7 +266,9 @@ extern "C" int cclqr_ctrl_destroy(cclqr_ctrl* c) {
 
 extern "C" int cclqr_rollout_layout_links(const cclqr_mech* m, int32_t* links) {
     if (!m || !links) return fail(CCLQR_EINVAL, "null argument");
-    *links = (m->host.loop || m->host.tree) ? 0 : chain_layout_links(m->nb);      // 0: not a chain-kernel mechanism
+    // links the rollout kernel's LDS image is laid out for (it names the instantiation): chains rollout_chain_kernel, branching trees
+    // rollout_treereg_kernel; 0 for closed-loop mechanisms (one kernel, runtime layout)
+    *links = m->host.loop ? 0 : (m->host.tree ? treereg_layout_links(m->nb, m->host.tree) : chain_layout_links(m->nb));
     return CCLQR_OK;
 }
 

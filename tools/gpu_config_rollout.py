@@ -1,6 +1,6 @@
 """diagnostic (not a test): ONE BASELINE config's rollout launched a few times and nothing else, so that a rocprofv3 --pmc pass attributes
 its counters to that config's kernel (tools/profile_configs.sh).  python tools/gpu_config_rollout.py <cartpole_cfg2|cartpole_cfg2_filled|
-sawyer_cfg4|tracking_cfg5> [launches]   -> one JSON line: kernel, instances, steps, wavefronts, ms per launch"""
+sawyer_cfg4|tracking_cfg5|tree14> [launches]   -> one JSON line: kernel, instances, steps, wavefronts, ms per launch"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,6 +25,10 @@ elif cfg == "tracking_cfg5":
     z0 = np.tile(z00, (16384, 1, 1))
     steps, record, extra = 1000, True, 1
     mh = mech._cclqr_handle; ctrl = tl._ctrl_handle(mh, fric=ex["fric"], noise_scale=2.0, noise_seed=0xC0FFEE)
+elif cfg == "tree14":
+    t, octrl, z0, steps = bench.tree14_workload(pkg)
+    record = False
+    mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, octrl["ctrl_joint"], K=octrl["K"], N=octrl["N"], zd=octrl["zd"])
 else:
     raise SystemExit("unknown config " + cfg)
 r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=reps, kernel=bench.kernel_name(mh, extra))
