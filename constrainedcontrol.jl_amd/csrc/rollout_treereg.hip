@@ -527,7 +527,13 @@ hipError_t launch_rollout_treereg(const RolloutArgs& a, int nb, int tree8, int n
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
     if (nb > G || nb > nbp) return hipErrorInvalidValue;
-    if (G == 16) return nbp == 4 ? launch_treereg_one<16, 4>(a, extra, newton_mode, grid, lds, stream) : launch_treereg_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
+    if (G == 16) {
+#if TR_G16_MAXLINKS > 8
+        if (nbp == 14) return launch_treereg_one<16, 14>(a, extra, newton_mode, grid, lds, stream);
+        if (nbp > 8) return hipErrorInvalidValue;
+#endif
+        return nbp == 4 ? launch_treereg_one<16, 4>(a, extra, newton_mode, grid, lds, stream) : launch_treereg_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
+    }
     switch (nbp) {
         case 8: return launch_treereg_one<32, 8>(a, extra, newton_mode, grid, lds, stream);
         case 10: return launch_treereg_one<32, 10>(a, extra, newton_mode, grid, lds, stream);
