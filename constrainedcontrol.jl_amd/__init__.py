@@ -5,7 +5,7 @@ Arithmetic on the hot path happens only in csrc/ (HIP, through the C-ABI of incl
 the host-side mirror of the reference's plugin interface and never falls back to a CPU implementation.
 """
 from .mechanism import (Body, Box, EqualityConstraint, FixedOrientation, MechTables, Mechanism, Origin, Prismatic, Quaternion, Revolute, RotX, RotY, RotZ,
-                        getid, mechanism_from_urdf_tables, minimal_to_maximal, one_quaternion, parse_urdf, qconj, qmul, setJointPosition, setPosition, setVelocity, vrotate, joint_position_states)
+                        getid, mechanism_from_urdf_tables, minimal_to_maximal, one_quaternion, parse_urdf, qconj, qmul, setJointPosition, setPosition, setVelocity, vrotate, joint_position_states, urdf_lump_fixed)
 from . import examples
 from . import _capi
 from . import dist

@@ -172,7 +172,7 @@ class Mechanism:
         if "Δt" in kw:
             dt = kw.pop("Δt")
         if isinstance(origin, str):      # Mechanism(path, floating=false, g=0.0)   examples/lqr_sawyer.jl:9
-            m = mechanism_from_urdf_tables(parse_urdf(origin), floating=floating, g=g, dt=0.01 if dt is None else dt)
+            m = mechanism_from_urdf_tables(parse_urdf(origin, keep_fixed=True), floating=floating, g=g, dt=0.01 if dt is None else dt)
             self.__dict__.update(m.__dict__)
             return
         if kw:
@@ -333,9 +333,10 @@ def joint_position_states(mech, θ):
 
 
 # ------------------------------------------------------------------ URDF subset: Mechanism(path, floating=false, g=0.0)
-def parse_urdf(path):
+def parse_urdf(path, keep_fixed=False):
     """links (mass, COM offset, inertia about the COM in the link frame) and revolute/prismatic joints of a URDF file.
-    Returns a plain dict of numbers (also the format of tests/golden/sawyer_arm_tables.json)."""
+    Returns a plain dict of numbers (also the format of tests/golden/sawyer_arm_tables.json).  keep_fixed: `fixed` joints are returned too
+    (type "fixed"; mechanism_from_urdf_tables lumps the links they hold together, urdf_lump_fixed) instead of being refused."""
     import xml.etree.ElementTree as ET
     root = ET.parse(path).getroot()
 
@@ -357,13 +358,63 @@ def parse_urdf(path):
                                      inertia=[float(I.get(k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")])
     for jn in root.findall("joint"):
         typ = jn.get("type")
-        if typ not in ("revolute", "continuous", "prismatic"):
+        if typ not in ("revolute", "continuous", "prismatic") and not (keep_fixed and typ == "fixed"):
             raise ValueError("URDF joint type %r is outside the supported subset (1-DoF joints)" % typ)
         org = jn.find("origin")
         ax = jn.find("axis")
-        joints.append(dict(name=jn.get("name"), type="prismatic" if typ == "prismatic" else "revolute", parent=jn.find("parent").get("link"),
+        joints.append(dict(name=jn.get("name"), type=typ if typ in ("prismatic", "fixed") else "revolute", parent=jn.find("parent").get("link"),
                            child=jn.find("child").get("link"), xyz=vec(org.get("xyz") if org is not None else None),
                            rpy=vec(org.get("rpy") if org is not None else None), axis=vec(ax.get("xyz")) if ax is not None else [1.0, 0.0, 0.0]))
+    return dict(links=links, joints=joints)
+
+
+def _rotmat(q):
+    return np.array([vrotate(e, q) for e in np.eye(3)]).T
+
+
+def _link_inertia(L):
+    """3x3 inertia about the COM in the LINK frame (the URDF gives it in the inertial frame, rotated by the inertial origin's rpy)"""
+    I = np.array([[L["inertia"][0], L["inertia"][1], L["inertia"][2]], [L["inertia"][1], L["inertia"][3], L["inertia"][4]],
+                  [L["inertia"][2], L["inertia"][4], L["inertia"][5]]])
+    if any(abs(a) > 0 for a in L["rpy"]):
+        Rm = _rotmat(rpy_quaternion(*L["rpy"]))
+        I = Rm @ I @ Rm.T
+    return I
+
+
+def urdf_lump_fixed(tab):
+    """parse_urdf(keep_fixed=True) tables -> tables without `fixed` joints: every link held by a fixed joint is lumped into the link it is fixed
+    to (one rigid body: summed mass, common COM, inertias moved by the parallel-axis theorem), and the joints that hung off it are re-anchored
+    on the lumped link (their origin transforms composed; the composed rotation is kept as a quaternion, key "quat").  The motion of the
+    remaining bodies is that of the original mechanism.  (The reference's dependency keeps a fixed joint as a 6-row constraint between two
+    bodies; the hot path here has 5-row joints only -- SURVEY 8f-2.)"""
+    links = {k: dict(v) for k, v in tab["links"].items()}
+    joints = [dict(j) for j in tab["joints"]]
+    for j in joints:
+        j.setdefault("quat", list(rpy_quaternion(*j["rpy"])))
+    S = lambda d: float(d @ d) * np.eye(3) - np.outer(d, d)
+    while True:
+        # a fixed joint whose child carries no further fixed joint below it: lump leaf-first so that every transform is used once
+        fixed = [j for j in joints if j["type"] == "fixed"]
+        if not fixed:
+            break
+        j = next(f for f in fixed if not any(g["type"] == "fixed" and g["parent"] == f["child"] for g in joints))
+        P, Cn = links[j["parent"]], links[j["child"]]
+        q = np.asarray(j["quat"], dtype=np.float64)
+        Rpc, xyz = _rotmat(q), np.asarray(j["xyz"], dtype=np.float64)
+        mp, mc = P["mass"], Cn["mass"]
+        cp, cc = np.asarray(P["com"], dtype=np.float64), xyz + Rpc @ np.asarray(Cn["com"], dtype=np.float64)
+        M = mp + mc
+        com = (mp * cp + mc * cc) / M if M > 0 else cp
+        I = _link_inertia(P) + mp * S(cp - com) + Rpc @ _link_inertia(Cn) @ Rpc.T + mc * S(cc - com)
+        links[j["parent"]] = dict(mass=M, com=list(com), rpy=[0.0, 0.0, 0.0], inertia=[I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]])
+        for g in joints:                      # what hung off the lumped link now hangs off its holder
+            if g is not j and g["parent"] == j["child"]:
+                g["parent"] = j["parent"]
+                g["xyz"] = list(xyz + Rpc @ np.asarray(g["xyz"], dtype=np.float64))
+                g["quat"] = list(qmul(q, np.asarray(g["quat"], dtype=np.float64)))
+        del links[j["child"]]
+        joints.remove(j)
     return dict(links=links, joints=joints)
 
 
@@ -373,6 +424,8 @@ def mechanism_from_urdf_tables(tab, floating=False, g=-9.81, dt=0.01):
     are full 3x3.  The bodies are placed at the zero pose."""
     if floating:
         raise NotImplementedError("floating base needs a 6-DoF root joint, outside the 1-DoF scope (lqr.jl:1-2)")
+    if any(j["type"] == "fixed" for j in tab["joints"]):
+        tab = urdf_lump_fixed(tab)
     links, joints = tab["links"], tab["joints"]
     children = {j["child"] for j in joints}
     roots = [n for n in links if n not in children]
@@ -388,15 +441,10 @@ def mechanism_from_urdf_tables(tab, floating=False, g=-9.81, dt=0.01):
             if j["parent"] not in body_of:
                 continue
             L = links[j["child"]]
-            Ic = np.array([[L["inertia"][0], L["inertia"][1], L["inertia"][2]], [L["inertia"][1], L["inertia"][3], L["inertia"][4]],
-                           [L["inertia"][2], L["inertia"][4], L["inertia"][5]]])
-            if any(abs(a) > 0 for a in L["rpy"]):
-                from_rpy = rpy_quaternion(*L["rpy"])
-                Rm = np.array([vrotate(e, from_rpy) for e in np.eye(3)]).T
-                Ic = Rm @ Ic @ Rm.T
+            Ic = _link_inertia(L)
             b = Body(L["mass"], Ic, name=j["child"])
             com[j["child"]] = np.asarray(L["com"], dtype=np.float64)
-            qj = rpy_quaternion(*j["rpy"])
+            qj = np.asarray(j["quat"], dtype=np.float64) if "quat" in j else rpy_quaternion(*j["rpy"])
             axis_parent = vrotate(np.asarray(j["axis"], dtype=np.float64), qj)
             p1 = np.asarray(j["xyz"], dtype=np.float64) - com[j["parent"]]
             p2 = -com[j["child"]]

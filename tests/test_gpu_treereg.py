@@ -144,3 +144,38 @@ def test_tree_launch_geometry(cclqr):
     assert lanes == 32 and 4 * lds <= 160 * 1024
     lanes, lds = capi.MechHandle(build(cclqr, "dual_cartpole")["mech"].tables()).geometry()
     assert lanes == 16
+
+
+def test_whole_sawyer_robot_lqr_pipeline(cclqr, orc):
+    """examples_files/sawyer.urdf (fixed joints lumped: eight bodies, head and arm both on the first link) through the mirror like
+    examples/lqr_sawyer.jl does for the arm alone: URDF numbers -> Mechanism -> LQR (mx = 96, mu = 8, ml = 40: tree linearisation + Riccati on
+    the device) -> batched simulate! on the register-resident tree kernel; gains and trajectories against the oracle"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_full_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    assert t.nb == 8 and sum(1 for a in t.parent if a == 0) == 2
+    ids = [cclqr.getid(b) for b in mech.bodies]
+    eids = [cclqr.getid(e) for e in mech.eqconstraints]
+    lqr = cclqr.LQR(mech, ids, eids, ex["Q"], ex["R"], 2.0, xd=ex["xd"], qd=ex["qd"])
+    assert lqr.K.shape == (199, 8, 96)
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    Ao, Buo, Blo, Go = orc.linearize(t, lqr.zd[0], list(range(8)), np.zeros(8))
+    for a, b in zip((lqr.A, lqr.Bu, lqr.Bλ, lqr.G), (Ao, Buo, Blo, Go)):
+        assert rel(a, b) < 1e-10
+    Ko, kbo = orc.riccati(Ao, Buo, Blo, Go, lqr.Q, lqr.R, 200)
+    assert lqr.kbreak == kbo and rel(lqr.K, Ko) < 1e-7
+    rng = np.random.default_rng(1)
+    z0 = []
+    for n in range(9):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.02, 0.02))
+        z0.append(mech.state())
+    z0 = np.stack(z0)
+    st = cclqr.simulate(mech, 1.5, lqr, z0=z0)
+    oc = orc.ctrl_desc(8, list(range(8)), K=lqr.K, N=lqr.N, zd=lqr.zd)
+    _, traj, sto = orc.rollout(t, oc, z0, 150, record=True)
+    assert (sto > 0).all() and np.array_equal(st.status > 0, sto > 0)
+    assert np.abs(st.z - traj).max() < 1e-9

@@ -285,6 +285,70 @@ def test_sawyer_fixture_matches_reference_urdf_when_present(cclqr):
     assert len(ex["mech"].bodies) == 7 and ex["mech"].tables().ml == 35      # Nb = 7, mλ = 35
 
 
+_URDF_FIXED = """<?xml version="1.0"?>
+<robot name="lumped">
+  <link name="base"/>
+  <link name="arm"><inertial><origin xyz="0 0 0.5" rpy="0 0 0"/><mass value="2.0"/><inertia ixx="0.2" ixy="0" ixz="0" iyy="0.2" iyz="0" izz="0.01"/></inertial></link>
+  <link name="tool"><inertial><origin xyz="0.1 0 0" rpy="0 0 0"/><mass value="1.0"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.03" iyz="0" izz="0.03"/></inertial></link>
+  <link name="marker"/>
+  <link name="finger"><inertial><origin xyz="0 0 0.05" rpy="0 0 0"/><mass value="0.2"/><inertia ixx="0.001" ixy="0" ixz="0" iyy="0.001" iyz="0" izz="0.0002"/></inertial></link>
+  <joint name="shoulder" type="revolute"><origin xyz="0 0 0.1" rpy="0 0 0"/><parent link="base"/><child link="arm"/><axis xyz="1 0 0"/></joint>
+  <joint name="tool_mount" type="fixed"><origin xyz="0 0 1.0" rpy="0 0 1.5707963267948966"/><parent link="arm"/><child link="tool"/></joint>
+  <joint name="marker_mount" type="fixed"><origin xyz="0.2 0 0" rpy="0 0 0"/><parent link="tool"/><child link="marker"/></joint>
+  <joint name="grip" type="prismatic"><origin xyz="0.2 0 0" rpy="0 0 0"/><parent link="tool"/><child link="finger"/><axis xyz="1 0 0"/></joint>
+</robot>
+"""
+
+
+def test_urdf_fixed_joints_are_lumped(cclqr, orc, tmp_path):
+    """a URDF `fixed` joint (examples_files/sawyer.urdf has 15) welds its child link to its parent: the reader lumps the two into one rigid body --
+    summed mass, common COM, parallel-axis inertia, the child's own joints re-anchored through the composed transform"""
+    f = tmp_path / "lumped.urdf"
+    f.write_text(_URDF_FIXED)
+    with pytest.raises(ValueError):
+        cclqr.parse_urdf(str(f))                                   # the strict reader still refuses what is not a 1-DoF joint
+    lump = cclqr.urdf_lump_fixed(cclqr.parse_urdf(str(f), keep_fixed=True))
+    assert sorted(lump["links"]) == ["arm", "base", "finger"] and [j["name"] for j in lump["joints"]] == ["shoulder", "grip"]
+    arm = lump["links"]["arm"]
+    # tool frame = arm frame moved to (0, 0, 1) and turned 90 deg about z: its COM (0.1, 0, 0) sits at (0, 0.1, 1) in the arm frame
+    assert np.isclose(arm["mass"], 3.0) and np.allclose(arm["com"], (2.0 * np.array([0, 0, 0.5]) + 1.0 * np.array([0, 0.1, 1.0])) / 3.0)
+    com = np.array(arm["com"])
+    S = lambda d: (d @ d) * np.eye(3) - np.outer(d, d)
+    I_tool_in_arm = np.diag([0.03, 0.01, 0.03])                    # diag(ixx, iyy, izz) with x and y swapped by the quarter turn
+    I = np.diag([0.2, 0.2, 0.01]) + 2.0 * S(np.array([0, 0, 0.5]) - com) + I_tool_in_arm + 1.0 * S(np.array([0, 0.1, 1.0]) - com)
+    got = arm["inertia"]
+    assert np.allclose([[got[0], got[1], got[2]], [got[1], got[3], got[4]], [got[2], got[4], got[5]]], I)
+    grip = lump["joints"][1]
+    assert grip["parent"] == "arm" and np.allclose(grip["xyz"], [0.0, 0.2, 1.0])          # (0.2, 0, 0) in the tool frame
+    mech = cclqr.Mechanism(str(f), floating=False, g=-9.81)
+    t = mech.tables()
+    assert t.nb == 2 and list(t.parent) == [-1, 0] and np.allclose(t.mass, [3.0, 0.2])
+    assert np.abs(orc.constraints(t, mech.state())).max() < 1e-14
+    # the finger slides along the TOOL's x axis = the arm's y axis
+    cclqr.setJointPosition(mech, mech.geteqconstraint("grip"), 0.05)
+    z = mech.state()
+    assert np.abs(orc.constraints(t, z)).max() < 1e-14 and np.allclose(z[1, 0:3], [0.0, 0.25, 1.1 + 0.05])
+
+
+def test_sawyer_full_fixture_is_a_branching_robot(cclqr, orc):
+    """examples_files/sawyer.urdf (24 links, 15 fixed joints; tests/golden/sawyer_full_tables.json holds its numbers): lumped it is the arm of
+    sawyer_arm.urdf plus the head on the first link -- eight bodies, a BRANCHING tree"""
+    import json
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "sawyer_full_tables.json")))
+    assert len(tab["links"]) == 24 and sum(j["type"] == "fixed" for j in tab["joints"]) == 15
+    ref = "/root/reference/examples/examples_files/sawyer.urdf"
+    if os.path.exists(ref):
+        assert cclqr.parse_urdf(ref, keep_fixed=True) == tab
+    mech = cclqr.mechanism_from_urdf_tables(tab, g=0.0)
+    t = mech.tables()
+    assert t.nb == 8 and t.ne == 8 and sorted(e.name for e in mech.eqconstraints) == sorted(["head_pan"] + ["right_j%d" % i for i in range(7)])
+    assert sum(1 for a in t.parent if a == 0) == 2                      # head and right_l1 both hang off right_l0
+    assert np.abs(orc.constraints(t, mech.state())).max() < 1e-14
+    total = sum(L["mass"] for L in tab["links"].values())
+    lumped = cclqr.urdf_lump_fixed(tab)["links"]
+    assert np.isclose(sum(L["mass"] for L in lumped.values()), total)
+
+
 def test_minimal_to_maximal_kinematics(cclqr, orc):
     """6-argument linearsystem's setpoint conversion (lqr.jl:80): joint coordinates/rates -> consistent maximal state"""
     ex = cclqr.examples.cartpole_n(3)

@@ -121,6 +121,31 @@ def test_emulated_register_resident_tree_rollout_matches_oracle(cclqr, orc, emu,
     assert np.abs(zT - zo).max() < 1e-9
 
 
+def test_emulated_whole_sawyer_robot(cclqr, orc, emu):
+    """examples_files/sawyer.urdf with its fixed joints lumped (tests/golden/sawyer_full_tables.json): eight bodies, the head and the arm both on
+    the first link -- a real robot that branches, under gravity, through the register-resident tree kernel's phases"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_full_tables.json")))
+    ex = cclqr.examples.sawyer(tab, g=-9.81)
+    mech = ex["mech"]
+    t = mech.tables()
+    rng = np.random.default_rng(3)
+    zd = mech.state()
+    K = rng.normal(size=(49, 8, 96)) * 0.004
+    z0 = []
+    for n in range(2):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-0.3, 0.3))
+        z0.append(mech.state())
+    z0 = np.stack(z0)
+    c = orc.ctrl_desc(8, list(range(8)), K=K, N=50, zd=zd, Fd=0.02 * rng.normal(size=(1, 8)))
+    zT_o, traj_o, st_o = orc.rollout(t, c, z0, 40, record=True)
+    zT, traj, st = emu_treereg_rollout(emu, orc, t, c, z0, 40)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10
+
+
 @pytest.mark.parametrize("name", ["dual_cartpole", "y", "four_children"])
 def test_emulated_tree_linearisation_matches_oracle(cclqr, orc, emu, name):
     ex = build(cclqr, name)
