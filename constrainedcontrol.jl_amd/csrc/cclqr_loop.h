@@ -28,7 +28,7 @@ HD Lay make_loop_layout(int nb, int nj) {
     L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;   L.DS = o; o += 6 * nb;
     L.LAM = o; o += 5 * nj;  L.LT = o; o += 5 * nj;  L.DL = o; o += 5 * nj;
     L.XQ = o; o += 7 * nb;   L.NB = o; o += 9 * nb;  L.DINV = o; o += 9 * nb; L.DTM = o; o += nb;
-    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nj;   L.R = o; o += 10 * nj;     // R: the solve's column permutation, then its pivot rows (as doubles)
+    L.D = o; o += 6 * nb;    L.G = o; o += 5 * nj;   L.R = o; o += 10 * nj;     // R: the solve's pivot columns, then its pivot rows (as doubles)
     L.GKA = o; o += BLK * nj; L.GKB = o; o += BLK * nj; L.GVA = o; o += BLK * nj; L.GVB = o; o += BLK * nj;
     L.UJ = o; o += nj;
     L.C = o; o += 6 * nb;    L.CD = o; o += 6 * nb;
@@ -195,78 +195,78 @@ HD void lp_schur_row(int row, const Lay& Y, double* L, const MechDev* M) {
     out[0] = rr;
 }
 
-// ---- dense solve with complete pivoting up to the numerical rank.  Lane = row for the whole solve (rows never move); columns are
-// swapped physically (every row swaps its own two entries) so that the columns still in play are contiguous, k .. mr-1 in step k.
-// Pivot choice: every remaining row carries its candidate as ONE 64-bit key -- the magnitude's bit pattern with the 12 lowest
-// mantissa bits replaced by 63 - row, 63 - column -- and the wavefront's largest key is the pivot: ties go to the smaller indices and
-// every lane ends with the same pivot.  A row finds its next candidate while it eliminates (the entries it has just updated are
-// the candidates of the next step), eight columns per pass: loads, arithmetic, stores -- no bounds test and no store between loads.
-// One wave barrier per step: after the column swap, before the pivot row is read.
-struct LoopRow {
-    int step;                     // pivot step this lane's row was used in (-1: not yet / never)
-    unsigned long long key;       // candidate of this row for the next step
+// ---- dense solve of the (singular, consistent) system S dl = r: Gauss-Jordan elimination, column by column, pivoting over the rows, that
+// SKIPS a column whose entries in the rows still in play are all below the rank tolerance (a redundant direction: its dl stays 0).
+// Lane = row for the whole solve, and since round 4 the row LIVES IN THE LANE'S REGISTERS (8 NCB >= 5 nj columns, compile time; the LDS
+// row it is loaded from is padded with zeros that far).  Nothing of the solve goes through LDS: with four wavefronts on a CU an LDS
+// instruction costs a wavefront ~17 cycles whatever its lane count (profiles/r04/lds_cost_vs_active_lanes_microbench.txt), and the
+// LDS-resident elimination with complete pivoting of rounds 2-3 spent 3.1-3.4 k cycles per pivot step on ~100 of them.  What shapes it:
+//   * the register file has no run-time index, so the COLUMN of a step must be known at compile time: columns are taken in their natural
+//     order (eight steps unrolled per pass of a run-time loop over eight-column blocks; the lane's entry in the step's column is a select
+//     over the blocks), and the pivot search runs over the ROWS -- one 32-bit key per lane (lp_row_key), the wavefront's largest key is
+//     the pivot row (ties go to the smaller row): six v_max_u32 with a DPP operand;
+//   * rank: a column whose largest candidate is below LOOP_RANK_TOL x the largest entry of the assembled system is skipped.  (Complete
+//     pivoting -- rounds 2-3, and two register-resident versions of it this round -- needs a column search per row and a run-time column:
+//     +120 and +90 instructions per step; measured 2.0 k cycles per step against ~1 k here.)
+//   * the pivot row reaches the other lanes by lane reads (v_readlane: the values land in scalar registers and feed the multiply-adds
+//     directly); blocks of columns that lie wholly before the current one are skipped (they hold rounding residue, never read again);
+//   * Gauss-Jordan, because in SIMD it is free: the retired rows' lanes execute the multiply-adds anyway, so they eliminate the column from
+//     their rows too and there is NO back substitution -- at the end a row that was a pivot row holds dl[its column] = rhs / pivot.
+// The multipliers of a loop mechanism are not unique; G_k' dl -- velocities, poses -- is (any solution of the consistent system).
+template <int NCB>
+struct LoopRowR {
+    double a[8 * NCB];            // the row (compile-time indices only: registers)
+    double rhs;
+    double ipiv;                  // 1 / pivot of the row once it has retired
+    int col;                      // the column this lane's row was the pivot row of (-1: not yet / never)
 };
 HD unsigned long long lp_bits(double v) { union { double d; unsigned long long u; } x; x.d = v; return x.u; }
-HD unsigned long long lp_cand(double v, int col) { return (lp_bits(fabs(v)) & ~0x3Full) | (unsigned long long)(63 - col); }     // within a row: 6 bits of column
-HD unsigned long long lp_row_key(unsigned long long cand, int row) { return (cand & ~0xFC0ull) | ((unsigned long long)(63 - row) << 6); }
-HD double lp_key_value(unsigned long long key) { union { double d; unsigned long long u; } x; x.u = key & ~0xFFFull; return x.d; }
-HD int lp_key_row(unsigned long long key) { return 63 - (int)((key >> 6) & 63); }
-HD int lp_key_col(unsigned long long key) { return 63 - (int)(key & 63); }
-// first candidate of row `row`: its largest entry
-HD void lp_row_init(LoopRow& R, int row, int mr, int stride, const Lay& Y, const double* L) {
-    R.step = -1; R.key = 0ull;
-    if (row >= mr) return;
-    const double* a = L + Y.SS + row * stride + 1;
-    unsigned long long best = 0ull;
-    for (int c0 = 0; c0 < mr; c0 += 8) {
-        double v[8];
+HD double lp_from_bits(unsigned long long u) { union { double d; unsigned long long u; } x; x.u = u; return x.d; }
+// a row's candidate as ONE 32-bit key: the high word of the magnitude (exponent and 20 mantissa bits) with its 6 lowest bits replaced by
+// 63 - row -- 14 bits of mantissa decide between candidates, which is all a pivot search needs (the pivot VALUE is read exactly, from the row)
+HD unsigned lp_row_key(double v, int row) { return ((unsigned)(lp_bits(fabs(v)) >> 32) & ~0x3Fu) | (unsigned)(63 - row); }
+HD int lp_key_row(unsigned key) { return 63 - (int)(key & 63); }
+// the lane's row out of the dense system (padding columns beyond 5 nj read the row's zero padding); returns its largest magnitude
+template <int NCB>
+HD double lpr_load(LoopRowR<NCB>& R, int row, int mr, int stride, const Lay& Y, const double* L) {
+    R.col = -1; R.ipiv = 0.0;
+    const double* a = L + Y.SS + (row < mr ? row : 0) * stride;
+    R.rhs = row < mr ? a[0] : 0.0;
+    double m_ = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = a[c0 + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const unsigned long long cu = lp_cand(v[u], c0 + u); if (c0 + u < mr && cu > best) best = cu; }
-    }
-    R.key = lp_row_key(best, row);
+    for (int c = 0; c < 8 * NCB; c++) { R.a[c] = row < mr ? a[1 + c] : 0.0; m_ = fmax(m_, fabs(R.a[c])); }       // lanes beyond 5 nj: a zero row
+    return row < mr ? m_ : 0.0;
 }
-// step k, first half: column pcol trades places with column k in EVERY row (retired pivot rows included: back substitution
-// addresses them by step index)
-HD void lp_col_swap(int row, int k, int pcol, int mr, int stride, const Lay& Y, double* L) {
-    if (pcol == k) return;
-    if (row < mr) { double* a = L + Y.SS + row * stride + 1; const double x = a[k]; a[k] = a[pcol]; a[pcol] = x; }
-    if (row == mr) { const double x = L[Y.R + k]; L[Y.R + k] = L[Y.R + pcol]; L[Y.R + pcol] = x; }
-}
-// step k, second half: the pivot row's lane retires; every other remaining row eliminates column k and finds its next candidate
-HD void lp_elim_search(LoopRow& R, int row, int k, int prow, int mr, int stride, const Lay& Y, double* L) {
-    if (row >= mr || R.step >= 0) return;
-    if (row == prow) { R.step = k; R.key = 0ull; L[Y.R + mr + k] = (double)prow; return; }
-    const double* p = L + Y.SS + prow * stride;
-    double* a = L + Y.SS + row * stride;
-    const double f = a[1 + k] / p[1 + k];
-    a[0] -= f * p[0];
-    unsigned long long best = 0ull;
-    for (int c0 = k + 1; c0 < mr; c0 += 8) {
-        double av[8], pv[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LOOP_OPAQUE(i) asm volatile("" : "+s"(i))
+#else
+#define LOOP_OPAQUE(i)
+#endif
+// the row's entry in column 8 kb + U (kb the same in every lane): a select over the blocks.  (Each comparison sees its own opaque copy of
+// kb: the optimiser otherwise folds the selects back into ONE load a[8 kb + U] with a run-time index -- and the row moves to scratch memory.)
+template <int NCB, int U>
+HD double lpr_entry(const LoopRowR<NCB>& R, int kb) {
+    double own = R.a[U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { av[u] = a[1 + c0 + u]; pv[u] = p[1 + c0 + u]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            av[u] -= f * pv[u];           // beyond column mr-1 this is padding: 0 - f 0
-            const unsigned long long cu = lp_cand(av[u], c0 + u);
-            if (c0 + u < mr && cu > best) best = cu;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) a[1 + c0 + u] = av[u];
-    }
-    R.key = lp_row_key(best, row);
+    for (int B = 1; B < NCB; B++) { int kq = kb; LOOP_OPAQUE(kq); own = (kq == B) ? R.a[8 * B + U] : own; }
+    return own;
 }
-// back substitution, pivot k (rank-1 .. 0) in row prow: x = r / a_kk ; the rows of EARLIER pivots take a_ik x out of their right-hand side
-HD void lp_back_step(const LoopRow& R, int row, int k, int prow, int mr, int stride, const Lay& Y, double* L) {
-    if (row >= mr || R.step < 0 || R.step > k) return;
-    const double* p = L + Y.SS + prow * stride;
-    const double xk = p[0] / p[1 + k];
-    if (R.step == k) { L[Y.DL + (int)L[Y.R + k]] = xk; return; }
-    double* a = L + Y.SS + row * stride;
-    a[0] -= a[1 + k] * xk;
+// the row's candidate for column col: 0 when the row is not in play
+template <int NCB>
+HD unsigned lpr_key(const LoopRowR<NCB>& R, int row, int mr, double own) { return (row < mr && R.col < 0) ? lp_row_key(own, row) : 0u; }
+// bookkeeping of a step (pivot row prow, column col, ip = 1 / pivot); returns the factor this lane's row eliminates with
+template <int NCB>
+HD double lpr_step(LoopRowR<NCB>& R, int row, int col, int prow, int mr, double own, double ip) {
+    if (row == prow) { R.col = col; R.ipiv = ip; }
+    return (row < mr && row != prow) ? own * ip : 0.0;          // retired rows too (Gauss-Jordan)
 }
+// the solution: dl[col] = rhs / pivot for the rows that were pivot rows (the columns that found none keep dl = 0)
+template <int NCB>
+HD void lpr_solution(const LoopRowR<NCB>& R, int row, int mr, const Lay& Y, double* L) {
+    if (row < mr && R.col >= 0) L[Y.DL + R.col] = R.rhs * R.ipiv;
+}
+// columns the instantiation must hold for nj joints
+HD int loop_col_blocks(int nj) { return (5 * nj + 7) / 8; }
 
 // body solve: cd = sum G_k' dl ; ds = D^-1 (d + cd)
 HD void lp_body_solve(int t, const Lay& Y, double* L, const MechDev* M) {

@@ -24,68 +24,85 @@ __device__ __forceinline__ double loop_eval(int t, const Lay& Y, double* L, cons
     return sqrt(group_sum<64>(part));
 }
 
-// maximum of one 64-bit key per lane over the wavefront, through the DPP crossbar (no LDS round trips): running maximum along
+// maximum of one 32-bit key per lane over the wavefront, through the DPP crossbar (no LDS round trips): running maximum along
 // each 16-lane row, row 0 -> 1 and 2 -> 3, rows {0,1} -> {2,3}; lane 63 holds the result, read back as a wavefront-uniform value
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long key_dpp_max(unsigned long long v) {
-    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+__device__ __forceinline__ unsigned key_dpp_max(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
     return o > v ? o : v;
 }
-__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+__device__ __forceinline__ unsigned wave_max_key(unsigned v) {
     v = key_dpp_max<0x111, 0xf>(v);      // row_shr:1
     v = key_dpp_max<0x112, 0xf>(v);      // row_shr:2
     v = key_dpp_max<0x114, 0xf>(v);      // row_shr:4
     v = key_dpp_max<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of each row holds the row's maximum
     v = key_dpp_max<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
     v = key_dpp_max<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's maximum
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-
-// S dl = r by elimination with complete pivoting up to the numerical rank; dl of the free (redundant) directions is 0
+// the wavefront's largest non-negative double
+__device__ __forceinline__ double wave_max_d(double v) {
+    for (int o = 1; o < 64; o <<= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double lane_read_d(double v, int lane) {       // lane: the same in every lane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// one step of the elimination: column 8 kb + U.  Returns whether the column found a pivot (the same in every lane).
+template <int NCB, int U>
+__device__ __forceinline__ bool loop_solve_step(LoopRowR<NCB>& R, int t, int kb, int mr, double tol) {
+    const int col = 8 * kb + U;
+    const double own = lpr_entry<NCB, U>(R, kb);
+    const int prow = lp_key_row(wave_max_key(lpr_key(R, t, mr, own)));            // uniform: every lane holds the same pivot row
+    const double piv = lane_read_d(own, prow);          // (no row in play: row 63's entry, 0 -- lanes beyond 5 nj hold zero rows)
+    const bool found = fabs(piv) > tol;
+    if (found) {
+        const double ip = 1.0 / piv;
+        const double f = lpr_step(R, t, col, prow, mr, own, ip);
+        R.rhs -= f * lane_read_d(R.rhs, prow);
+#pragma unroll
+        for (int B = 0; B < NCB; B++)
+            if (B >= kb) {                                     // (uniform) blocks before the current one hold residue nobody reads again
+#pragma unroll
+                for (int u = 0; u < 8; u++) R.a[8 * B + u] -= f * lane_read_d(R.a[8 * B + u], prow);
+            }
+    }
+    return found;
+}
+// S dl = r by Gauss-Jordan elimination over the columns that have a pivot, rows in registers (cclqr_loop.h); dl of the free (redundant) directions is 0
+template <int NCB>
 __device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const MechDev* M PROF_ARG) {
     const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
     lp_schur_row(t, Y, L, M);
-    if (t < mr) { L[Y.R + t] = (double)t; L[Y.DL + t] = 0.0; }
+    if (t < mr) L[Y.DL + t] = 0.0;
     __syncthreads();
     STAMP(PF_SCHUR_S);
-    LoopRow R;
-    lp_row_init(R, t, mr, stride, Y, L);
-    int rank = 0;
-    double first = 0.0;
-    for (int k = 0; k < mr; k++) {
-        const unsigned long long key = wave_max_key(R.key);            // uniform: every lane holds the same pivot
-        const double best = lp_key_value(key);
-        if (k == 0) first = best;
-        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) break;
-        const int prow = lp_key_row(key), pcol = lp_key_col(key);
-        lp_col_swap(t, k, pcol, mr, stride, Y, L);
-        __syncthreads();
-        lp_elim_search(R, t, k, prow, mr, stride, Y, L);
-        rank = k + 1;
+    LoopRowR<NCB> R;
+    const double tol = LOOP_RANK_TOL * wave_max_d(lpr_load(R, t, mr, stride, Y, L));
+#pragma unroll 1
+    for (int kb = 0; kb < NCB; kb++) {            // (columns beyond 5 nj are zero padding: no pivot, skipped)
+        loop_solve_step<NCB, 0>(R, t, kb, mr, tol); loop_solve_step<NCB, 1>(R, t, kb, mr, tol);
+        loop_solve_step<NCB, 2>(R, t, kb, mr, tol); loop_solve_step<NCB, 3>(R, t, kb, mr, tol);
+        loop_solve_step<NCB, 4>(R, t, kb, mr, tol); loop_solve_step<NCB, 5>(R, t, kb, mr, tol);
+        loop_solve_step<NCB, 6>(R, t, kb, mr, tol); loop_solve_step<NCB, 7>(R, t, kb, mr, tol);
     }
-    __syncthreads();
     STAMP(PF_TRI_FWD);
-    for (int k = rank - 1; k >= 0; k--) {
-        lp_back_step(R, t, k, (int)L[Y.R + mr + k], mr, stride, Y, L);
-        __syncthreads();
-    }
+    lpr_solution(R, t, mr, Y, L);
+    __syncthreads();
     STAMP(PF_TRI_BWD);
 }
 
 // newton! on the instance held in LDS (S / LAM = guess in, solution out), the rules of the tree kernels: returns the
 // iterations used; *failed = a non-finite residual (the instance has left the integrator's domain) or no convergence in NEWTON_MAXIT
 // eps_alone > 0: the measured-error mode of cclqr_rollout_opts.newton_mode = 1 (a solve also stops on ||f|| < eps_alone, whatever the step)
+template <int NCB>
 __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, bool* failed, double eps_alone PROF_ARG) {
     bool done = false, fail = false;
     int its = 0;
     double normf0 = loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);
     for (int iter = 1; iter <= NEWTON_MAXIT && !done; iter++) {
         PCOUNT(PF_NEWTON_ITERS);
-        loop_solve(t, Y, L, M PROF_PASS);
+        loop_solve<NCB>(t, Y, L, M PROF_PASS);
         lp_body_solve(t, Y, L, M);
         __syncthreads();
         STAMP(PF_BODY_SOLVE);
@@ -113,7 +130,8 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
     return its;
 }
 
-// relax: 0 = the reference's stopping rule, 1 = newton_mode 1 (a.eps_alone)
+// relax: 0 = the reference's stopping rule, 1 = newton_mode 1 (a.eps_alone).  NCB: the dense system's rows are held in registers 8 NCB columns wide
+template <int NCB>
 __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int relax) {
     extern __shared__ double lds[];
     const int t = threadIdx.x;
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int rel
         PCOUNT(PF_STEPS);
         // ---------------- newton! (tolerances and line search: SURVEY 8a-bis)
         bool failed = false;
-        const int its = dead ? 0 : loop_newton(t, Y, L, r, M, &failed, relax ? a.eps_alone : 0.0 PROF_PASS);
+        const int its = dead ? 0 : loop_newton<NCB>(t, Y, L, r, M, &failed, relax ? a.eps_alone : 0.0 PROF_PASS);
         const bool done = true;
         if (!dead) {
             const bool conv = done && !failed;
@@ -214,6 +232,7 @@ extern "C" int cclqr_prof_read_loop(unsigned long long* out, int reset) {
 // linearsystem(mechanism, xd, vd, qd, ωd, Fτd, bodyids, eqcids) (lqr.jl:63, lqr_tracking.jl:88) for a closed-loop mechanism: one knot per
 // wavefront -- one converged Newton step at the setpoint, then A, Bu, Bl, G with the multipliers exogenous (cclqr_lin_loop.h).  a.cj = joint
 // indices of the inputs; zd in the caller's body order (the closed-loop tables keep it).
+template <int NCB>
 __global__ __launch_bounds__(64) void linearize_loop_kernel(LinArgs a) {
     extern __shared__ double lds[];
     const int t = threadIdx.x, knot = blockIdx.x;
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(64) void linearize_loop_kernel(LinArgs a) {
     prof.start();
 #endif
     bool failed = false;
-    const int its = loop_newton(t, Y, L, r, M, &failed, 0.0 PROF_PASS);
+    const int its = loop_newton<NCB>(t, Y, L, r, M, &failed, 0.0 PROF_PASS);
     loop_eval<true>(t, Y, L, r, M, Y.S, 0.0 PROF_PASS);      // D_R^-1, N D_R^-1 and the next pose at the converged solution
     __syncthreads();
     lp_lin_joint(t, Y, JB, L, r, M);
@@ -348,13 +367,27 @@ __global__ __launch_bounds__(PROJ_THREADS) void project_model_kernel(int mx, int
 }
 
 size_t linearize_loop_lds_bytes(int nb, int nj) { return (size_t)(make_loop_layout(nb, nj).total + LJB * nj) * sizeof(double); }
+template <int NCB>
+static hipError_t launch_linearize_loop_t(const LinArgs& a, size_t lds, hipStream_t stream) {
+    hipError_t e = set_max_dynamic_lds_once((const void*)linearize_loop_kernel<NCB>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(linearize_loop_kernel<NCB>, dim3(a.nk), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
 hipError_t launch_linearize_loop(const LinArgs& a, int nb, int nj, hipStream_t stream) {
     if (a.nk <= 0) return hipSuccess;
     const size_t lds = linearize_loop_lds_bytes(nb, nj);
-    hipError_t e = set_max_dynamic_lds_once((const void*)linearize_loop_kernel, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(linearize_loop_kernel, dim3(a.nk), dim3(64), lds, stream, a);
-    return hipGetLastError();
+    switch (loop_col_blocks(nj)) {
+        case 1: return launch_linearize_loop_t<1>(a, lds, stream);
+        case 2: return launch_linearize_loop_t<2>(a, lds, stream);
+        case 3: return launch_linearize_loop_t<3>(a, lds, stream);
+        case 4: return launch_linearize_loop_t<4>(a, lds, stream);
+        case 5: return launch_linearize_loop_t<5>(a, lds, stream);
+        case 6: return launch_linearize_loop_t<6>(a, lds, stream);
+        case 7: return launch_linearize_loop_t<7>(a, lds, stream);
+        case 8: return launch_linearize_loop_t<8>(a, lds, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 // dynamic LDS of project_model_kernel; project_model_fits adds the kernel's static LDS (red_v, red_i, four scalars) before comparing with a CU's 160 KB
 size_t project_model_lds_bytes(int mx, int mu, int ml) { return ((size_t)ml * (ml + mx + mu) + ml) * sizeof(double) + 2 * (size_t)ml * sizeof(int) + 16; }
@@ -374,13 +407,27 @@ hipError_t launch_project_model(int nk, int mx, int mu, int ml, const double* A,
 
 size_t loop_lds_bytes(int nb, int nj) { return (size_t)make_loop_layout(nb, nj).total * sizeof(double); }
 
+template <int NCB>
+static hipError_t launch_rollout_loop_t(const RolloutArgs& a, size_t lds, int newton_mode, hipStream_t stream) {
+    hipError_t e = set_max_dynamic_lds_once((const void*)rollout_loop_kernel<NCB>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rollout_loop_kernel<NCB>, dim3((unsigned)a.n_inst), dim3(64), lds, stream, a, newton_mode != 0 ? 1 : 0);
+    return hipGetLastError();
+}
 hipError_t launch_rollout_loop(const RolloutArgs& a, int nb, int nj, int newton_mode, hipStream_t stream) {
     if (a.n_inst <= 0) return hipSuccess;
     const size_t lds = loop_lds_bytes(nb, nj);
-    hipError_t e = set_max_dynamic_lds_once((const void*)rollout_loop_kernel, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rollout_loop_kernel, dim3((unsigned)a.n_inst), dim3(64), lds, stream, a, newton_mode != 0 ? 1 : 0);
-    return hipGetLastError();
+    switch (loop_col_blocks(nj)) {       // 5 nj <= 60 columns (CCLQR_LOOP_MAXJ) in blocks of eight
+        case 1: return launch_rollout_loop_t<1>(a, lds, newton_mode, stream);
+        case 2: return launch_rollout_loop_t<2>(a, lds, newton_mode, stream);
+        case 3: return launch_rollout_loop_t<3>(a, lds, newton_mode, stream);
+        case 4: return launch_rollout_loop_t<4>(a, lds, newton_mode, stream);
+        case 5: return launch_rollout_loop_t<5>(a, lds, newton_mode, stream);
+        case 6: return launch_rollout_loop_t<6>(a, lds, newton_mode, stream);
+        case 7: return launch_rollout_loop_t<7>(a, lds, newton_mode, stream);
+        case 8: return launch_rollout_loop_t<8>(a, lds, newton_mode, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace cclqr

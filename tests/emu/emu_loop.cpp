@@ -30,31 +30,58 @@ double loop_eval(LoopInst& I, int s_off, double alpha) {
     return sqrt(acc);
 }
 
-void loop_solve(LoopInst& I) {
+template <int NCB, int U>
+void loop_solve_step(std::vector<LoopRowR<NCB>>& R, int kb, int mr, double tol) {
+    const int col = 8 * kb + U;
+    double own[64];
+    unsigned key = 0u;
+    for (int t = 0; t < 64; t++) {
+        own[t] = lpr_entry<NCB, U>(R[t], kb);
+        const unsigned kt = lpr_key(R[t], t, mr, own[t]);
+        if (kt > key) key = kt;                                    // the wavefront's maximum key
+    }
+    const int prow = lp_key_row(key);
+    if (!(fabs(own[prow]) > tol)) return;
+    const LoopRowR<NCB> P = R[prow];                               // the lane reads of the kernel (the pivot row before this step)
+    const double ip = 1.0 / own[prow];
+    for (int t = 0; t < 64; t++) {
+        const double f = lpr_step(R[t], t, col, prow, mr, own[t], ip);
+        R[t].rhs -= f * P.rhs;
+        for (int B = kb; B < NCB; B++)
+            for (int u = 0; u < 8; u++) R[t].a[8 * B + u] -= f * P.a[8 * B + u];
+    }
+}
+template <int NCB>
+void loop_solve_t(LoopInst& I) {
     const MechDev* M = I.M;
     const Lay& Y = I.Y;
     double* L = I.L;
     const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
     for (int t = 0; t < 64; t++) lp_schur_row(t, Y, L, M);
-    for (int t = 0; t < mr; t++) { L[Y.R + t] = (double)t; L[Y.DL + t] = 0.0; }
-    LoopRow R[64];
-    for (int t = 0; t < 64; t++) lp_row_init(R[t], t, mr, stride, Y, L);
-    int rank = 0;
-    double first = 0.0;
-    for (int k = 0; k < mr; k++) {
-        unsigned long long key = 0ull;
-        for (int t = 0; t < 64; t++) if (R[t].key > key) key = R[t].key;       // the wavefront's maximum key
-        const double best = lp_key_value(key);
-        if (k == 0) first = best;
-        if (!(best > LOOP_RANK_TOL * first) || !(best > 0.0)) break;
-        const int prow = lp_key_row(key), pcol = lp_key_col(key);
-        for (int t = 0; t < 64; t++) lp_col_swap(t, k, pcol, mr, stride, Y, L);
-        // lanes run in lock step on the GPU; the pivot row's lane only retires here and nobody writes that row, so a serial sweep is equivalent
-        for (int t = 0; t < 64; t++) lp_elim_search(R[t], t, k, prow, mr, stride, Y, L);
-        rank = k + 1;
+    for (int t = 0; t < mr; t++) L[Y.DL + t] = 0.0;
+    std::vector<LoopRowR<NCB>> R(64);
+    double amax = 0.0;
+    for (int t = 0; t < 64; t++) amax = fmax(amax, lpr_load(R[t], t, mr, stride, Y, L));
+    const double tol = LOOP_RANK_TOL * amax;
+    for (int kb = 0; kb < NCB; kb++) {
+        loop_solve_step<NCB, 0>(R, kb, mr, tol); loop_solve_step<NCB, 1>(R, kb, mr, tol);
+        loop_solve_step<NCB, 2>(R, kb, mr, tol); loop_solve_step<NCB, 3>(R, kb, mr, tol);
+        loop_solve_step<NCB, 4>(R, kb, mr, tol); loop_solve_step<NCB, 5>(R, kb, mr, tol);
+        loop_solve_step<NCB, 6>(R, kb, mr, tol); loop_solve_step<NCB, 7>(R, kb, mr, tol);
     }
-    for (int k = rank - 1; k >= 0; k--)
-        for (int t = 0; t < 64; t++) lp_back_step(R[t], t, k, (int)L[Y.R + mr + k], mr, stride, Y, L);
+    for (int t = 0; t < 64; t++) lpr_solution(R[t], t, mr, Y, L);
+}
+void loop_solve(LoopInst& I) {
+    switch (loop_col_blocks(I.M->nj)) {
+        case 1: loop_solve_t<1>(I); break;
+        case 2: loop_solve_t<2>(I); break;
+        case 3: loop_solve_t<3>(I); break;
+        case 4: loop_solve_t<4>(I); break;
+        case 5: loop_solve_t<5>(I); break;
+        case 6: loop_solve_t<6>(I); break;
+        case 7: loop_solve_t<7>(I); break;
+        default: loop_solve_t<8>(I); break;
+    }
 }
 }  // namespace
 
