@@ -248,14 +248,14 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instanc
 def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0,
                 first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0, newton_eps_alone=0.0):
     """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
-    Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][nb][2] doubles, noise_ws / noise_ws_len = caller's
+    Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][joints][2] doubles, noise_ws / noise_ws_len = caller's
     Philox workspace, newton_mode; none given: cclqr_rollout_dev (= NULL options)"""
     vp = lambda p: C.c_void_p(int(p)) if p else None
     if first_instance is None and pid_state is None and noise_ws is None and not newton_mode:
         check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                       vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
         return
-    o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.nb * 2 if pid_state else 0,
+    o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.ne * 2 if pid_state else 0,       # one pair per joint (a tree has nb joints, a loop mechanism more)
                     int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), 0, float(newton_eps_alone))
     check(lib().cclqr_rollout_ex(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), C.byref(o), vp(stream)))

@@ -300,7 +300,8 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     if (c->host.n_ctrl > 1 && first + n_inst > c->host.n_ctrl) return fail(CCLQR_EINVAL, "more instances than per-instance controller tables");
     const CtrlDev& H = c->host;
     double* pid_state = (opts && H.has_pid) ? opts->pid_state_dev : nullptr;      // never forwarded to a controller without a PID law
-    if (pid_state && opts->pid_state_len != n_inst * (int64_t)m->nb * 2) return fail(CCLQR_EINVAL, "pid_state_len must be n_inst * nb * 2");
+    const int pid_slots = m->host.loop ? m->nj : m->nb;           // one (integrated, last) pair per joint; a tree has as many joints as bodies
+    if (pid_state && opts->pid_state_len != n_inst * (int64_t)pid_slots * 2) return fail(CCLQR_EINVAL, "pid_state_len must be n_inst * nb * 2 (closed loops: n_inst * joints * 2)");
     // counter-based noise: generated for this launch into a workspace, read by the rollout like an injected array.  The workspace is the
     // caller's (opts->noise_ws_dev: required for launches that share one controller on different streams or threads) or the handle's,
     // which only ever grows OUTSIDE stream capture: hipMalloc / hipFree are illegal while a stream is being captured, so a captured
@@ -336,8 +337,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     const int newton_mode = opts ? opts->newton_mode : 0;
     a.eps_alone = (opts && opts->newton_eps_alone > 0.0) ? opts->newton_eps_alone : 1e-10;
     if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");
-    if (m->host.loop) {      // closed loops: LQR / TrackingLQR law, friction, noise, newton_mode 1; no PID (build_ctrl_tables refuses it)
-        if (extra == 2) return fail(CCLQR_EUNSUPPORTED, "closed-loop mechanisms take no PID law");
+    if (m->host.loop) {      // closed loops: one kernel, every law at run time (LQR / TrackingLQR, friction, noise, PID); newton_mode 1 under any of them
         HIPCHK(launch_rollout_loop(a, m->nb, m->nj, newton_mode, (hipStream_t)stream));
         return CCLQR_OK;
     }

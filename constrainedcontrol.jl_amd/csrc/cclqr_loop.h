@@ -40,7 +40,7 @@ HD Lay make_loop_layout(int nb, int nj) {
 }
 
 // constants of the owned body (t < nb: m, J) and of the owned joint (t < nj: vertices, axis, offset, row selectors)
-HD void loop_load_consts(LaneRegs& r, const MechDev* M, int t) {
+HD void loop_load_link_consts(LaneRegs& r, const MechDev* M, int t) {
     const int b = t < M->nb ? t : 0, j = t < M->nj ? t : 0;
     r.m = M->m[b];
     for (int i = 0; i < 9; i++) r.J[i] = M->J[b][i];
@@ -49,6 +49,9 @@ HD void loop_load_consts(LaneRegs& r, const MechDev* M, int t) {
     for (int i = 0; i < 5; i++)
         for (int k = 0; k < 3; k++) r.sel[i][k] = M->sel[j][i][k];
     r.parent = M->parent[j]; r.childl = M->jchild[j]; r.rotmask = M->rotmask[j]; r.type = M->type[j];
+}
+HD void loop_load_consts(LaneRegs& r, const MechDev* M, int t) {
+    loop_load_link_consts(r, M, t);
     for (int i = 0; i < 3; i++) { r.cT[i] = 0; r.cR[i] = 0; }
     r.pid_int = 0.0; r.pid_last = 0.0;
 }
@@ -71,6 +74,41 @@ HD double lp_friction(int t, const Lay& Y, const double* L, const LaneRegs& r, c
         rel = r.axis[0] * dva[0] + r.axis[1] * dva[1] + r.axis[2] * dva[2];
     }
     return -fric * rel;
+}
+
+// control_pid!(mechanism, pid, k) for joint t (pid.jl:69-88), the law of ph_pid / ck_pid on a mechanism whose joints and bodies are separate
+// index sets: minimalCoordinates of the joint from its two bodies' poses (angle about / offset along the axis), wrapped error for revolutes
+// (pid.jl:43-57), u = P e + I int(e) + D de/dt added to the joint input.  The integrated / last error stay in the joint's lane.
+HD void lp_pid(int t, const Lay& Y, double* L, LaneRegs& r, const MechDev* M, const CtrlDev* C, bool first) {
+    if (t >= M->nj || !C->pid_on[t] || r.type > 1) return;
+    const int a = r.parent, b = r.childl;
+    const double dt = M->dt;
+    const double X0[3] = {0, 0, 0};
+    const double* za = (a >= 0) ? L + Y.Z + 13 * a : nullptr;
+    const double* zb = L + Y.Z + 13 * b;
+    const double* qa = za ? za + 3 : QID_;
+    double th;
+    if (r.type == 0) {
+        double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
+        qmul(qac, zb + 3, rel);
+        qmul(rel, r.qoc, e);
+        th = 2.0 * atan2(r.axis[0] * e[1] + r.axis[1] * e[2] + r.axis[2] * e[3], e[0]);
+    } else {
+        double Ra[9], Rb[9], rp[3], w[3], gT[3];
+        rotmat(qa, Ra); rotmat(zb + 3, Rb);
+        mv3(Rb, r.p2, rp);
+        for (int i = 0; i < 3; i++) w[i] = zb[i] + rp[i] - (za ? za[i] : X0[i]);
+        mtv3(Ra, w, gT);
+        th = r.axis[0] * (gT[0] - r.p1[0]) + r.axis[1] * (gT[1] - r.p1[1]) + r.axis[2] * (gT[2] - r.p1[2]);
+    }
+    const double PI = 3.14159265358979323846;
+    double e = C->pid_goal[t] - th;
+    if (r.type == 0) { if (e > PI) e -= 2 * PI; else if (e < -PI) e += 2 * PI; }
+    if (first) r.pid_last = e;
+    r.pid_int += e * dt;
+    const double de = (e - r.pid_last) / dt;
+    L[Y.UJ + t] += C->pid_P[t] * e + C->pid_I[t] * r.pid_int + C->pid_D[t] * de;
+    r.pid_last = e;
 }
 
 // F1: joint inputs -> force / torque on body t (SURVEY 8a-bis 'Joint input': a revolute applies +-u axis as a torque, a prismatic
@@ -176,16 +214,20 @@ HD void lp_schur_row(int row, const Lay& Y, double* L, const MechDev* M) {
         // the products of one joint are formed in registers and stored together: a store into the same LDS array between the loads
         // would serialise them (the compiler cannot tell the row of S from the Jacobian blocks)
         double sj[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (bb || ba || ab || aa) {
-            double ka[30], kb[30];
-            for (int e = 0; e < 30; e++) { ka[e] = L[Y.GKA + BLK * j + e]; kb[e] = L[Y.GKB + BLK * j + e]; }
+        if (bb || ab) {                 // joint j's child-side block meets joint i's child body (bb) or parent body (ab): one block in flight at a time
+            double kb[30];
+            for (int e = 0; e < 30; e++) kb[e] = L[Y.GKB + BLK * j + e];
             for (int rj = 0; rj < 5; rj++) {
-                double acc = 0.0;
-                if (bb) acc += dot6(wb, kb + 6 * rj);
-                if (ba) acc += dot6(wb, ka + 6 * rj);
-                if (ab) acc += dot6(wa, kb + 6 * rj);
-                if (aa) acc += dot6(wa, ka + 6 * rj);
-                sj[rj] = acc;
+                if (bb) sj[rj] += dot6(wb, kb + 6 * rj);
+                if (ab) sj[rj] += dot6(wa, kb + 6 * rj);
+            }
+        }
+        if (ba || aa) {
+            double ka[30];
+            for (int e = 0; e < 30; e++) ka[e] = L[Y.GKA + BLK * j + e];
+            for (int rj = 0; rj < 5; rj++) {
+                if (ba) sj[rj] += dot6(wb, ka + 6 * rj);
+                if (aa) sj[rj] += dot6(wa, ka + 6 * rj);
             }
         }
         for (int rj = 0; rj < 5; rj++) out[1 + 5 * j + rj] = sj[rj];

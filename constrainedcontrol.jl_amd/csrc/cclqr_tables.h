@@ -255,16 +255,15 @@ static inline int build_ctrl_tables(const cclqr_mech* m, const cclqr_ctrl_desc* 
         if (j < 0 || j >= nj) { err = "controlled joint out of range"; return CCLQR_EINVAL; }
         H.cj[i] = m->link_of_joint[j];
     }
-    // closed loops: the friction / noise law of examples/trackingLQR_triple_cartpole.jl:93-111 is accepted (round 4; per joint in the caller's joint
-    // order), PID is not (its joint coordinate is read off a tree's relative pose)
-    if (m->host.loop && d->npid > 0) { err = "closed-loop mechanisms take the LQR / TrackingLQR law with friction and noise, not PID"; return CCLQR_EUNSUPPORTED; }
+    // closed loops: the friction / noise law of examples/trackingLQR_triple_cartpole.jl:93-111 and the PID law (pid.jl) are taken per joint in the
+    // caller's joint order (a loop mechanism has more joints than bodies)
     if (d->fric)
         for (int j = 0; j < (m->host.loop ? nj : nb); j++) { H.fric[m->link_of_joint[j]] = d->fric[j]; if (d->fric[j] != 0.0) H.has_fric = 1; }
     H.noise_philox = d->noise_philox ? 1 : 0;
     H.noise_key0 = (unsigned)(d->noise_seed & 0xffffffffu) ^ (unsigned)(d->noise_seed >> 32);
     for (int i = 0; i < d->npid; i++) {
         int j = d->pid_joint ? d->pid_joint[i] : -1;
-        if (j < 0 || j >= nb || !d->pid_P || !d->pid_I || !d->pid_D || !d->pid_goal) { err = "PID joint out of range"; return CCLQR_EINVAL; }
+        if (j < 0 || j >= nj || !d->pid_P || !d->pid_I || !d->pid_D || !d->pid_goal) { err = "PID joint out of range"; return CCLQR_EINVAL; }
         int l = m->link_of_joint[j];
         H.pid_on[l] = 1; H.has_pid = 1;
         H.pid_P[l] = d->pid_P[i]; H.pid_I[l] = d->pid_I[i]; H.pid_D[l] = d->pid_D[i]; H.pid_goal[l] = d->pid_goal[i];

@@ -63,8 +63,11 @@ __device__ __forceinline__ bool loop_solve_step(LoopRowR<NCB>& R, int t, int kb,
 #pragma unroll
         for (int B = 0; B < NCB; B++)
             if (B >= kb) {                                     // (uniform) blocks before the current one hold residue nobody reads again
+                double p[8];                                   // eight lane reads ahead of the multiply-adds that use them (a scalar register
+#pragma unroll                                                 // written by a lane read needs two idle cycles before the vector ALU may read it)
+                for (int u = 0; u < 8; u++) p[u] = lane_read_d(R.a[8 * B + u], prow);
 #pragma unroll
-                for (int u = 0; u < 8; u++) R.a[8 * B + u] -= f * lane_read_d(R.a[8 * B + u], prow);
+                for (int u = 0; u < 8; u++) R.a[8 * B + u] -= f * p[u];
             }
     }
     return found;
@@ -103,6 +106,12 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
     for (int iter = 1; iter <= NEWTON_MAXIT && !done; iter++) {
         PCOUNT(PF_NEWTON_ITERS);
         loop_solve<NCB>(t, Y, L, M PROF_PASS);
+        {   // the link constants (38 doubles per lane) are re-read from the mechanism tables behind the solve, through a pointer the optimiser
+            // cannot see through: the solve's row (up to 64 doubles per lane) then takes their registers instead of coming on top of them
+            const MechDev* Mq = M;
+            asm volatile("" : "+s"(Mq));
+            loop_load_link_consts(r, Mq, t);
+        }
         lp_body_solve(t, Y, L, M);
         __syncthreads();
         STAMP(PF_BODY_SOLVE);
@@ -131,8 +140,11 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
 }
 
 // relax: 0 = the reference's stopping rule, 1 = newton_mode 1 (a.eps_alone).  NCB: the dense system's rows are held in registers 8 NCB columns wide
+// Two wavefronts per SIMD (<= 256 registers): the deltabot's image is 24.8 KB, so LDS admits SIX workgroups per CU where the 307 registers the
+// kernel would like admit four; at 256 the compiler parks ~50 doubles of the evaluation phases in scratch (204 bytes per lane, none inside
+// the solve) and the rollout is still 19 % faster (11.6 against 9.8 M instance-steps/s at 8192 instances, 13.4 against 11.2 M at 32768).
 template <int NCB>
-__global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int relax) {
+__global__ __launch_bounds__(64, 2) void rollout_loop_kernel(RolloutArgs a, int relax) {
     extern __shared__ double lds[];
     const int t = threadIdx.x;
     const int64_t inst = blockIdx.x;
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int rel
     for (int e = t; e < nz; e += 64) L[Y.Z + e] = a.z0[inst * nz + e];
     if (a.lam && a.k0 > 1)
         for (int e = t; e < 5 * nj; e += 64) L[Y.LAM + e] = a.lam[inst * 5 * nj + e];
+    if (a.pid_state && a.k0 > 1 && t < nj) { r.pid_int = a.pid_state[(inst * nj + t) * 2]; r.pid_last = a.pid_state[(inst * nj + t) * 2 + 1]; }
     __syncthreads();
 
 #ifdef CCLQR_PROFILE
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int rel
         __syncthreads();
         // joint friction in the loop's own bookkeeping (ph_control_error's friction term assumes link t = body t = joint t and is overwritten here)
         if (t < nj) L[Y.UJ + t] = (gate && C->has_fric) ? lp_friction(t, Y, L, r, M, C->fric[t]) : 0.0;
+        if (C->has_pid) lp_pid(t, Y, L, r, M, C, k == 1);            // control_pid! runs every step (pid.jl:69-88), whatever the LQR horizon
         __syncthreads();
         if (gate) {
             for (int i = 0; i < C->mu; i++) {
@@ -215,6 +229,7 @@ __global__ __launch_bounds__(64) void rollout_loop_kernel(RolloutArgs a, int rel
     for (int e = t; e < nz; e += 64) a.zT[inst * nz + e] = L[Y.Z + e];
     if (a.lam) for (int e = t; e < 5 * nj; e += 64) a.lam[inst * 5 * nj + e] = L[Y.LAM + e];
     if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
+    if (a.pid_state && t < nj) { a.pid_state[(inst * nj + t) * 2] = r.pid_int; a.pid_state[(inst * nj + t) * 2 + 1] = r.pid_last; }
 #ifdef CCLQR_PROFILE
     prof.stamp(PF_IO);
     prof.flush();

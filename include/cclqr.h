@@ -204,10 +204,11 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *   first_instance  global index of instance 0 of this launch: the Philox noise stream (noise_philox) and the per-instance
  *                   controller table (n_ctrl > 1) of an instance are keyed by its GLOBAL index, so rank r of a sharded batch
  *                   passes its shard's first index and reproduces the unsharded batch;
- *   pid_state_dev   DEVICE buffer [n_inst][nb][2] (integrated error, last error per joint, opaque order) that carries the PID
+ *   pid_state_dev   DEVICE buffer [n_inst][nb][2] ([n_inst][joints][2] for a closed-loop mechanism, which has more joints than bodies;
+ *                   integrated error, last error per joint, opaque order) that carries the PID
  *                   integrators of pid.jl:10-11 between launches: read when k0 > 1, always written; only used by controllers with
  *                   npid > 0.  NULL: they live for one launch;
- *   pid_state_len   doubles in that buffer (checked against n_inst * nb * 2);
+ *   pid_state_len   doubles in that buffer (checked against n_inst * nb * 2, closed loops: n_inst * joints * 2);
  *   noise_ws_dev    DEVICE workspace of n_inst * steps doubles for the launch's Philox samples (noise_philox controllers without an
  *                   injected noise array).  NULL: the controller handle's own workspace is used -- ONE buffer per handle, so two
  *                   launches that share a controller on different streams or host threads must each bring their own here, and

@@ -114,6 +114,7 @@ extern "C" int emu_loop_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc
         for (int e = 0; e < Y.total; e++) L[e] = 0.0;
         for (int e = 0; e < nz; e++) L[Y.Z + e] = z0[inst * nz + e];
         if (lam && k0 > 1) for (int e = 0; e < 5 * nj; e++) L[Y.LAM + e] = lam[inst * 5 * nj + e];
+        for (int t = 0; t < 64; t++) { I.r[t].pid_int = 0.0; I.r[t].pid_last = 0.0; }
         int worst = 0;
         bool bad = false, dead = false;
         for (int kk = 0; kk < steps; kk++) {
@@ -124,6 +125,7 @@ extern "C" int emu_loop_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc
             const int kidx = (C->N <= 0) ? 0 : ((k - 1 < C->nK) ? k - 1 : C->nK - 1);
             if (gate) for (int t = 0; t < 64; t++) ph_control_error(t, nb, Y, L, I.r[t], C, C->zd + inst * C->zd_stride + (size_t)ksp * nz);
             for (int t = 0; t < nj; t++) L[Y.UJ + t] = (gate && C->has_fric) ? lp_friction(t, Y, L, I.r[t], M, C->fric[t]) : 0.0;      // (noise: GPU tests only)
+            if (C->has_pid) for (int t = 0; t < nj; t++) lp_pid(t, Y, L, I.r[t], M, C, k == 1);
             if (gate)
                 for (int i = 0; i < C->mu; i++) {
                     double s = 0.0;

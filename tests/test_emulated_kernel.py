@@ -306,16 +306,42 @@ def emu_loop_rollout(emu, orc, t, ctrl, z0, steps):
     return zT, traj, st
 
 
-def loop_feedback_reference(lm, z, Fd, K, zd, steps, fric=None, noise=None, noise_scale=0.0):
+def loop_joint_coordinate(j, z):
+    """minimalCoordinates of a 1-DoF joint of oracle/loops.py from its two bodies' poses, as oracle/cclqr_oracle.c joint_coordinate states it for
+    trees (pid.jl:43-57 reads it): revolute -> angle of qa^-1 qb qoff^-1 about the axis, prismatic -> offset along the axis"""
+    from oracle import loops
+    conj = lambda q: np.concatenate([[q[0]], -q[1:]])
+    ax = j.axis / np.linalg.norm(j.axis)
+    qa = z[j.parent, 3:7] if j.parent >= 0 else np.array([1.0, 0, 0, 0])
+    xa = z[j.parent, 0:3] if j.parent >= 0 else np.zeros(3)
+    if j.kind == loops.REVOLUTE:
+        e = loops.qmul(loops.qmul(conj(qa), z[j.child, 3:7]), conj(j.qoff))
+        return 2.0 * np.arctan2(ax @ e[1:], e[0])
+    w = z[j.child, 0:3] + loops.rot(z[j.child, 3:7]) @ j.p2 - xa
+    return ax @ (loops.rot(qa).T @ w - j.p1)
+
+
+def loop_feedback_reference(lm, z, Fd, K, zd, steps, fric=None, noise=None, noise_scale=0.0, pid=None):
     """oracle side of a closed-loop rollout: u = Fd - K dz (lqr.jl:92-111, error order x, v, q~, w per body) on the controlled joints
     0, 1 of oracle/loops.py's deltabot, stepped by its dense-KKT minimum-norm Newton; fric [njoints]: viscous friction -fric * (axis . relative
     angular velocity, each body's in its own frame) on every revolute joint and noise [steps] * noise_scale on the controlled ones
     (examples/trackingLQR_triple_cartpole.jl:93-111 as ck_friction / lp_friction state it)"""
     from oracle import loops
     traj, lam = [], np.zeros(lm.nrows)
+    integ, last = (np.zeros(len(pid["joint"])), np.zeros(len(pid["joint"]))) if pid else (None, None)
     for k in range(steps):
         traj.append(z.copy())
         u = np.zeros(len(lm.joints))
+        if pid:                                    # control_pid!, pid.jl:69-88 (k is 0-based here: the reference's k == 1 is the first step)
+            for i, ji in enumerate(pid["joint"]):
+                e = pid["goal"][i] - loop_joint_coordinate(lm.joints[ji], z)
+                if lm.joints[ji].kind == loops.REVOLUTE:
+                    e = e - 2 * np.pi if e > np.pi else (e + 2 * np.pi if e < -np.pi else e)
+                if k == 0:
+                    last[i] = e
+                integ[i] += e * lm.dt
+                u[ji] += pid["P"][i] * e + pid["I"][i] * integ[i] + pid["D"][i] * (e - last[i]) / lm.dt
+                last[i] = e
         if fric is not None:
             for ji, j in enumerate(lm.joints):
                 if j.kind == loops.REVOLUTE and fric[ji] != 0.0:
@@ -373,6 +399,14 @@ def test_emulated_closed_loop_deltabot(cclqr, orc, emu):
     reff, zreff = loop_feedback_reference(lm, z.copy(), 0.8 * ex["Fd"], K[0], zd[0], steps, fric=fric)
     assert st[0] > 0 and np.abs(trajf[0] - reff).max() < 1e-9 and np.abs(zTf[0] - zreff).max() < 1e-9
     assert np.abs(zTf[0] - zT[0]).max() > 1e-3                      # (the friction did something)
+    # PID on a loop mechanism (round 4: lp_pid, pid.jl:69-88 on the two actuated platform joints; the joint coordinate from the joint's two
+    # bodies, goals 0.15 rad off the start): on top of the holding torques, against the dense-KKT reference under the same law
+    pid = dict(joint=cj, P=[8.0, 6.0], I=[3.0, 2.0], D=[0.4, 0.3], goal=[loop_joint_coordinate(lm.joints[j], z) + d for j, d in zip(cj, (0.15, -0.1))])
+    pc = orc.ctrl_desc(t.nb, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2), pid=pid)
+    zTp, trajp, st = emu_loop_rollout(emu, orc, t, pc, z0, steps)
+    refp, zrefp = loop_feedback_reference(lm, z.copy(), ex["Fd"], None, zd[0], steps, pid=pid)
+    assert st[0] > 0 and np.abs(trajp[0] - refp).max() < 1e-9 and np.abs(zTp[0] - zrefp).max() < 1e-9
+    assert np.abs(zTp[0] - z0).max() > 1e-2                         # (the PID moved the platform)
 
 
 def emu_loop_linearize(emu, orc, t, zd, cj, Fd, force_loop):

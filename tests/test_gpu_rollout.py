@@ -375,10 +375,25 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
     assert np.abs(zTf - zT).max() > 1e-3
     zT1, _, st1 = capi.rollout(mech, ctrl, zb, steps, newton_mode=1, newton_eps_alone=1e-12)      # the measured-error stop on the loop kernel
     assert (st1 > 0).all() and (st1 <= st).all() and 0.0 <= np.abs(zT1 - zT).max() < 1e-8
-    pid = capi.CtrlHandle                                                                      # PID stays refused on loops (its joint coordinate is a tree's)
-    with pytest.raises(capi.CclqrError) as e:
-        pid(mech, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2), pid=dict(joint=[0], P=[1.0], I=[0.0], D=[0.0], goal=[0.0]))
-    assert e.value.code == capi.EUNSUPPORTED
+    # PID on a loop mechanism (pid.jl:69-88 on the two actuated platform joints, lp_pid): against the dense-KKT reference under the same law, and
+    # the integrators carried between two launches through pid_state_dev ([n_inst][joints][2] for a loop mechanism) equal one launch
+    from tests.test_emulated_kernel import loop_joint_coordinate
+    pidd = dict(joint=cj, P=[8.0, 6.0], I=[3.0, 2.0], D=[0.4, 0.3], goal=[loop_joint_coordinate(lm.joints[j], z) + d for j, d in zip(cj, (0.15, -0.1))])
+    pc = capi.CtrlHandle(mech, cj, K=None, N=0, zd=zd, Fd=ex["Fd"].reshape(1, 2), pid=pidd)
+    zTp, trajp, stp = capi.rollout(mech, pc, z0[None], steps, record=True)
+    refp, zrefp = loop_feedback_reference(lm, z.copy(), ex["Fd"], None, zd[0], steps, pid=pidd)
+    assert stp[0] > 0 and np.abs(trajp[0] - refp).max() < TOL and np.abs(zTp[0] - zrefp).max() < TOL
+    assert np.abs(zTp[0] - z0).max() > 1e-2
+    import torch
+    dev = torch.device("cuda", 0)
+    zt = torch.from_numpy(z0[None].copy()).to(dev); zo = torch.empty_like(zt)
+    lamt = torch.zeros((1, 5 * t.ne), dtype=torch.float64, device=dev); stt = torch.zeros(1, dtype=torch.int32, device=dev)
+    pst = torch.zeros((1, t.ne, 2), dtype=torch.float64, device=dev)
+    h = steps // 2
+    capi.rollout_dev(mech, pc, 1, h, 1, zt.data_ptr(), lamt.data_ptr(), 0, 0, 0, zo.data_ptr(), stt.data_ptr(), 0, pid_state=pst.data_ptr())
+    capi.rollout_dev(mech, pc, 1, steps - h, h + 1, zo.data_ptr(), lamt.data_ptr(), 0, 0, 0, zt.data_ptr(), stt.data_ptr(), 0, pid_state=pst.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(zt.cpu().numpy()[0] - zTp[0]).max() < 1e-12
 
 
 

@@ -489,7 +489,9 @@ def test_loop_rollout_kernel_resources(tmp_path):
     kernels = _kernel_resources(tmp_path, "rollout_loop.hip", "rollout_loop_kernel")
     assert len(kernels) == 8, sorted(kernels)
     for name, k in kernels.items():
-        assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
+        # two wavefronts per SIMD (six instances per CU by LDS instead of four): 256 registers and a small, bounded spill of the evaluation
+        # phases (measured +19 % against the 307-register build without scratch)
+        assert k["scratch"] <= 256 and k["vgpr"] <= 256 and k["lds"] == 0, (name, k)
 
 
 def test_tree_rollout_kernel_resources(tmp_path):

@@ -8,6 +8,9 @@ PROF = "--phases" in sys.argv
 if PROF:
     sys.argv.remove("--phases")
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libcclqr_prof.so")       # diagnostic build with phase stamps
+for a in list(sys.argv):
+    if a.startswith("--lib="):
+        sys.argv.remove(a); capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), a[6:])       # an experiment build next to the shipped library
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ex = pkg.examples.deltabot(); mech_py = ex["mech"]; t = mech_py.tables()
