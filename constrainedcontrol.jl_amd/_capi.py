@@ -16,7 +16,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_host_ex", "cclqr_ctrl_reserve_noise", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex",
-           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links"]
+           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward"]
 ABI_VERSION = 200     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header
 
 
@@ -186,6 +186,15 @@ class CtrlHandle:
     def reserve_noise(self, n_inst, steps):
         """size the handle's Philox workspace (needed before a noise_philox launch is captured into a hipGraph)"""
         check(lib().cclqr_ctrl_reserve_noise(self.ptr, C.c_int64(int(n_inst)), C.c_int32(int(steps))))
+
+    def set_feedforward(self, Fd=None, dev_ptr=None, length=None, stream=0):
+        """the controlfunction hook (lqr.jl:14, :56): replace the feed-forward table [n_ctrl][nsp][mu] -- host array Fd, or device address dev_ptr
+        (+ length in doubles) copied on `stream`"""
+        if dev_ptr is not None:
+            check(lib().cclqr_ctrl_set_feedforward(self.ptr, C.c_void_p(int(dev_ptr)), C.c_int64(int(length)), C.c_int32(1), C.c_void_p(int(stream)) if stream else None))
+            return
+        Fd = f64(Fd).reshape(-1)
+        check(lib().cclqr_ctrl_set_feedforward(self.ptr, _d(Fd), C.c_int64(Fd.size), C.c_int32(0), None))
 
     def close(self):
         if self.ptr:

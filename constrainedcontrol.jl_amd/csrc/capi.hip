@@ -136,6 +136,7 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     if (e == hipSuccess && !T.Fd.empty()) {
         e = hipMalloc((void**)&c->Fd_dev, T.Fd.size() * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(c->Fd_dev, T.Fd.data(), T.Fd.size() * sizeof(double), hipMemcpyHostToDevice);
+        c->Fd_len = T.Fd.size();
     }
     c->host = T.H;
     c->host.K = c->K_dev; c->host.zd = c->zd_dev; c->host.Fd = c->Fd_dev;
@@ -145,6 +146,19 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     if (e == hipSuccess) e = hipMemcpy(c->dev, &c->host, sizeof(CtrlDev), hipMemcpyHostToDevice);
     if (e != hipSuccess) { cclqr_ctrl_destroy(c); return fail(CCLQR_EHIP, std::string("controller upload: ") + hipGetErrorString(e)); }
     *out = c;
+    return CCLQR_OK;
+}
+
+// controlfunction hook (lqr.jl:14, :56): the host's closure has computed the joint inputs of the next step
+extern "C" int cclqr_ctrl_set_feedforward(cclqr_ctrl* c, const double* Fd, int64_t len, int32_t on_device, void* stream) {
+    if (!c || !Fd) return fail(CCLQR_EINVAL, "null argument");
+    if (!c->Fd_dev) return fail(CCLQR_EINVAL, "the controller was created without a feed-forward table");
+    if (len < 0 || (size_t)len != c->Fd_len) return fail(CCLQR_EINVAL, "feed-forward table length differs from the one the controller was created with");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return fail(CCLQR_EINVAL, "the calling thread is not on the controller's device");
+    hipError_t e = on_device ? hipMemcpyAsync(c->Fd_dev, Fd, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                             : hipMemcpy(c->Fd_dev, Fd, (size_t)len * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(CCLQR_EHIP, std::string("feed-forward upload: ") + hipGetErrorString(e));
     return CCLQR_OK;
 }
 
@@ -205,6 +219,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     if (e == hipSuccess && Fd) {
         e = hipMalloc((void**)&c->Fd_dev, np * mu * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(c->Fd_dev, Fd, np * mu * sizeof(double), hipMemcpyHostToDevice);
+        c->Fd_len = (size_t)np * mu;
     }
     if (e == hipSuccess) e = ws_get((void**)&dzd, np * nz * sizeof(double));
     if (e == hipSuccess) e = ws_get((void**)&dA, np * mx * mx * sizeof(double));

@@ -95,6 +95,7 @@ struct cclqr_ctrl {
     cclqr::CtrlDev host;
     cclqr::CtrlDev* dev;
     double *K_dev, *zd_dev, *Fd_dev;
+    size_t Fd_len;       // doubles in Fd_dev
     int nb;
     int device;           // the device the tables (and the noise workspace) live on = the mechanism's
     // workspace of the counter-based noise of one launch (noise_philox), grown on demand and kept with the handle

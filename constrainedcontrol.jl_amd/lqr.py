@@ -8,7 +8,9 @@ meaning; the arithmetic (linearsystem, dlqr, simulate!) runs in HIP through the 
     Storage{T}(steps, Nb)                                                            examples/trackingLQR_triple_cartpole.jl:50-51
 
 What is new relative to the reference (which has no batch API): simulate(..., z0=batch) rolls out n_inst
-independent instances at once; custom `controlfunction`s cannot run on the device and are rejected.
+independent instances at once.  A custom `controlfunction(batch, controller, k)` (lqr.jl:14, :56) is a host closure: simulate then steps the
+device one launch per step, shows the closure the batch's states (BatchState) and applies the joint inputs it sets with setForce
+(cclqr_ctrl_set_feedforward) -- the built-in laws (LQR / TrackingLQR / friction + noise / PID) stay fused in one persistent launch.
 """
 import math
 
@@ -65,9 +67,7 @@ class LQR(Controller):
             vd = kw.pop("vωd")
         if kw:
             raise TypeError("unexpected keyword(s): %s" % list(kw))
-        if controlfunction is not None:
-            raise NotImplementedError("custom controlfunction (lqr.jl:56) cannot run on the device; the friction/noise law of "
-                                      "examples/trackingLQR_triple_cartpole.jl is available through simulate(..., fric=, noise=)")
+        self.controlfunction = controlfunction          # lqr.jl:14: a host closure (batch, lqr, k); None = control_lqr! on the device
         if not isinstance(mechanism, Mechanism):
             raise TypeError("LQR(mechanism, bodyids, eqcids, Q, R, horizon; ...)")
         nb = len(mechanism.bodies)
@@ -153,6 +153,7 @@ class LQR(Controller):
         """the inner constructor lqr.jl:17-47 for callers that bring their own linear model"""
         self = cls.__new__(cls)
         nb = len(xd)
+        self.controlfunction = None
         self.mechanism = mechanism
         self.eqcids = [int(e) for e in eqcids]
         self.ctrl_joints = [mechanism.joint_index(e) for e in self.eqcids] if mechanism is not None else list(range(len(eqcids)))
@@ -199,8 +200,7 @@ class TrackingLQR(Controller):
     """TrackingLQR{T,N,NK}: per-step setpoints copied out of `storage` and per-step feed-forward Fτ  (lqr_tracking.jl:3-43)"""
 
     def __init__(self, mechanism, storage, Fτ, eqcids, Q, R, controlfunction=None):
-        if controlfunction is not None:
-            raise NotImplementedError("custom controlfunction (lqr_tracking.jl:19) cannot run on the device; use simulate(..., fric=, noise=)")
+        self.controlfunction = controlfunction          # lqr_tracking.jl:19: a host closure (batch, lqr, k); None = control_trackinglqr! on the device
         nb = len(mechanism.bodies)
         N = storage.steps
         self.mechanism = mechanism
@@ -253,8 +253,7 @@ class PID(Controller):
     PID(mechanism, eqcid::Int, goal; P, I, D)  /  PID(mechanism, eqcids::Vector, goals::Vector; P, I, D)"""
 
     def __init__(self, mechanism, eqcids, goals, P=None, I=None, D=None, controlfunction=None):
-        if controlfunction is not None:
-            raise NotImplementedError("custom controlfunction (pid.jl:16,27) cannot run on the device")
+        self.controlfunction = controlfunction          # pid.jl:16, :27: a host closure (batch, pid, k); None = control_pid! on the device
         scalar = np.ndim(eqcids) == 0
         ids = [int(eqcids)] if scalar else [int(e) for e in eqcids]
         n = len(ids)
@@ -269,6 +268,99 @@ class PID(Controller):
     def _ctrl_handle(self, dev, fric=None, noise_scale=0.0, noise_seed=None):
         return _capi.CtrlHandle(dev, [], K=None, N=0, fric=fric, noise_scale=noise_scale, noise_seed=noise_seed,
                                 pid=dict(joint=self.joints, P=self.P, I=self.I, D=self.D, goal=self.goals))
+
+
+class BatchState:
+    """What a `controlfunction(batch, controller, k)` sees at step k: the states of every instance, in the mechanism's body order
+    (z [n_inst][nb][13] = x, q, v, ω per body; the reference's closure reads body.state.xsol[2] ... of ONE mechanism, lqr.jl:98-103), and the
+    joint inputs it sets with setForce (the reference's setForce!(mechanism, eqc, u), lqr.jl:110)."""
+
+    def __init__(self, mechanism, z, k):
+        self.mechanism, self.z, self.k = mechanism, z, int(k)
+        self.n_inst = z.shape[0]
+        self.u = {}
+
+    x = property(lambda self: self.z[:, :, 0:3])
+    q = property(lambda self: self.z[:, :, 3:7])
+    v = property(lambda self: self.z[:, :, 7:10])
+    ω = property(lambda self: self.z[:, :, 10:13])
+    w = ω
+
+
+def setForce(batch, eqc, u):
+    """setForce!(mechanism, eqconstraint, u) on a batch: u a scalar, [n_inst] or [n_inst][1]; eqc an EqualityConstraint or its id"""
+    j = batch.mechanism.joint_index(getattr(eqc, "id", eqc))
+    batch.u[j] = np.broadcast_to(np.asarray(u, dtype=np.float64).reshape(-1), (batch.n_inst,)).copy()
+
+
+def state_error(batch, controller, k):
+    """Δz [n_inst][12 nb] of lqr.jl:92-103 / lqr_tracking.jl:49-62 about the controller's setpoint of step k (bodies in mechanism order)"""
+    zd = controller.zd
+    d = zd[min(k - 1, zd.shape[0] - 1)] if zd.shape[0] > 1 else zd[0]
+    z = batch.z
+    qd = d[:, 3:7] * np.array([1.0, -1.0, -1.0, -1.0])
+    s0, v0 = qd[:, 0], qd[:, 1:]
+    s1, v1 = z[:, :, 3], z[:, :, 4:7]
+    qe = s0[None, :, None] * v1 + s1[:, :, None] * v0[None] + np.cross(np.broadcast_to(v0[None], v1.shape), v1)      # vector part of qd \ q
+    dz = np.concatenate([z[:, :, 0:3] - d[None, :, 0:3], z[:, :, 7:10] - d[None, :, 7:10], qe, z[:, :, 10:13] - d[None, :, 10:13]], axis=2)
+    return dz.reshape(z.shape[0], -1)
+
+
+def control_lqr(batch, lqr, k):
+    """control_lqr! (lqr.jl:89-139) / control_trackinglqr! (lqr_tracking.jl:46-71) on the host for a batch: u = Fτd - K[k] Δz on the
+    controller's joints, gated by k < N; sets the forces and returns u [n_inst][mu] -- the building block of a custom controlfunction"""
+    mu = len(lqr.eqcids)
+    u = np.zeros((batch.n_inst, mu))
+    if lqr.N <= 0 or k < lqr.N:                                  # LQR{T,Inf}: always; finite: k < N (lqr.jl:106)
+        dz = state_error(batch, lqr, k)
+        K = lqr.K[0] if lqr.N <= 0 else lqr.K[min(k - 1, lqr.K.shape[0] - 1)]
+        Fd = lqr.Fd[min(k - 1, lqr.Fd.shape[0] - 1)] if lqr.Fd.shape[0] > 1 else lqr.Fd[0]
+        u = Fd[None, :] - dz @ K.reshape(mu, -1).T
+        for i, e in enumerate(lqr.eqcids):
+            setForce(batch, e, u[:, i])
+    return u
+
+
+def _simulate_hosted(mechanism, steps, controller, record, z0):
+    """simulate! with a host-side controlfunction: one single-step launch per step through the k0 continuation of cclqr_rollout_dev (state and
+    multipliers stay on the device), the states copied to the host for the closure and its joint inputs handed back (cclqr_ctrl_set_feedforward)"""
+    import torch
+    t = mechanism.tables()
+    nb, n = t.nb, z0.shape[0]
+    dev = _device_mech(mechanism)
+    joints = [j for j in range(t.ne) if int(t.type[j]) in (0, 1)]             # every 1-DoF joint can be given an input (revolute, prismatic)
+    slot = {j: i for i, j in enumerate(joints)}
+    ctrl = _capi.CtrlHandle(dev, joints, K=None, N=0, Fd=np.zeros((n, len(joints))), n_ctrl=n)
+    td = torch.device("cuda", torch.cuda.current_device())
+    z = torch.from_numpy(np.ascontiguousarray(z0)).to(td)
+    zn = torch.empty_like(z)
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
+    st = torch.zeros(n, dtype=torch.int32, device=td)
+    traj = np.zeros((n, steps if record else 0, nb, 13))
+    worst, bad = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=bool)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for k in range(1, steps + 1):
+            zh = z.cpu().numpy()
+            if record:
+                traj[:, k - 1] = zh
+            batch = BatchState(mechanism, zh, k)
+            controller.controlfunction(batch, controller, k)
+            U = np.zeros((n, len(joints)))
+            for j, u in batch.u.items():
+                if j not in slot:
+                    raise ValueError("setForce on a constraint without a degree of freedom")
+                U[:, slot[j]] = u
+            ctrl.set_feedforward(U)
+            _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
+            z, zn = zn, z
+            s = st.cpu().numpy()
+            bad |= s <= 0
+            worst = np.maximum(worst, np.abs(s))
+    finally:
+        ctrl.close()
+    zT = z.cpu().numpy()
+    return zT, traj, np.where(bad, -worst, worst).astype(np.int32)
 
 
 def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None, noise_seed=None,
@@ -289,11 +381,17 @@ def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=
     dev = _device_mech(mechanism)
     if (noise is not None or noise_seed is not None) and noise_scale is None:
         noise_scale = 1.0
-    ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale, noise_seed=noise_seed)
-    try:
-        zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record, first_instance=first_instance)
-    finally:
-        ctrl.close()
+    if getattr(controller, "controlfunction", None) is not None:
+        # a custom controlfunction (lqr.jl:14): the closure owns the whole law, as in the reference -- the built-in extras do not apply on top of it
+        if fric is not None or noise is not None or noise_seed is not None:
+            raise ValueError("fric / noise are options of the built-in laws; a custom controlfunction computes its own inputs")
+        zT, traj, status = _simulate_hosted(mechanism, steps, controller, record, z0)
+    else:
+        ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale, noise_seed=noise_seed)
+        try:
+            zT, traj, status = _capi.rollout(dev, ctrl, z0, steps, k0=1, noise=noise, record=record, first_instance=first_instance)
+        finally:
+            ctrl.close()
     mechanism.set_state(zT[0])
     if isinstance(tend_or_storage, Storage) and record:
         tend_or_storage.z = traj

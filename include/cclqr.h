@@ -249,6 +249,15 @@ int cclqr_rollout_host_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_in
  * that would have to grow the workspace is refused with CCLQR_EINVAL before anything is touched: cclqr_rollout_ex). */
 int cclqr_ctrl_reserve_noise(cclqr_ctrl *c, int64_t n_inst, int32_t steps);
 
+/* The `controlfunction` hook of the reference's controllers (src/control/lqr.jl:14, :56; lqr_tracking.jl:19; pid.jl:16 -- a Julia closure
+ * `controlfunction(mechanism, controller, k)` that ends in setForce!(mechanism, eqc, u), e.g. examples/trackingLQR_triple_cartpole.jl:93-117)
+ * with the closure on the HOST and the batch on the device: the caller steps the rollout one launch per step (k0 continuation of
+ * cclqr_rollout_dev), reads the states, lets its closure compute every instance's joint inputs and hands them over here; the next launch applies
+ * them as feed-forward inputs.  Fd: [n_ctrl][nsp][mu] doubles exactly as given to cclqr_ctrl_create (len is checked against that), a HOST
+ * pointer (on_device = 0: copied synchronously) or a DEVICE pointer (on_device = 1: copied on `stream`, ordered with the launches on it).
+ * The controller must have been created with a feed-forward table (Fd != NULL). */
+int cclqr_ctrl_set_feedforward(cclqr_ctrl *c, const double *Fd, int64_t len, int32_t on_device, void *stream);
+
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py; no counterpart in the reference's simulate!,
  * examples/lqr_cartpole.jl:44): lanes per instance and LDS bytes per workgroup; links the chain kernel's LDS image is laid out for
  * (names the instantiation rollout_chain_kernel<lanes, links, law>; 0 when the mechanism takes the tree or the closed-loop kernel) */

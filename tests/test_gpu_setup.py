@@ -158,6 +158,53 @@ def test_lqr_pipeline_cartpole(cclqr, orc):
     assert np.allclose(mech.bodies[0].state.xc, storage.zT[0, 0, 0:3])
 
 
+def test_custom_controlfunction_closure(cclqr, orc):
+    """`controlfunction` (lqr.jl:14, :56; used at examples/trackingLQR_triple_cartpole.jl:117): a host closure (batch, lqr, k) that ends in
+    setForce.  (i) a closure that is control_lqr! itself reproduces the fused device rollout of the same controller (the closure's u is
+    formed in numpy, the device's in the kernel: 1e-9 over 300 steps of a batch of 16) AND the oracle; (ii) the script's friction law
+    (trackingLQR_triple_cartpole.jl:93-111: LQR input on the cart, -fric x relative joint velocity on every joint) written as a closure
+    equals the built-in `fric=` option of simulate; (iii) fric / noise options on top of a closure are refused (the closure owns the law)"""
+    ex = cclqr.examples.cartpole_n(1)
+    mech = ex["mech"]
+    ids = [cclqr.getid(b) for b in ex["bodies"]]
+    rng = np.random.default_rng(5)
+    z0 = cclqr.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, 16), rng.uniform(0.0, 0.3, (16, 1)))
+    calls = []
+
+    def law(batch, lqr, k):
+        calls.append(k)
+        cclqr.control_lqr(batch, lqr, k)
+
+    lqr_dev = cclqr.LQR(mech, ids, [cclqr.getid(ex["ctrl"][0])], ex["Q"], ex["R"], 10.0, xd=ex["xd"])
+    lqr_host = cclqr.LQR(mech, ids, [cclqr.getid(ex["ctrl"][0])], ex["Q"], ex["R"], 10.0, xd=ex["xd"], controlfunction=law)
+    assert np.array_equal(lqr_dev.K, lqr_host.K)
+    sd = cclqr.simulate(mech, 3.0, lqr_dev, z0=z0)
+    sh = cclqr.simulate(mech, 3.0, lqr_host, z0=z0)
+    assert calls == list(range(1, 301))
+    assert (sh.status > 0).all() and np.array_equal(sh.status, sd.status)
+    assert np.abs(sh.z - sd.z).max() < 1e-9 and np.abs(sh.zT - sd.zT).max() < 1e-9
+    t = mech.tables()
+    zTo, trajo, sto = orc.rollout(t, orc.ctrl_desc(2, [0], K=lqr_dev.K, N=lqr_dev.N, zd=lqr_dev.zd), z0, 300, record=True)
+    assert np.abs(sh.z - trajo).max() < 1e-9
+    fric = np.array([0.3, 0.05])
+    axes = [np.asarray(e.joint.axis, dtype=np.float64) / np.linalg.norm(e.joint.axis) for e in mech.eqconstraints]
+
+    def law_fric(batch, lqr, k):
+        u = cclqr.control_lqr(batch, lqr, k)[:, 0]
+        cart_v = batch.v[:, 0] @ axes[0]                                       # prismatic on the origin: velocity along the axis
+        pole_w = (batch.ω[:, 1] - batch.ω[:, 0]) @ axes[1]                     # revolute: axis . relative angular velocity
+        cclqr.setForce(batch, mech.eqconstraints[0], u - fric[0] * cart_v)
+        cclqr.setForce(batch, mech.eqconstraints[1], -fric[1] * pole_w)
+
+    lqr_host.controlfunction = law_fric
+    shf = cclqr.simulate(mech, 2.0, lqr_host, z0=z0)
+    sdf = cclqr.simulate(mech, 2.0, lqr_dev, z0=z0, fric=fric)
+    assert (shf.status > 0).all() and np.abs(shf.z - sdf.z).max() < 1e-9
+    assert np.abs(sdf.z - sd.z[:, :200]).max() > 1e-3                         # (the friction did something)
+    with pytest.raises(ValueError):
+        cclqr.simulate(mech, 0.1, lqr_host, z0=z0, fric=fric)
+
+
 def test_lqr_pendulum_inf_horizon(cclqr, orc):
     """examples/lqr_pendulum.jl: horizon = Inf -> K = [Ku[1]] (lqr.jl:40-43), always-on feedback (lqr.jl:116-139)"""
     ex = cclqr.examples.pendulum()

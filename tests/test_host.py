@@ -506,3 +506,28 @@ def test_tree_rollout_kernel_resources(tmp_path):
         assert k["vgpr"] <= 512 and k["lds"] == 0, (name, k)      # all LDS is dynamic (one instance image per lane group)
         assert k["scratch"] == 0 and k["vgpr_spill"] <= 8, (name, k)
         assert k["sgpr_spill"] <= (16 if "ELi2ELb0EEEv" in name else 0), (name, k)
+
+
+def test_controlfunction_helpers_on_the_host(cclqr, orc):
+    """the building blocks a custom controlfunction closure is given (lqr.py: BatchState, state_error, setForce): the batched error
+    coordinates equal the per-instance statement of lqr.jl:92-103 in oracle/loops.py, setForce broadcasts and maps constraint ids to joints.
+    (No device call: the closure path itself is covered by tests/test_gpu_setup.py::test_custom_controlfunction_closure.)"""
+    from oracle import loops
+    ex = cclqr.examples.cartpole_n(2)
+    mech = ex["mech"]
+    rng = np.random.default_rng(2)
+    z = cclqr.examples.cartpole_states(2, rng.uniform(-0.5, 0.5, 5), rng.uniform(-0.4, 0.4, (5, 2)))
+    z[:, :, 7:13] = rng.normal(size=(5, 3, 6)) * 0.1
+    zd = cclqr.examples.cartpole_states(2, [0.1], [[0.3, -0.2]])
+
+    class Ctl:
+        pass
+    c = Ctl(); c.zd = zd
+    batch = cclqr.BatchState(mech, z, 1)
+    dz = cclqr.state_error(batch, c, 1)
+    for i in range(5):
+        assert np.abs(dz[i] - loops.state_error(z[i], zd[0])).max() < 1e-15
+    cclqr.setForce(batch, mech.eqconstraints[1], 2.0)
+    cclqr.setForce(batch, cclqr.getid(mech.eqconstraints[0]), np.arange(5.0))
+    assert sorted(batch.u) == [0, 1] and np.array_equal(batch.u[1], np.full(5, 2.0)) and np.array_equal(batch.u[0], np.arange(5.0))
+
