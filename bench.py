@@ -413,6 +413,7 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
             more["chain_16_bodies_N15"] = chain_rate(pkg, capi, torch, dev, 15, args.instances, args.sim_steps, count)
         more.update(other_configs(pkg, capi, torch, dev, count))
         more["branching_tree_14_bodies"] = tree14_rate(pkg, capi, torch, dev, count)
+        more["deltabot_closed_loops"] = deltabot_rate(pkg, capi, torch, dev)
     except Exception as e:        # the extra lines never take the headline line down with them
         more["other_configs_error"] = repr(e)
     m = mu + ml
@@ -505,6 +506,30 @@ def tree14_rate(pkg, capi, torch, dev, count=True):
     out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, False, f_step=f, kernel=kernel_name(mh)), lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
                workload="branching tree of 14 bodies (parents %s, tools/gpu_tree_rate.py), %d instances x %d steps, record=false: the register-resident tree "
                         "kernel of round 4 (8.0 M inst-steps/s on the LDS-resident kernel of rounds 1-3)" % (TREE14_PARENTS, len(z0), steps))
+    ctrl.close(); mh.close()
+    return out
+
+
+def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200):
+    """examples/lqr_deltabot.jl:25-53 as a batch (not a BASELINE config): five bodies, seven joints, three closed kinematic loops,
+    feedback on the two actuated joints with a setpoint-holding torque scaled 0.97..1.03 per instance (tools/gpu_loop_rate.py).  No roofline
+    figure: the checker of this kernel is oracle/loops.py (numpy dense-KKT), which has no flop counter."""
+    ex = pkg.examples.deltabot()
+    mech_py = ex["mech"]
+    t = mech_py.tables()
+    cj = [mech_py.joint_index(e) for e in ex["eqcids"]]
+    z00 = mech_py.state()
+    rng = np.random.default_rng(0)
+    K = rng.normal(size=(1, 2, 12 * t.nb)) * 0.05
+    scale = rng.uniform(0.97, 1.03, n)
+    mh = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mh, cj, K=np.repeat(K[None], n, 0), N=0, zd=np.repeat(z00[None, None], n, 0), Fd=scale[:, None, None] * ex["Fd"].reshape(1, 1, 2), n_ctrl=n)
+    lanes, lds = mh.geometry()
+    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z00[None], (n, 1, 1)), steps, False, kernel="rollout_loop_kernel<%d>" % ((5 * t.ne + 7) // 8)),
+               lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
+               workload="lqr_deltabot.jl as a batch: %d deltabots (5 bodies, 7 joints, 35 constraint rows of rank 28) x %d steps, feedback on the two actuated "
+                        "joints, record=false: the closed-loop kernel with the register-resident Gauss-Jordan solve of round 4 (4.6 M inst-steps/s with the "
+                        "LDS-resident complete-pivoting solve of rounds 2-3)" % (n, steps))
     ctrl.close(); mh.close()
     return out
 

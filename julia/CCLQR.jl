@@ -290,6 +290,11 @@ end
 "Size the controller handle's Philox workspace before step-per-launch rollouts are captured into a hipGraph (cclqr_ctrl_reserve_noise)."
 reserve_noise!(c::CtrlHandle, n::Integer, steps::Integer) = check(ccall((:cclqr_ctrl_reserve_noise, lib), Cint, (Ptr{Cvoid}, Int64, Int32), c.ptr, n, steps))
 
+"The `controlfunction` hook (lqr.jl:14, :56) with the closure on the host: U (mu x nsp x n_ctrl, as given to CtrlHandle) are the joint inputs the
+closure computed for the next single-step launch (cclqr_ctrl_set_feedforward; host array, copied synchronously)."
+set_feedforward!(c::CtrlHandle, U::Array{Float64}) =
+    check(ccall((:cclqr_ctrl_set_feedforward, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32, Ptr{Cvoid}), c.ptr, U, length(U), 0, C_NULL))
+
 "Storage{T}(steps, Nb) view of instance n of a batched trajectory: storage.x[i][k] etc. (lqr_tracking.jl:32-35)."
 function storage_fields(traj::Array{Float64,4}, n::Integer)
     nb, steps = size(traj, 2), size(traj, 3)
