@@ -510,10 +510,9 @@ def tree14_rate(pkg, capi, torch, dev, count=True):
     return out
 
 
-def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200):
+def deltabot_workload(pkg, capi, n=32768):
     """examples/lqr_deltabot.jl:25-53 as a batch (not a BASELINE config): five bodies, seven joints, three closed kinematic loops,
-    feedback on the two actuated joints with a setpoint-holding torque scaled 0.97..1.03 per instance (tools/gpu_loop_rate.py).  No roofline
-    figure: the checker of this kernel is oracle/loops.py (numpy dense-KKT), which has no flop counter."""
+    feedback on the two actuated joints with a setpoint-holding torque scaled 0.97..1.03 per instance (tools/gpu_loop_rate.py)"""
     ex = pkg.examples.deltabot()
     mech_py = ex["mech"]
     t = mech_py.tables()
@@ -524,9 +523,14 @@ def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200):
     scale = rng.uniform(0.97, 1.03, n)
     mh = capi.MechHandle(t)
     ctrl = capi.CtrlHandle(mh, cj, K=np.repeat(K[None], n, 0), N=0, zd=np.repeat(z00[None, None], n, 0), Fd=scale[:, None, None] * ex["Fd"].reshape(1, 1, 2), n_ctrl=n)
+    return mh, ctrl, np.tile(z00[None], (n, 1, 1)), "rollout_loop_kernel<%d>" % ((5 * t.ne + 7) // 8)
+
+
+def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200):
+    """No roofline figure: the checker of this kernel is oracle/loops.py (numpy dense-KKT), which has no flop counter."""
+    mh, ctrl, z0, kern = deltabot_workload(pkg, capi, n)
     lanes, lds = mh.geometry()
-    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, np.tile(z00[None], (n, 1, 1)), steps, False, kernel="rollout_loop_kernel<%d>" % ((5 * t.ne + 7) // 8)),
-               lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
+    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, False, kernel=kern), lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
                workload="lqr_deltabot.jl as a batch: %d deltabots (5 bodies, 7 joints, 35 constraint rows of rank 28) x %d steps, feedback on the two actuated "
                         "joints, record=false: the closed-loop kernel with the register-resident Gauss-Jordan solve of round 4 (4.6 M inst-steps/s with the "
                         "LDS-resident complete-pivoting solve of rounds 2-3)" % (n, steps))

@@ -1,6 +1,6 @@
 """diagnostic (not a test): ONE BASELINE config's rollout launched a few times and nothing else, so that a rocprofv3 --pmc pass attributes
 its counters to that config's kernel (tools/profile_configs.sh).  python tools/gpu_config_rollout.py <cartpole_cfg2|cartpole_cfg2_filled|
-sawyer_cfg4|tracking_cfg5|tree14> [launches]   -> one JSON line: kernel, instances, steps, wavefronts, ms per launch"""
+sawyer_cfg4|tracking_cfg5|tree14|deltabot> [launches]   -> one JSON line: kernel, instances, steps, wavefronts, ms per launch"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,9 +29,12 @@ elif cfg == "tree14":
     t, octrl, z0, steps = bench.tree14_workload(pkg)
     record = False
     mh = capi.MechHandle(t); ctrl = capi.CtrlHandle(mh, octrl["ctrl_joint"], K=octrl["K"], N=octrl["N"], zd=octrl["zd"])
+elif cfg == "deltabot":
+    mh, ctrl, z0, kern = bench.deltabot_workload(pkg, capi)
+    steps, record = 200, False
 else:
     raise SystemExit("unknown config " + cfg)
-r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=reps, kernel=bench.kernel_name(mh, extra))
+r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=reps, kernel=kern if cfg == "deltabot" else bench.kernel_name(mh, extra))
 lanes, lds = mh.geometry()
 r.update(config=cfg, lanes_per_instance=lanes, instances_per_wavefront=64 // lanes, wavefronts=(len(z0) + 64 // lanes - 1) // (64 // lanes),
          lds_bytes_per_workgroup=lds, workgroups_per_cu_by_lds=int(160 * 1024 // lds))

@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, shutil, sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 table = {}
-for cfg in ("cartpole_cfg2", "cartpole_cfg2_filled", "sawyer_cfg4", "tracking_cfg5", "tree14"):
+for cfg in ("cartpole_cfg2", "cartpole_cfg2_filled", "sawyer_cfg4", "tracking_cfg5", "tree14", "deltabot"):
     if not os.path.exists(os.path.join(src, cfg + ".pmcA.log")):
         continue
     logs = [x for x in open(os.path.join(src, cfg + ".pmcA.log")) if x.startswith("{")]
