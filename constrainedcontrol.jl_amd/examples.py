@@ -287,3 +287,23 @@ def deltabot_initial_states(ex, stride=1):
         out.append(mech.state())
     mech.set_state(saved)
     return np.array(out), yz
+
+
+def fourbar(θ=0.6, a=0.5, b=0.9):
+    """a planar parallelogram four-bar linkage in the y-z plane (not one of the reference's scripts: a second closed-loop topology for the
+    tests): crank and rocker of length a on floor revolutes b apart, a coupler of length b between their tips, every joint a revolute about
+    ex -- three bodies, four joints, 20 constraint rows on 18 body coordinates with one degree of freedom (rank 17), placed at crank angle θ."""
+    ex = [1.0, 0.0, 0.0]
+    origin = Origin()
+    crank, coupler, rocker = Box(0.05, 0.05, a, 0.8, "crank"), Box(0.05, b, 0.05, 1.1, "coupler"), Box(0.05, 0.05, a, 0.7, "rocker")
+    ha, hb = np.array([0, 0, a / 2]), np.array([0, b / 2, 0])
+    j1 = EqualityConstraint(Revolute(origin, crank, ex, p2=-ha), "floor_crank")
+    j2 = EqualityConstraint(Revolute(crank, coupler, ex, p1=ha, p2=-hb), "crank_coupler")
+    j3 = EqualityConstraint(Revolute(coupler, rocker, ex, p1=hb, p2=ha), "coupler_rocker")
+    j4 = EqualityConstraint(Revolute(origin, rocker, ex, p1=np.array([0, b, 0]), p2=-ha), "floor_rocker")
+    mech = Mechanism(origin, [crank, coupler, rocker], [j1, j2, j3, j4], g=-9.81, dt=0.01)
+    setPosition(origin, crank, p2=-ha, Δq=RotX(θ))
+    setPosition(crank, coupler, p1=ha, p2=-hb, Δq=RotX(-θ))          # the coupler stays level in a parallelogram
+    setPosition(coupler, rocker, p1=hb, p2=ha, Δq=RotX(θ))
+    return {"mech": mech, "eqcids": [getid(j1)], "bodies": [crank, coupler, rocker]}
+

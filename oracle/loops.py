@@ -230,3 +230,11 @@ def deltabot():
     place(z, UL, PL, pul, pp, rotx(3 * np.pi / 4))                                              # :41
     u = np.zeros(len(joints)); u[0], u[1] = 6.7879484, -6.7879484                               # Fτd :53
     return mech, z, u
+
+
+def from_tables(t):
+    """the LoopMechanism of a host-mirror mechanism's tables (constrainedcontrol.jl_amd/mechanism.py MechTables: bodies and joints in the caller's
+    order, parent -1 = origin) -- so that any mechanism the tests build through the mirror has its dense-KKT reference"""
+    joints = [Joint(int(t.type[j]), int(t.parent[j]), int(t.child[j]), t.axis[j], t.p1[j], t.p2[j], t.qoff[j]) for j in range(t.ne)]
+    return LoopMechanism(t.mass, t.inertia.reshape(t.nb, 3, 3), joints, dt=t.dt, g=t.g)
+

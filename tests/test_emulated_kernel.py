@@ -409,6 +409,36 @@ def test_emulated_closed_loop_deltabot(cclqr, orc, emu):
     assert np.abs(zTp[0] - z0).max() > 1e-2                         # (the PID moved the platform)
 
 
+def test_emulated_fourbar_linkage(cclqr, orc, emu):
+    """a second closed-loop topology for the column-order Gauss-Jordan solve of round 4 (csrc/cclqr_loop.h): a parallelogram four-bar linkage --
+    three bodies, four revolutes about one axis, 20 constraint rows of rank 17 (every joint repeats the two out-of-plane rotational rows and the
+    loop closes one planar row pair twice).  The mechanism is closed at its pose, falls under gravity with a PID-free feedback law on the crank,
+    and equals the dense-KKT minimum-norm reference (oracle/loops.py, built from the same tables) step by step"""
+    from oracle import loops
+    ex = cclqr.examples.fourbar()
+    mech = ex["mech"]
+    t = mech.tables()
+    assert mech.has_loops and (t.nb, t.ne) == (3, 4)
+    lm = loops.from_tables(t)
+    z0 = mech.state()
+    assert np.abs(lm.constraints(z0)).max() < 1e-14                          # the loop is closed at the placed pose
+    steps = 40
+    rng = np.random.default_rng(11)
+    K = rng.normal(size=(1, 1, 12 * t.nb)) * 1.5
+    Fd = np.array([0.7])
+    c = orc.ctrl_desc(t.nb, [0], K=K, N=0, zd=z0[None], Fd=Fd.reshape(1, 1))
+    zT, traj, st = emu_loop_rollout(emu, orc, t, c, z0, steps)
+    traj_ref, lam, z = [], np.zeros(lm.nrows), z0.copy()
+    for k in range(steps):
+        traj_ref.append(z.copy())
+        u = np.zeros(4)
+        u[0] = Fd[0] - K[0, 0] @ loops.state_error(z, z0)
+        z, lam, _ = lm.step(z, lam, u)
+    assert st[0] > 0
+    assert np.abs(traj[0] - np.array(traj_ref)).max() < 1e-9 and np.abs(zT[0] - z).max() < 1e-9
+    assert np.abs(lm.constraints(zT[0])).max() < 1e-11 and np.abs(zT[0] - z0).max() > 0.05      # still closed, and it moved
+
+
 def emu_loop_linearize(emu, orc, t, zd, cj, Fd, force_loop):
     m = orc.mech_desc(t)
     nb, nj, mu = t.nb, t.ne, len(cj)

@@ -397,6 +397,34 @@ def test_closed_loop_deltabot_rollout_matches_oracle(cclqr, orc):
 
 
 
+def test_fourbar_linkage_rollout_matches_oracle(cclqr, orc):
+    """a second closed-loop topology on `rollout_loop_kernel<3>` (20 constraint rows of rank 17: three redundant directions, another pattern
+    than the deltabot's): a batch of parallelogram four-bar linkages at different crank angles under a feedback law on the crank, every
+    instance against the dense-KKT reference built from the same tables (oracle/loops.py from_tables)"""
+    from oracle import loops
+    capi = cclqr._capi
+    steps, n = 40, 4
+    exs = [cclqr.examples.fourbar(θ=th) for th in (0.6, 0.3, -0.4, 1.1)]
+    t = exs[0]["mech"].tables()
+    lm = loops.from_tables(t)
+    z0 = np.array([e["mech"].state() for e in exs])
+    rng = np.random.default_rng(11)
+    K = rng.normal(size=(n, 1, 1, 12 * t.nb)) * 1.5
+    Fd = rng.uniform(-1.0, 1.0, (n, 1, 1))
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=0, zd=z0[:, None], Fd=Fd, n_ctrl=n)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, steps, record=True)
+    assert (st > 0).all()
+    for i in range(n):
+        z, lam = z0[i].copy(), np.zeros(lm.nrows)
+        for k in range(steps):
+            assert np.abs(traj[i, k] - z).max() < 1e-8, (i, k)        # north_star's tolerance: the linkage swings at up to 5 rad/s and the
+            u = np.zeros(4)                                             # reference's own Newton stops at |f| < 1e-10 per step (1.2e-9 after 24 steps)
+            u[0] = Fd[i, 0, 0] - K[i, 0, 0] @ loops.state_error(z, z0[i])
+            z, lam, _ = lm.step(z, lam, u)
+        assert np.abs(zT[i] - z).max() < 1e-8 and np.abs(lm.constraints(zT[i])).max() < 1e-11
+
+
 _SHARDED_WORKER = r"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, %(root)r)
