@@ -20,9 +20,6 @@ namespace cclqr {
 
 // LDS image of one instance.  Body-indexed arrays keep the names (and meaning) of the tree kernels' layout so that their body phases
 // (ph_body_eval, ph_control_error, ph_gain_partial, ph_accept, ph_update) run unchanged; joint-indexed arrays have nj entries.
-// SS = the dense system, one row per lane: [r | S row (5 nj columns) | 8 doubles of padding that stay zero], odd stride.  The padding
-// lets the solve move through a row eight columns at a time without a bounds test per element.
-HD int loop_row_stride(int nj) { return (5 * nj + 9) | 1; }
 HD Lay make_loop_layout(int nb, int nj) {
     Lay L; int o = 0;
     L.Z = o; o += 13 * nb;   L.S = o; o += 6 * nb;   L.ST = o; o += 6 * nb;   L.DS = o; o += 6 * nb;
@@ -33,7 +30,7 @@ HD Lay make_loop_layout(int nb, int nj) {
     L.UJ = o; o += nj;
     L.C = o; o += 6 * nb;    L.CD = o; o += 6 * nb;
     L.DZ = o; o += 12 * nb;
-    L.SS = o; o += 5 * nj * loop_row_stride(nj);
+    L.SS = 0;            // (the dense system is assembled straight into the lanes' registers since round 4: lpr_assemble)
     L.SJJ = L.SJP = L.SPJ = 0;
     L.total = o | 1;
     return L;
@@ -197,46 +194,6 @@ HD double lp_joint_eval(int t, const Lay& Y, double* L, const LaneRegs& r, const
     return acc;
 }
 
-// S: row `row` of the dense system [S | r] (lane = row; joint i = row / 5):
-//   S[(i,ri)][(j,rj)] = sum over the bodies joints i and j share of  W_side(i)[ri] . Gk_side(j)[rj]
-//   r[(i,ri)] = g_i[ri] - W_b(i)[ri] . d_{jb(i)} - W_a(i)[ri] . d_{ja(i)}
-HD void lp_schur_row(int row, const Lay& Y, double* L, const MechDev* M) {
-    const int nj = M->nj, mr = 5 * nj;
-    if (row >= mr) return;
-    const int i = row / 5, ri = row - 5 * i;
-    const int ia = M->parent[i], ib = M->jchild[i];
-    double wa[6], wb[6];
-    for (int c = 0; c < 6; c++) { wa[c] = L[Y.GVA + BLK * i + 6 * ri + c]; wb[c] = L[Y.GVB + BLK * i + 6 * ri + c]; }
-    double* out = L + Y.SS + row * loop_row_stride(nj);
-    for (int j = 0; j < nj; j++) {
-        const int ja = M->parent[j], jb = M->jchild[j];
-        const bool bb = ib == jb, ba = ib == ja, ab = ia >= 0 && ia == jb, aa = ia >= 0 && ia == ja;
-        // the products of one joint are formed in registers and stored together: a store into the same LDS array between the loads
-        // would serialise them (the compiler cannot tell the row of S from the Jacobian blocks)
-        double sj[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (bb || ab) {                 // joint j's child-side block meets joint i's child body (bb) or parent body (ab): one block in flight at a time
-            double kb[30];
-            for (int e = 0; e < 30; e++) kb[e] = L[Y.GKB + BLK * j + e];
-            for (int rj = 0; rj < 5; rj++) {
-                if (bb) sj[rj] += dot6(wb, kb + 6 * rj);
-                if (ab) sj[rj] += dot6(wa, kb + 6 * rj);
-            }
-        }
-        if (ba || aa) {
-            double ka[30];
-            for (int e = 0; e < 30; e++) ka[e] = L[Y.GKA + BLK * j + e];
-            for (int rj = 0; rj < 5; rj++) {
-                if (ba) sj[rj] += dot6(wb, ka + 6 * rj);
-                if (aa) sj[rj] += dot6(wa, ka + 6 * rj);
-            }
-        }
-        for (int rj = 0; rj < 5; rj++) out[1 + 5 * j + rj] = sj[rj];
-    }
-    double rr = L[Y.G + 5 * i + ri] - dot6(wb, L + Y.D + 6 * ib);
-    if (ia >= 0) rr -= dot6(wa, L + Y.D + 6 * ia);
-    out[0] = rr;
-}
-
 // ---- dense solve of the (singular, consistent) system S dl = r: Gauss-Jordan elimination, column by column, pivoting over the rows, that
 // SKIPS a column whose entries in the rows still in play are all below the rank tolerance (a redundant direction: its dl stays 0).
 // Lane = row for the whole solve, and since round 4 the row LIVES IN THE LANE'S REGISTERS (8 NCB >= 5 nj columns, compile time; the LDS
@@ -268,16 +225,53 @@ HD double lp_from_bits(unsigned long long u) { union { double d; unsigned long l
 // 63 - row -- 14 bits of mantissa decide between candidates, which is all a pivot search needs (the pivot VALUE is read exactly, from the row)
 HD unsigned lp_row_key(double v, int row) { return ((unsigned)(lp_bits(fabs(v)) >> 32) & ~0x3Fu) | (unsigned)(63 - row); }
 HD int lp_key_row(unsigned key) { return 63 - (int)(key & 63); }
-// the lane's row out of the dense system (padding columns beyond 5 nj read the row's zero padding); returns its largest magnitude
+// S: row `row` of the dense system [S | r] (lane = row; joint i = row / 5), assembled straight into the lane's registers:
+//   S[(i,ri)][(j,rj)] = sum over the bodies joints i and j share of  W_side(i)[ri] . Gk_side(j)[rj]
+//   r[(i,ri)] = g_i[ri] - W_b(i)[ri] . d_{jb(i)} - W_a(i)[ri] . d_{ja(i)}
+// The loop over the joints j is unrolled to the 8 NCB / 5 joints the instantiation holds (register numbers are compile-time), guarded by the
+// mechanism's joint count; columns beyond 5 nj and the rows of lanes beyond 5 nj are zero.  Returns the row's largest magnitude.
 template <int NCB>
-HD double lpr_load(LoopRowR<NCB>& R, int row, int mr, int stride, const Lay& Y, const double* L) {
+HD double lpr_assemble(LoopRowR<NCB>& R, int row, const Lay& Y, const double* L, const MechDev* M) {
+    const int nj = M->nj, mr = 5 * nj;
+    const bool on = row < mr;
+    const int i = on ? row / 5 : 0, ri = on ? row - 5 * i : 0;
+    const int ia = M->parent[i], ib = M->jchild[i];
     R.col = -1; R.ipiv = 0.0;
-    const double* a = L + Y.SS + (row < mr ? row : 0) * stride;
-    R.rhs = row < mr ? a[0] : 0.0;
+    double wa[6], wb[6];
+    for (int c = 0; c < 6; c++) { wa[c] = L[Y.GVA + BLK * i + 6 * ri + c]; wb[c] = L[Y.GVB + BLK * i + 6 * ri + c]; }
     double m_ = 0.0;
 #pragma unroll
-    for (int c = 0; c < 8 * NCB; c++) { R.a[c] = row < mr ? a[1 + c] : 0.0; m_ = fmax(m_, fabs(R.a[c])); }       // lanes beyond 5 nj: a zero row
-    return row < mr ? m_ : 0.0;
+    for (int c = 0; c < 8 * NCB; c++) R.a[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (8 * NCB) / 5; j++) {
+        if (j < nj) {                                      // (uniform)
+            const int ja = M->parent[j], jb = M->jchild[j];
+            const bool bb = on && ib == jb, ba = on && ib == ja, ab = on && ia >= 0 && ia == jb, aa = on && ia >= 0 && ia == ja;
+            double sj[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (bb || ab) {                 // joint j's child-side block meets joint i's child body (bb) or parent body (ab): one block in flight at a time
+                double kb[30];
+                for (int e = 0; e < 30; e++) kb[e] = L[Y.GKB + BLK * j + e];
+                for (int rj = 0; rj < 5; rj++) {
+                    if (bb) sj[rj] += dot6(wb, kb + 6 * rj);
+                    if (ab) sj[rj] += dot6(wa, kb + 6 * rj);
+                }
+            }
+            if (ba || aa) {
+                double ka[30];
+                for (int e = 0; e < 30; e++) ka[e] = L[Y.GKA + BLK * j + e];
+                for (int rj = 0; rj < 5; rj++) {
+                    if (ba) sj[rj] += dot6(wb, ka + 6 * rj);
+                    if (aa) sj[rj] += dot6(wa, ka + 6 * rj);
+                }
+            }
+#pragma unroll
+            for (int rj = 0; rj < 5; rj++) { R.a[5 * j + rj] = sj[rj]; m_ = fmax(m_, fabs(sj[rj])); }
+        }
+    }
+    double rr = L[Y.G + 5 * i + ri] - dot6(wb, L + Y.D + 6 * ib);
+    if (ia >= 0) rr -= dot6(wa, L + Y.D + 6 * ia);
+    R.rhs = on ? rr : 0.0;
+    return m_;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LOOP_OPAQUE(i) asm volatile("" : "+s"(i))

@@ -75,13 +75,11 @@ __device__ __forceinline__ bool loop_solve_step(LoopRowR<NCB>& R, int t, int kb,
 // S dl = r by Gauss-Jordan elimination over the columns that have a pivot, rows in registers (cclqr_loop.h); dl of the free (redundant) directions is 0
 template <int NCB>
 __device__ __forceinline__ void loop_solve(int t, const Lay& Y, double* L, const MechDev* M PROF_ARG) {
-    const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
-    lp_schur_row(t, Y, L, M);
-    if (t < mr) L[Y.DL + t] = 0.0;
-    __syncthreads();
-    STAMP(PF_SCHUR_S);
+    const int mr = 5 * M->nj;
     LoopRowR<NCB> R;
-    const double tol = LOOP_RANK_TOL * wave_max_d(lpr_load(R, t, mr, stride, Y, L));
+    const double tol = LOOP_RANK_TOL * wave_max_d(lpr_assemble(R, t, Y, L, M));
+    if (t < mr) L[Y.DL + t] = 0.0;
+    STAMP(PF_SCHUR_S);
 #pragma unroll 1
     for (int kb = 0; kb < NCB; kb++) {            // (columns beyond 5 nj are zero padding: no pivot, skipped)
         loop_solve_step<NCB, 0>(R, t, kb, mr, tol); loop_solve_step<NCB, 1>(R, t, kb, mr, tol);
@@ -140,9 +138,11 @@ __device__ __forceinline__ int loop_newton(int t, const Lay& Y, double* L, LaneR
 }
 
 // relax: 0 = the reference's stopping rule, 1 = newton_mode 1 (a.eps_alone).  NCB: the dense system's rows are held in registers 8 NCB columns wide
-// Two wavefronts per SIMD (<= 256 registers): the deltabot's image is 24.8 KB, so LDS admits SIX workgroups per CU where the 307 registers the
-// kernel would like admit four; at 256 the compiler parks ~50 doubles of the evaluation phases in scratch (204 bytes per lane, none inside
-// the solve) and the rollout is still 19 % faster (11.6 against 9.8 M instance-steps/s at 8192 instances, 13.4 against 11.2 M at 32768).
+// Two wavefronts per SIMD (<= 256 registers): with the dense system assembled in registers the deltabot's LDS image is 12.2 KB (24.8 KB with the
+// system staged in LDS), so LDS admits thirteen workgroups per CU where the 307 registers the kernel would like admit four; at 256 the compiler
+// parks ~50 doubles of the evaluation / assembly phases in scratch (364 bytes per lane, none inside the elimination) and the rollout is faster:
+// 9.8 M instance-steps/s at 8192 instances with one wavefront per SIMD, 11.6 M with two and the staged system (six per CU), 14.6 M with two and
+// the register assembly (eight per CU); three per SIMD (168 registers, 992 bytes of scratch) falls back to 12.4 M.
 template <int NCB>
 __global__ __launch_bounds__(64, 2) void rollout_loop_kernel(RolloutArgs a, int relax) {
     extern __shared__ double lds[];

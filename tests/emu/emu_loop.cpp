@@ -56,12 +56,11 @@ void loop_solve_t(LoopInst& I) {
     const MechDev* M = I.M;
     const Lay& Y = I.Y;
     double* L = I.L;
-    const int mr = 5 * M->nj, stride = loop_row_stride(M->nj);
-    for (int t = 0; t < 64; t++) lp_schur_row(t, Y, L, M);
+    const int mr = 5 * M->nj;
     for (int t = 0; t < mr; t++) L[Y.DL + t] = 0.0;
     std::vector<LoopRowR<NCB>> R(64);
     double amax = 0.0;
-    for (int t = 0; t < 64; t++) amax = fmax(amax, lpr_load(R[t], t, mr, stride, Y, L));
+    for (int t = 0; t < 64; t++) amax = fmax(amax, lpr_assemble(R[t], t, Y, L, M));
     const double tol = LOOP_RANK_TOL * amax;
     for (int kb = 0; kb < NCB; kb++) {
         loop_solve_step<NCB, 0>(R, kb, mr, tol); loop_solve_step<NCB, 1>(R, kb, mr, tol);

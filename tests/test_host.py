@@ -489,9 +489,10 @@ def test_loop_rollout_kernel_resources(tmp_path):
     kernels = _kernel_resources(tmp_path, "rollout_loop.hip", "rollout_loop_kernel")
     assert len(kernels) == 8, sorted(kernels)
     for name, k in kernels.items():
-        # two wavefronts per SIMD (six instances per CU by LDS instead of four): 256 registers and a small, bounded spill of the evaluation
-        # phases (measured +19 % against the 307-register build without scratch)
-        assert k["scratch"] <= 256 and k["vgpr"] <= 256 and k["lds"] == 0, (name, k)
+        # two wavefronts per SIMD (eight instances per CU instead of four): 256 registers and a small, bounded spill of the evaluation and
+        # assembly phases (measured: +19 % against the 307-register build without scratch at six per CU, +28 % more at eight per CU once the
+        # dense system is assembled in registers and its 12.6 KB leave the LDS image)
+        assert k["scratch"] <= 384 and k["vgpr"] <= 256 and k["lds"] == 0, (name, k)
 
 
 def test_tree_rollout_kernel_resources(tmp_path):
