@@ -41,7 +41,7 @@ extern "C" {
 /* Mechanism(origin, bodies, eqconstraints; g, Δt) -- examples/lqr_cartpole.jl:32.
  * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
  * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
- * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (LQR / TrackingLQR law with joint friction and noise, no PID; one instance per wavefront, multipliers lam
+ * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (LQR / TrackingLQR law with joint friction and noise, PID; one instance per wavefront, multipliers lam
  * [n_inst][5*ne]); cclqr_linearize returns their A, Bu, Bλ, G (ml = 5*ne rows, a FixedOrientation contributing two null rows), but G*Bλ
  * is singular for a loop, so LQR / TrackingLQR construction goes through cclqr_linearize_projected + cclqr_riccati / cclqr_riccati_tv with
  * ml = 0 (cclqr_riccati_tracking, which divides by G*Bλ at every knot, returns CCLQR_EUNSUPPORTED for them). */
