@@ -84,6 +84,25 @@ HD void link_load_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
     c.sxa = has_a ? dt * dt / M->m[pa >= 0 ? pa : 0] : 0.0;
     c.fric = 0.0;
 }
+// the link constants again (not the flags, not the friction coefficient): an experiment switch of rollout_chain.hip (CHAIN_RELOAD_CONSTS)
+HD void link_reload_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
+    const bool on = t < nb;
+    const int l = on ? t : 0;
+    c.m = M->m[l];
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.J[i] = M->J[l][i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c.p1[i] = M->p1[l][i]; c.p2[i] = M->p2[l][i]; c.axis[i] = M->axis[l][i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.qoc[i] = M->qoc[l][i];
+    const int vrow = c.rev() ? 3 : 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c.V12[i] = M->sel[l][vrow][i]; c.V12[3 + i] = M->sel[l][vrow + 1][i]; }
+    const int pa = M->parent[l];
+    c.dtm = dt / c.m;
+    c.sxb = dt * c.dtm;
+    c.sxa = c.has_a() ? dt * dt / M->m[pa >= 0 ? pa : 0] : 0.0;
+}
 // selector of constraint row `row` (compile-time row index)
 HD void row_sel(const LinkC& c, int row, double* s) {
     const bool rev = c.rev();

@@ -374,6 +374,14 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             }
             double nd;
             LINK_FLAGS_FRESH(c);
+#ifdef CHAIN_RELOAD_CONSTS
+            {   // experiment: the link constants (33 doubles per lane) re-read behind the linear solve through a pointer the optimiser cannot see
+                // through, so that they are dead -- 66 registers free -- while the solve runs
+                const MechDev* Mq = ap->M;
+                asm volatile("" : "+s"(Mq));
+                link_reload_consts(c, Mq, t, nb, dt);
+            }
+#endif
             {   // multiplier step from LDS, body solve
                 double own[6], par[6], cpar[6], dl[5], pdn = 0.0;
 #pragma unroll
