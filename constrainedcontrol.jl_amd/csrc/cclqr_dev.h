@@ -17,7 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#define CCLQR_MAXL 32          // links per mechanism supported by the device path
+#define CCLQR_MAXL 64          // links per mechanism supported by the device path (chains: one lane per link of a wavefront; branching trees: 32, cclqr_treereg.h)
 #define CCLQR_MAXK 4           // child joints per body (general trees)
 #define CCLQR_MAXP 48          // sibling pairs (joints that share their parent body)
 #define CCLQR_MAXI 8           // joints around one body of a closed-loop mechanism
@@ -37,7 +37,7 @@ struct MechDev {
     int jperm[CCLQR_MAXL];    // user joint index of link l's joint
     // links are numbered chain by chain (parent[l] == l-1 inside a chain): bit l of start_mask / end_mask marks the
     // link attached to the origin / the leaf of its chain, so the hot phases need no table lookups
-    unsigned start_mask, end_mask;
+    unsigned long long start_mask, end_mask;       // (64 links)
     int nchains, chain_start[CCLQR_MAXL], chain_len[CCLQR_MAXL];
     double m[CCLQR_MAXL], J[CCLQR_MAXL][9];
     double p1[CCLQR_MAXL][3], p2[CCLQR_MAXL][3], axis[CCLQR_MAXL][3], qoc[CCLQR_MAXL][4]; // qoc = conj(qoffset)
@@ -489,9 +489,9 @@ HD double ph_joint_eval(int t, int nb, const Lay& Y, double* L, const LaneRegs& 
 
 
 // F3 (once per step, after the knot Jacobians): C_b = Gk_b(own joint)' lambda_b + Gk_a(child joint)' lambda_child
-HD void ph_force_map(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
+HD void ph_force_map(int t, int G, int nb, const Lay& Y, double* L, unsigned long long end_mask) {
     for (int b = t; b < nb; b += G) {
-        const bool has_c = !((end_mask >> b) & 1u);
+        const bool has_c = !((end_mask >> b) & 1ull);
         double gb[30], lb[5], ga[30], lc[5];
 #pragma unroll
         for (int i = 0; i < 30; i++) gb[i] = L[Y.GKB + BLK * b + i];
@@ -524,12 +524,12 @@ HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b
 //   part 0: (W_b[j], Gk_b[j]) + (W_a[j], Gk_a[j]) -> row of S_jj ;  r_j = g_j - W_b d_b - W_a d_a
 //   part 1: (W_a[j], Gk_b[p]) -> row of S_jp ,  (W_b[p], Gk_a[j]) -> row of S_pj        (p = j-1, the parent link)
 // Each task loads all its operands into registers, computes, then stores (no store between loads).
-HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, unsigned start_mask) {
+HD void ph_schur_s(int t, int G, int nb, const Lay& Y, double* L, unsigned long long start_mask) {
     for (int e = t; e < 10 * nb; e += G) {
         const int part = (e >= 5 * nb) ? 1 : 0;
         const int e5 = e - part * 5 * nb;
         const int j = e5 / 5, row = e5 - 5 * j;
-        const bool has_p = !((start_mask >> j) & 1u);
+        const bool has_p = !((start_mask >> j) & 1ull);
         if (part && !has_p) continue;
         const int p = has_p ? j - 1 : j;
         const int ov1 = (part ? Y.GVA + BLK * j : Y.GVB + BLK * j) + 6 * row;
@@ -674,9 +674,9 @@ HD void ph_tri_back(int t, int j, const TriPlan& P, const Lay& Y, double* L) {
 }
 
 // S4: ds_b = D_b^-1 (d_b + Gk_b(own joint)' dl_b + Gk_a(child joint)' dl_child), one task per body
-HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned end_mask) {
+HD void ph_body_solve(int t, int G, int nb, const Lay& Y, double* L, unsigned long long end_mask) {
     for (int b = t; b < nb; b += G) {
-        const bool has_c = !((end_mask >> b) & 1u);
+        const bool has_c = !((end_mask >> b) & 1ull);
         double d[6], gb[30], lb[5], ga[30], lc[5], Di[9];
 #pragma unroll
         for (int i = 0; i < 6; i++) d[i] = L[Y.D + 6 * b + i];

@@ -125,7 +125,7 @@ __device__ __forceinline__ int newton_solve(int t, int nb, const Lay& Y, double*
     double normf0 = eval_point<G, true>(t, nb, FRESH_Y, L, r, M, dt, Y.S, 0.0, valid PROF_PASS);
     bool done = !valid, failed = false;
     int its = 0;
-    const unsigned smask = M->start_mask, emask = M->end_mask;
+    const unsigned long long smask = M->start_mask, emask = M->end_mask;
     const int nchains = M->nchains;
     int s_cur = Y.S, s_try = Y.ST, l_cur = Y.LAM, l_try = Y.LT;   // accepted / trial buffers swap roles on every acceptance
     // lane groups of the level-parallel line search: group lg works on link tl (the caller has loaded link tl's constants and

@@ -105,7 +105,7 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
         if (loop) return build_loop_tables(d, m, err);
     }
     m->nj = nb;
-    if (nb > CCLQR_MAXL) { err = "more than 32 bodies"; return CCLQR_EUNSUPPORTED; }
+    if (nb > CCLQR_MAXL) { err = "more than 64 bodies"; return CCLQR_EUNSUPPORTED; }
     std::vector<int> pj(nb, -1), nchild(nb, 0);
     for (int j = 0; j < nb; j++) {
         int a = d->parent[j], b = d->child[j];
@@ -192,12 +192,12 @@ static inline int build_mech_tables(const cclqr_mech_desc* d, cclqr_mech* m, std
     H.start_mask = 0; H.end_mask = 0;
     for (int c = 0; c < H.nchains; c++) {
         H.chain_start[c] = cstart[c]; H.chain_len[c] = clen[c];
-        H.start_mask |= 1u << cstart[c];
-        H.end_mask |= 1u << (cstart[c] + clen[c] - 1);
+        H.start_mask |= 1ull << cstart[c];
+        H.end_mask |= 1ull << (cstart[c] + clen[c] - 1);
     }
     for (int l = 0; l < nb; l++) {
         if (H.parent[l] >= l) { err = "internal: a link precedes its parent"; return CCLQR_EINVAL; }
-        if (!tree && H.parent[l] != (((H.start_mask >> l) & 1u) ? -1 : l - 1)) { err = "internal: link order is not chain-contiguous"; return CCLQR_EINVAL; }
+        if (!tree && H.parent[l] != (((H.start_mask >> l) & 1ull) ? -1 : l - 1)) { err = "internal: link order is not chain-contiguous"; return CCLQR_EINVAL; }
     }
     if (tree) {
         // sibling pairs and the elimination program (links in reverse order; when l goes, what is left around its parent body

@@ -547,11 +547,11 @@ extern "C" int cclqr_prof_read_chain(unsigned long long* out, int reset) {
 #endif
 
 // 8 lanes per instance up to 4 links (one elimination front of 6 lanes; eight instances per wavefront: the cartpole and triple-cartpole
-// configs), 16 up to 8 links (the two fronts need 14), 32 beyond: with 16 lanes a 9..16-link instance would fill LDS with two
-// wavefronts per CU
-int chain_lanes_per_instance(int nb) { return nb <= 4 ? 8 : (nb <= 8 ? 16 : 32); }
+// configs), 16 up to 8 links (the two fronts need 14), 32 up to 32 links: with 16 lanes a 9..16-link instance would fill LDS with two
+// wavefronts per CU; 33..64 links: the whole wavefront is one instance (76.8 KB of LDS: two workgroups per CU)
+int chain_lanes_per_instance(int nb) { return nb <= 4 ? 8 : (nb <= 8 ? 16 : (nb <= 32 ? 32 : 64)); }
 // links the LDS image is laid out for: the instantiations below (17 = the headline mechanism: exactly four workgroups per CU)
-int chain_layout_links(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : 32))); }
+int chain_layout_links(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : (nb <= 32 ? 32 : 64)))); }
 
 size_t chain_lds_bytes(int nb) { return (size_t)(64 / chain_lanes_per_instance(nb)) * make_chain_layout(chain_layout_links(nb)).total * sizeof(double); }
 
@@ -586,7 +586,8 @@ hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int new
         case 8: return launch_chain_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
         case 16: return launch_chain_one<32, 16>(a, extra, newton_mode, grid, lds, stream);
         case 17: return launch_chain_one<32, 17>(a, extra, newton_mode, grid, lds, stream);
-        default: return launch_chain_one<32, 32>(a, extra, newton_mode, grid, lds, stream);
+        case 32: return launch_chain_one<32, 32>(a, extra, newton_mode, grid, lds, stream);
+        default: return launch_chain_one<64, 64>(a, extra, newton_mode, grid, lds, stream);
     }
 }
 

@@ -101,10 +101,10 @@ extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_des
     const int nb = M->nb, nz = 13 * nb;
     const double dt = M->dt;
     Inst I;
-    I.G = G_override > 0 ? G_override : (nb <= 4 ? 8 : (nb <= 8 ? 16 : 32));
+    I.G = G_override > 0 ? G_override : (nb <= 4 ? 8 : (nb <= 8 ? 16 : (nb <= 32 ? 32 : 64)));
     if (I.G < nb) return CCLQR_EINVAL;
     I.nb = nb; I.dt = dt;
-    I.Y = make_chain_layout(nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : 32))));     // = chain_layout_links(nb) of rollout_chain.hip
+    I.Y = make_chain_layout(nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : (nb <= 32 ? 32 : 64)))));     // = chain_layout_links(nb) of rollout_chain.hip
     I.lds.resize(I.Y.total);          // exact size: an out-of-range offset is an out-of-bounds access for the sanitizer
     I.L = I.lds.data();
     I.c.resize(I.G); I.S.resize(I.G); I.T.resize(I.G);

@@ -249,7 +249,7 @@ def test_emulated_acrobot_and_pid_double_pendulum(cclqr, orc, emu):
 
 
 def test_emulated_maximum_size_32_bodies(cclqr, orc, emu):
-    """the largest mechanism the device path takes (CCLQR_MAXL = 32 links: cart + 31 links) and the first one it refuses"""
+    """the largest mechanism of a 32-lane group (cart + 31 links: two instances per wavefront, the 32-link image)"""
     ex = cclqr.examples.cartpole_n(31)
     t = ex["mech"].tables()
     zd = hanging_setpoint(cclqr, 31)
@@ -261,6 +261,26 @@ def test_emulated_maximum_size_32_bodies(cclqr, orc, emu):
     oc = orc.ctrl_desc(32, [0], K=K, N=0, zd=zd)
     _, traj_o, st_o = orc.rollout(t, oc, z0, 12, record=True)
     _, traj, st = emu_rollout(emu, orc, t, oc, z0, 12)
+    assert (st_o > 0).all() and (st > 0).all()
+    assert np.abs(traj - traj_o).max() < 1e-10
+
+
+@pytest.mark.parametrize("n_links", [39, 63])
+def test_emulated_chains_beyond_32_links(cclqr, orc, emu, n_links):
+    """chains of 33 .. 64 bodies (CCLQR_MAXL = 64 since round 4): one instance per wavefront, the 64-link image, the plain two-front sweep
+    (no reduction level beyond 17 links) -- a 40-body and a 64-body hanging chain under a feedback law, against the oracle"""
+    nb = n_links + 1
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    rng = np.random.default_rng(8)
+    K = rng.normal(size=(1, 1, 12 * nb)) * 0.01
+    phi = rng.uniform(-1, 1, (1, n_links)) * 0.1
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, [0.2], phi)
+    oc = orc.ctrl_desc(nb, [0], K=K, N=0, zd=zd)
+    _, traj_o, st_o = orc.rollout(t, oc, z0, 8, record=True)
+    _, traj, st = emu_rollout(emu, orc, t, oc, z0, 8)
     assert (st_o > 0).all() and (st > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-10
 

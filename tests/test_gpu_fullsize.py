@@ -247,8 +247,8 @@ def test_cfg4_sawyer_8192_full_horizon(cclqr, orc):
 
 
 def test_maximum_mechanism_size_32_bodies(cclqr, orc):
-    """CCLQR_MAXL = 32 links (cart + 31 links; mx = 384, ml = 160): linearisation, the tiled Riccati sweep and a batched rollout against
-    the oracle; 33 bodies are refused with CCLQR_EUNSUPPORTED"""
+    """the largest mechanism of a 32-lane group (cart + 31 links; mx = 384, ml = 160): linearisation, the tiled Riccati sweep and a batched
+    rollout against the oracle"""
     capi = cclqr._capi
     ex = cclqr.examples.cartpole_n(31)
     t = ex["mech"].tables()
@@ -273,7 +273,43 @@ def test_maximum_mechanism_size_32_bodies(cclqr, orc):
     zo, traj_o, sto = orc.rollout(t, orc.ctrl_desc(32, [0], K=K, N=N, zd=zd), z0, 30, record=True)
     assert (st > 0).all() and (sto > 0).all()
     assert np.abs(traj - traj_o).max() < 1e-9
-    big = cclqr.examples.cartpole_n(32)["mech"].tables()
+
+
+def test_chains_of_33_to_64_bodies(cclqr, orc):
+    """CCLQR_MAXL = 64 since round 4: a chain of 33 .. 64 bodies is one instance per wavefront on `rollout_chain_kernel<64, 64, law>` (76.8 KB
+    of LDS, two workgroups per CU).  40 bodies: linearisation (mx = 480), a short Riccati sweep and a batched rollout against the oracle;
+    64 bodies: the rollout (the linearisation's LDS image still fits: 153.6 KB) ; 65 bodies are refused with CCLQR_EUNSUPPORTED"""
+    capi = cclqr._capi
+    for n_links, with_lqr in ((39, True), (63, False)):
+        nb = n_links + 1
+        ex = cclqr.examples.cartpole_n(n_links)
+        t = ex["mech"].tables()
+        zd = hanging_setpoint(cclqr, n_links)
+        mech = capi.MechHandle(t)
+        assert mech.geometry()[0] == 64
+        rng = np.random.default_rng(8)
+        N = 12
+        if with_lqr:
+            A, Bu, Bl, G = (m[0] for m in capi.linearize(mech, zd[None], [0], np.zeros((1, 1))))
+            Ao, Buo, Blo, Go = orc.linearize(t, zd, [0], np.zeros(1))
+            for X, Xo in ((A, Ao), (Bu, Buo), (Bl, Blo), (G, Go)):
+                assert np.abs(X - Xo).max() < 1e-8 * max(1.0, np.abs(Xo).max())
+            Q, R = np.eye(12 * nb) * t.dt, np.eye(1) * t.dt
+            K, kb = capi.riccati(A, Bu, Bl, G, Q, R, N)
+            Ko, kbo = orc.riccati(Ao, Buo, Blo, Go, Q, R, N)
+            assert kb == kbo and np.abs(K - Ko).max() < 1e-7 * max(1.0, np.abs(Ko).max())
+        else:
+            K = rng.normal(size=(N - 1, 1, 12 * nb)) * 0.01
+        n = 24
+        phi = rng.uniform(-1, 1, (n, n_links)) * 0.1
+        phi[:, 0] += np.pi
+        z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.3, 0.3, n), phi)
+        ctrl = capi.CtrlHandle(mech, [0], K=K, N=N, zd=zd)
+        zT, traj, st = capi.rollout(mech, ctrl, z0, 16, record=True)
+        zo, traj_o, sto = orc.rollout(t, orc.ctrl_desc(nb, [0], K=K, N=N, zd=zd), z0, 16, record=True)
+        assert (st > 0).all() and (sto > 0).all()          # (the iteration counts of these long chains differ at the residual's noise floor: 7..12 either way)
+        assert np.abs(traj - traj_o).max() < 1e-9 and np.abs(zT - zo).max() < 1e-9
+    big = cclqr.examples.cartpole_n(64)["mech"].tables()
     with pytest.raises(capi.CclqrError) as e:
         capi.MechHandle(big)
     assert e.value.code == capi.EUNSUPPORTED
