@@ -123,6 +123,8 @@ if rank == 0:
     print("GLOO_OK")
 else:
     assert out is None and traj is None
+import torch.distributed as _d
+_d.barrier(); _d.destroy_process_group()
 '''
 
 
@@ -211,6 +213,8 @@ if rank == 0:
     print("GLOO8_OK")
 else:
     assert traj is None and zT is None
+torch.distributed.barrier(); torch.distributed.destroy_process_group()      # every rank leaves together (a rank that exits while a peer's gloo threads
+                                                                            # still talk to it aborts in its teardown under load)
 '''
 
 
@@ -464,7 +468,7 @@ def test_linearize_and_riccati_kernel_resources(tmp_path):
     assert len(lin) == 2, sorted(lin)
     for name, k in lin.items():
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 512 and k["lds"] == 0, (name, k)
-        assert k["sgpr_spill"] <= (23 if "ILb1E" in name else 6), (name, k)
+        assert k["sgpr_spill"] <= (25 if "ILb1E" in name else 8), (name, k)      # (25 / 8 since the chain masks are 64 bits wide: 64-link chains; 23 / 6 before)
     ric = _kernel_resources(tmp_path, "riccati.hip", "ric")
     assert len(ric) >= 24, sorted(ric)
     for name, k in ric.items():
