@@ -136,6 +136,46 @@ __device__ __forceinline__ void chain_eval2(LinkC& c, const TrialIn& T, const do
     n2 = sqrt(group_sum<G>(part2));
 }
 
+// ---- line search of the 8- and 16-lane instantiations (eight / four instances per wavefront): a wavefront pays the LONGEST of its instances'
+// searches, and with eight heavy-tailed searches per wavefront somebody nearly always runs deep (53 % of the noise-floor iterations of a
+// wavefront of eight see a search go to the 10th halving) while the groups whose search has ended sit idle.  So the idle groups evaluate
+// further step lengths of the instances still searching (group_assist below): ||f|| at ONE step length, for any group's lanes, of the
+// instance whose trial state is T and whose LDS image is Lc.  Same functions, same order as chain_eval<G, false>.
+template <int G>
+__device__ __forceinline__ double chain_eval1(LinkC& c, const TrialIn& T, const double* Lc, int t, const Lay& Y, double a1, bool active, double dt) {
+    double part1 = 0.0, xq1[7];
+    LINK_FLAGS_FRESH(c);
+#pragma unroll
+    for (int k = 0; k < 7; k++) xq1[k] = T.z[k];
+    if (active) {
+        double cf1[6], sv1[6], cTR[6], d1[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            cTR[k] = Lc[Y.D + 6 * t + k];
+            cf1[k] = Lc[Y.C + 6 * t + k] - a1 * T.cd[k];
+            sv1[k] = T.s[k] - a1 * T.ds[k];
+        }
+        part1 = ck_body_eval<false>(c, T.z, sv1, cf1, cTR, cTR + 3, dt, xq1, d1, nullptr, nullptr);
+    }
+    double p1[7];
+    from_prev<7>(xq1, p1);
+    if (!c.has_a()) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) p1[i] = (i == 3) ? 1.0 : 0.0;
+    }
+    if (active) {
+        double g1[5];
+        joint_eval_sparse<false>(c, p1, p1 + 3, xq1, xq1 + 3, nullptr, nullptr, g1, (double(*)[3]) nullptr, (double(*)[3]) nullptr, (double(*)[3]) nullptr);
+#pragma unroll
+        for (int i = 0; i < 5; i++) part1 += g1[i] * g1[i];
+    }
+    return sqrt(group_sum<G>(part1));
+}
+// value of lane `addr / 4` of the wavefront (ds_bpermute: the LDS crossbar, no memory access)
+__device__ __forceinline__ double lane_fetch(double v, int addr) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+
 // Counter-based noise (noise_philox): the samples of a launch are generated by this kernel into a workspace and the rollout
 // reads them like an injected array -- sqrt/log/cos inside the persistent kernel cost it ~20 scalar registers of polynomial
 // constants for its whole lifetime.  sample (instance n, step k) = Box-Muller of Philox-4x32-10 keyed by the GLOBAL instance index.
@@ -456,14 +496,56 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     lv += (mine && other) ? 2 : 4;
                 }
             } else {
-                for (int lv = 1; lv <= LINE_MAXIT; lv++) {
+                // group assist: the NG = 64 / G groups of the wavefront are dealt to the `count` instances that are still searching -- group g
+                // works for the (g mod count)-th of them at level lv + g / count -- so that a pass covers NG / count levels of every search
+                // (all of them searching: one level each, as before; one straggler: NG levels at once).  Same accept sequence: the first
+                // level that does not grow, level LINE_MAXIT at the latest.
+                constexpr int NG = 64 / G;
+                for (int lv = 1; lv <= LINE_MAXIT;) {
                     if (!__any(!ls_done)) break;
-                    const double a_l = ldexp(1.0, -lv);
-                    const double nf = chain_eval<G, false>(c, S, t, Y, L, a_l, c.live() && !ls_done, dt PROF_PASS);
-                    if (!ls_done) {
-                        normf1 = nf; alpha = a_l; jac_ok = false;
-                        if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
+                    const bool mine = !ls_done;                                                   // uniform over the group
+                    const unsigned long long heads = __ballot(mine && t == 0);                    // bit g G: group g is searching
+                    const int count = __builtin_popcountll(heads);                                // >= 1 behind the vote above
+                    const int per = NG / count;                                                   // levels of every search this pass (>= 1)
+                    const int kq = grp % count, off = grp / count;                                // this group works for the kq-th searcher, level lv + off
+                    unsigned long long hm = heads;
+                    for (int i = 0; i < kq; i++) hm &= hm - 1;                                    // (kq < count: the kq-th set bit exists)
+                    const int src = __builtin_ctzll(hm) / G;                                      // that searcher's group
+                    int myrank = 0;                                                               // rank of this group among the searchers
+                    for (int g2 = 0; g2 < NG; g2++) myrank += (g2 < grp && ((heads >> (g2 * G)) & 1ull)) ? 1 : 0;
+                    const int l0 = lv + off;
+                    const bool work = off < per && l0 <= LINE_MAXIT;
+                    const int fa = (src * G + t) * 4;
+                    TrialIn T;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) T.z[i] = S.z[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { T.s[i] = S.s[i]; T.ds[i] = S.ds[i]; T.cd[i] = S.cd[i]; }
+                    if (count < NG) {                                                             // (uniform) somebody has lanes to spare: hand the trials over
+#pragma unroll
+                        for (int i = 0; i < 7; i++) T.z[i] = lane_fetch(S.z[i], fa);
+#pragma unroll
+                        for (int i = 0; i < 6; i++) { T.s[i] = lane_fetch(S.s[i], fa); T.ds[i] = lane_fetch(S.ds[i], fa); T.cd[i] = lane_fetch(S.cd[i], fa); }
                     }
+                    const double nf = chain_eval1<G>(c, T, lds + src * Y.total, t, Y, ldexp(1.0, -l0), c.on() && work, dt);
+                    PCOUNT(PF_EVALS);
+                    if (count == NG) {                                                            // (uniform) everybody searches: one level each, the group's own result
+                        if (mine) {
+                            normf1 = nf; alpha = ldexp(1.0, -lv); jac_ok = false;
+                            if (!(nf > normf0) || lv == LINE_MAXIT) ls_done = true;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NG; i++) {                                            // the searcher collects its levels in order
+                            const double ci = lane_fetch(nf, ((myrank + i * count) % NG) * G * 4);
+                            const int l = lv + i;
+                            if (mine && !ls_done && i < per && l <= LINE_MAXIT) {
+                                normf1 = ci; alpha = ldexp(1.0, -l); jac_ok = false;
+                                if (!(ci > normf0) || l == LINE_MAXIT) ls_done = true;
+                            }
+                        }
+                    }
+                    lv += per;
                 }
             }
             bool need_jac = false;

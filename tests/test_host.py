@@ -429,7 +429,8 @@ def test_chain_rollout_kernel_resources(tmp_path):
             # No scalar spill (pointers, lane masks) and no scratch anywhere.  "vgpr_spill" counts values the allocator moves to AGPRs after
             # its first pass -- the same v_accvgpr moves as the ~230 values it places there itself, never memory (scratch == 0 above): the
             # 32-lane kernels with the reduction level and the two-level / partner-assisted line search carry up to 8 of them, the rest none
-            assert k["vgpr_spill"] <= (8 if "ILi32ELi1" in name else 0), (name, k)
+            # (the 8- and 16-lane kernels carry up to 8 since their line search hands trial points to idle groups: TrialIn, round 4)
+            assert k["vgpr_spill"] <= (8 if ("ILi32ELi1" in name or "ILi8E" in name or "ILi16E" in name) else 0), (name, k)
             # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
             assert k["vgpr"] <= (504 if "ILi32ELi1" in name else 440), (name, k)
         elif variant == 1:
