@@ -130,7 +130,10 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     hipError_t e = hipMalloc((void**)&c->zd_dev, T.zd.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(c->zd_dev, T.zd.data(), T.zd.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && !T.K.empty()) {
-        e = hipMalloc((void**)&c->K_dev, T.K.size() * sizeof(double));
+        // CCLQR_K_PAD zero doubles behind the last gain row: the rollout kernels fetch a row in whole strides of their lane group and let the
+        // entries past its end meet a zero factor (rollout_chain.hip, control phase) -- past the LAST row that read must stay inside the table
+        e = hipMalloc((void**)&c->K_dev, (T.K.size() + CCLQR_K_PAD) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(c->K_dev + T.K.size(), 0, CCLQR_K_PAD * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(c->K_dev, T.K.data(), T.K.size() * sizeof(double), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && !T.Fd.empty()) {
@@ -215,7 +218,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     WsScope scope;
     hipError_t e = hipMalloc((void**)&c->zd_dev, np * nz * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(c->zd_dev, zl.data(), np * nz * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->K_dev, nK * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->K_dev, (nK + CCLQR_K_PAD) * sizeof(double));      // (padding: see cclqr_ctrl_create)
     if (e == hipSuccess && Fd) {
         e = hipMalloc((void**)&c->Fd_dev, np * mu * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(c->Fd_dev, Fd, np * mu * sizeof(double), hipMemcpyHostToDevice);
@@ -243,7 +246,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     if (e == hipSuccess) e = ws_get((void**)&dst, np * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(dQ, Q, mx * mx * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dR, R, (size_t)mu * mu * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(c->K_dev, 0, nK * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(c->K_dev, 0, (nK + CCLQR_K_PAD) * sizeof(double));
     ra.stop = dstop; ra.A = dA; ra.Bu = dBu; ra.Bl = dBl; ra.G = dG; ra.Q = dQ; ra.R = dR; ra.K = c->K_dev; ra.kbreak = dkb; ra.status = dst; ra.work = dwork;
     if (e == hipSuccess) e = launch_riccati(ra, nullptr);
     if (e == hipSuccess) {

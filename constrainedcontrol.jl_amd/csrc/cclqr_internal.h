@@ -91,6 +91,7 @@ struct cclqr_mech {
     int link_of_joint[CCLQR_MAXL];  // user joint -> internal link (= link of its child body)
     int device;
 };
+#define CCLQR_K_PAD 64          // zero doubles behind a controller's gain table (a whole lane-group stride of the widest instantiation)
 struct cclqr_ctrl {
     cclqr::CtrlDev host;
     cclqr::CtrlDev* dev;

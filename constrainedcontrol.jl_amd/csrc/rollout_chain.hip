@@ -298,20 +298,62 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 if (EXTRA && C->has_fric && c.has_fric()) uj = ck_friction(c, zf, za);
             }
             __syncthreads();
-            for (int i = 0; i < C->mu; i++) {
-                double part = 0.0;
-                if (C->K && c.valid()) {
-                    const double* Krow = C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb;
-                    for (int e = t; e < 12 * nb; e += G) part += Krow[e] * L[Y.DZ + e];
-                }
-                const double s = group_sum<G>(part);
-                double u = ((C->Fd && c.valid()) ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
-                // noise: injected by the caller, or generated for this launch by philox_fill_kernel
+            {
+                // u_i = Fd_i - K_i . dz for the mu inputs.  The gain entries of a lane -- NE per input, read from HBM / L2 -- are ALL requested
+                // before the first one is used, CH inputs at a time, together with the inputs' feed-forward values and joint numbers: as a loop
+                // "load, multiply-add, next entry" every entry paid its own memory round trip (6 round trips per input and lane; 25 % of a
+                // step of the seven-input Sawyer arm, 2.4 % of the headline's).  Same products, same order of summation.
+                constexpr int NE = (12 * NBP + G - 1) / G;
+                constexpr int CH = (G == 16) ? 4 : 1;       // (16 lanes = 5 .. 8 links: the multi-input arms; the others usually have one input)
+                // No predicate lives across the loads (each would be a 64-bit lane mask in scalar registers): an entry past the end of a row is
+                // fetched all the same -- it is the next row's, or the zero padding behind the table (CCLQR_K_PAD) -- and meets a zero in dz;
+                // a lane of an instance that does not exist reads the first instance's tables, and its result is never used.
+                const long long gi = c.valid() ? ginst : a.inst0;
+                const int ne = 12 * nb;
+                double unoise = 0.0;                    // noise: injected by the caller, or generated for this launch by philox_fill_kernel
                 if (EXTRA) {
                     const double* noise = ap->noise;
-                    if (C->noise_scale != 0.0 && c.valid() && noise) u += C->noise_scale * noise[(size_t)inst * ap->noise_stride + (k - 1)];
+                    if (C->noise_scale != 0.0 && c.valid() && noise) unoise = C->noise_scale * noise[(size_t)inst * ap->noise_stride + (k - 1)];
                 }
-                if (t == C->cj[i]) uj += u;
+                double dzv[NE];
+                int tf = t;
+                asm volatile("" : "+v"(tf));            // the entries' range tests are made here, every step -- not once per launch and kept as NE lane masks
+#pragma unroll
+                for (int q = 0; q < NE; q++) { const int e = tf + q * G; dzv[q] = (c.valid() && e < ne) ? L[Y.DZ + e] : 0.0; }
+                const int mu = C->mu;
+                const double* Fp = C->Fd ? C->Fd + gi * C->Fd_stride + (size_t)ksp * mu : nullptr;
+                if (C->K) {                                  // (uniform) LQR / TrackingLQR
+                    const double* Kp = C->K + gi * C->K_stride + (size_t)kidx * mu * ne + t;      // the lane's first entry of the step's first row
+                    for (int i0 = 0; i0 < mu; i0 += CH) {
+                        double kv[CH][NE], fd[CH];
+                        int cjv[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; j++) {
+                            const bool ok = i0 + j < mu;         // (uniform)
+                            const int ij = ok ? i0 + j : i0;
+#pragma unroll
+                            for (int q = 0; q < NE; q++) kv[j][q] = Kp[(size_t)ij * ne + q * G];
+                            fd[j] = Fp ? Fp[ij] : 0.0;
+                            cjv[j] = ok ? C->cj[ij] : -1;
+                        }
+#pragma unroll
+                        for (int j = 0; j < CH; j++) {
+                            double part = 0.0;
+#pragma unroll
+                            for (int q = 0; q < NE; q++) part += kv[j][q] * dzv[q];
+                            const double s = group_sum<G>(part);
+                            double u = fd[j] - s;
+                            if (EXTRA) u += unoise;
+                            if (t == cjv[j]) uj += u;
+                        }
+                    }
+                } else {                                     // feed-forward only (OpenLoop, a host closure's inputs)
+                    for (int i = 0; i < mu; i++) {
+                        double u = Fp ? Fp[i] : 0.0;
+                        if (EXTRA) u += unoise;
+                        if (t == C->cj[i]) uj += u;
+                    }
+                }
             }
             __syncthreads();
         }
