@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 // "load, multiply-add, next entry" every entry paid its own memory round trip (6 round trips per input and lane; 25 % of a
                 // step of the seven-input Sawyer arm, 2.4 % of the headline's).  Same products, same order of summation.
                 constexpr int NE = (12 * NBP + G - 1) / G;
-                constexpr int CH = (G == 16) ? 4 : 1;       // (16 lanes = 5 .. 8 links: the multi-input arms; the others usually have one input)
+                constexpr int CH = (G == 16) ? 8 : 1;       // (16 lanes = 5 .. 8 links: the multi-input arms, all their inputs at once; the others usually have one input)
                 // No predicate lives across the loads (each would be a 64-bit lane mask in scalar registers): an entry past the end of a row is
                 // fetched all the same -- it is the next row's, or the zero padding behind the table (CCLQR_K_PAD) -- and meets a zero in dz;
                 // a lane of an instance that does not exist reads the first instance's tables, and its result is never used.
