@@ -250,19 +250,58 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
                 if (EXTRA && C->has_fric && c.has_fric()) uj = ck_friction(c, zf, za);
             }
             __syncthreads();
-            for (int i = 0; i < C->mu; i++) {
-                double part = 0.0;
-                if (C->K && c.valid()) {
-                    const double* Krow = C->K + ginst * C->K_stride + ((size_t)kidx * C->mu + i) * 12 * nb;
-                    for (int e = t; e < 12 * nb; e += G) part += Krow[e] * L[Y.DZ + e];
-                }
-                const double s = group_sum<G>(part);
-                double u = ((C->Fd && c.valid()) ? C->Fd[ginst * C->Fd_stride + (size_t)ksp * C->mu + i] : 0.0) - s;
+            {
+                // u_i = Fd_i - K_i . dz: the gain entries of a lane are all requested before the first is used, CH inputs at a time (the whole
+                // arm's on the 16-lane kernels), entries past a row's end meet a zero in dz (the tables are padded: CCLQR_K_PAD) -- the control
+                // phase of rollout_chain.hip, where the measurement and the reasons are
+                constexpr int NE = (12 * NBP + G - 1) / G;
+                constexpr int CH = (G == 16) ? 8 : 1;
+                const long long gi = c.valid() ? ginst : a.inst0;
+                const int ne = 12 * nb;
+                double unoise = 0.0;
                 if (EXTRA) {
                     const double* noise = ap->noise;
-                    if (C->noise_scale != 0.0 && c.valid() && noise) u += C->noise_scale * noise[(size_t)inst * ap->noise_stride + (k - 1)];
+                    if (C->noise_scale != 0.0 && c.valid() && noise) unoise = C->noise_scale * noise[(size_t)inst * ap->noise_stride + (k - 1)];
                 }
-                if (t == C->cj[i]) uj += u;
+                double dzv[NE];
+                int tf = t;
+                asm volatile("" : "+v"(tf));            // the entries' range tests are made here, every step -- not once per launch and kept as NE lane masks
+#pragma unroll
+                for (int q = 0; q < NE; q++) { const int e = tf + q * G; dzv[q] = (c.valid() && e < ne) ? L[Y.DZ + e] : 0.0; }
+                const int mu = C->mu;
+                const double* Fp = C->Fd ? C->Fd + gi * C->Fd_stride + (size_t)ksp * mu : nullptr;
+                if (C->K) {                                  // (uniform) LQR / TrackingLQR
+                    const double* Kp = C->K + gi * C->K_stride + (size_t)kidx * mu * ne + t;
+                    for (int i0 = 0; i0 < mu; i0 += CH) {
+                        double kv[CH][NE], fd[CH];
+                        int cjv[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; j++) {
+                            const bool ok = i0 + j < mu;         // (uniform)
+                            const int ij = ok ? i0 + j : i0;
+#pragma unroll
+                            for (int q = 0; q < NE; q++) kv[j][q] = Kp[(size_t)ij * ne + q * G];
+                            fd[j] = Fp ? Fp[ij] : 0.0;
+                            cjv[j] = ok ? C->cj[ij] : -1;
+                        }
+#pragma unroll
+                        for (int j = 0; j < CH; j++) {
+                            double part = 0.0;
+#pragma unroll
+                            for (int q = 0; q < NE; q++) part += kv[j][q] * dzv[q];
+                            const double s = group_sum<G>(part);
+                            double u = fd[j] - s;
+                            if (EXTRA) u += unoise;
+                            if (t == cjv[j]) uj += u;
+                        }
+                    }
+                } else {                                     // feed-forward only (OpenLoop, a host closure's inputs)
+                    for (int i = 0; i < mu; i++) {
+                        double u = Fp ? Fp[i] : 0.0;
+                        if (EXTRA) u += unoise;
+                        if (t == C->cj[i]) uj += u;
+                    }
+                }
             }
             __syncthreads();
         }
