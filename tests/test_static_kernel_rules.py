@@ -38,6 +38,8 @@ UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAX
            # rollout_treereg.hip: schedule lengths and the largest child count are mechanism constants (TreeRegDev), the same in every lane
            r"^int s = 0; s < (ne_steps|nb_steps)", r"^s < (ne_steps|nb_steps)", r"^int k = 0; k < maxchild",
            r"^mine != other$", r"^int i = 0; i < \d+; i\+\+$",        # (compile-time unrolled component loops)
+           # control phase (round 4): mu = C->mu inputs in chunks of the compile-time CH; the gain table's presence is a controller constant
+           r"^int i0 = 0; i0 < mu", r"^int j = 0; j < CH; j\+\+$", r"^int i = 0; i < mu",
            # rollout_loop.hip project_model_kernel: tree reductions over a fixed workgroup size, pivot steps up to the kernel argument ml, and the
            # stop on s_pi -- a __shared__ word written by thread 0 and read by everyone behind a barrier
            r"^int o = PROJ_THREADS / 2; o > 0; o >>= 1$", r"^int k = 0; k < ml", r"^s_pi < 0$",
