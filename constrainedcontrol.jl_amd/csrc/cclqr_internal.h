@@ -91,7 +91,9 @@ struct cclqr_mech {
     int link_of_joint[CCLQR_MAXL];  // user joint -> internal link (= link of its child body)
     int device;
 };
-#define CCLQR_K_PAD 64          // zero doubles behind a controller's gain table (a whole lane-group stride of the widest instantiation)
+// zero doubles behind a controller's gain table: the control phase fetches ceil(12 NBP / G) G entries of a row whatever the mechanism's own
+// 12 nb, i.e. up to 12 x 64 - 12 past the end of the LAST row when a short chain runs on a long image
+#define CCLQR_K_PAD 768
 struct cclqr_ctrl {
     cclqr::CtrlDev host;
     cclqr::CtrlDev* dev;

@@ -315,6 +315,32 @@ def test_chains_of_33_to_64_bodies(cclqr, orc):
     assert e.value.code == capi.EUNSUPPORTED
 
 
+@pytest.mark.parametrize("n_links", [4, 8, 11, 17, 24, 32])
+def test_short_chains_on_long_images_with_per_instance_gains(cclqr, orc, n_links):
+    """chains whose 12 nb gain entries do not fill the lane strides of their kernel's image (nb = 5 on the 8-link image ... nb = 33 on the 64-link
+    one): the control phase fetches whole strides -- entries past a row's end are the next row's or the zero padding behind the table
+    (CCLQR_K_PAD) and meet a zero in dz.  One gain table PER INSTANCE and a finite horizon, so that the last instance's last row ends the
+    allocation; every trajectory against the oracle"""
+    capi = cclqr._capi
+    nb = n_links + 1
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links)
+    rng = np.random.default_rng(n_links)
+    n, N, steps = 6, 9, 8
+    K = rng.normal(size=(n, N - 1, 1, 12 * nb)) * 0.02
+    phi = rng.uniform(-1, 1, (n, n_links)) * 0.1
+    phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.3, 0.3, n), phi)
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, [0], K=K, N=N, zd=np.repeat(zd[None, None], n, 0), n_ctrl=n)
+    zT, traj, st = capi.rollout(mech, ctrl, z0, steps, record=True)
+    assert (st > 0).all()
+    for i in range(n):
+        zo, traj_o, sto = orc.rollout(t, orc.ctrl_desc(nb, [0], K=K[i], N=N, zd=zd), z0[i:i + 1], steps, record=True)
+        assert (sto > 0).all() and np.abs(traj[i] - traj_o[0]).max() < 1e-9 and np.abs(zT[i] - zo[0]).max() < 1e-9, i
+
+
 def test_cfg3_as_scripted_upright_is_lost_on_both_paths(cclqr, orc):
     """configs[2] exactly as examples/lqr_cartpole_n_pendulum.jl writes it with N = 16: upright setpoint (:45), y0 ~ U(-0.5, 0.5),
     phi_i ~ U(0, 3^-16) (:21-22), Q = I, R = 1, horizon 10 s, 1000 steps (:53).  The reference's own recursion gives |K| ~ 1e11 there
