@@ -604,11 +604,22 @@ def other_configs(pkg, capi, torch, dev, count=True):
     except Exception as e:
         out["triple_cartpole_tracking_cfg5"]["step_per_launch_in_a_hip_graph"] = {"error": repr(e)}
     ctrl.close()
+    try:
+        out["triple_cartpole_tracking_cfg5"]["host_closure_controlfunction"] = _host_closure_rate(pkg, capi, torch, mech, tl, ex, np.tile(z00, (16384, 1, 1)), 100)
+    except Exception as e:
+        out["triple_cartpole_tracking_cfg5"]["host_closure_controlfunction"] = {"error": repr(e)}
     return out
 
 
-def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne):
+def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne, branches=(1, 4)):
+    """configs[4]'s "hipGraph-captured step": `steps` single-step launches (state and multipliers round-trip HBM between them, the Philox sample
+    generated inside the step kernel) captured once and replayed.  branches = 1: ONE chain of launches over the whole batch -- every step waits for
+    the slowest wavefront of the step before (the Newton iteration counts of the noise-floor line searches are heavy-tailed), which a persistent
+    launch never does.  branches = B: the batch cut into B independent sub-batches, each its own chain of single-step launches on its own captured
+    stream (parallel branches of one graph): a straggler only holds up its own sub-batch while the other chains keep the device busy.  Same
+    launches, same bits; what an MPC loop that looks at every state of a sub-batch would do."""
     n = z0.shape[0]
+    nb13 = z0.shape[1] * 13 * 8
     z0_d = torch.from_numpy(np.ascontiguousarray(z0)).to(dev)
     ref, st = torch.empty_like(z0_d), torch.zeros(n, dtype=torch.int32, device=dev)
     capi.rollout_dev(mh, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, 0, ref.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -616,41 +627,88 @@ def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne):
     failed_fused = int((st <= 0).sum().item())      # the persistent launch's status covers the whole horizon (a lost instance stays flagged)
     za, zb = z0_d.clone(), torch.empty_like(z0_d)
     lam = torch.zeros((n, 5 * ne), dtype=torch.float64, device=dev)
-    ws = torch.empty(n, dtype=torch.float64, device=dev)          # the launches' Philox samples (one step each): caller-owned, nothing grows under capture
-    graph = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    t0 = time.perf_counter()
-    with torch.cuda.stream(side):
-        graph.capture_begin()
-        src, dst = za, zb
-        for k in range(1, steps + 1):
-            capi.rollout_dev(mh, ctrl, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream,
-                             noise_ws=ws.data_ptr(), noise_ws_len=n)
-            src, dst = dst, src
-        graph.capture_end()
-    torch.cuda.current_stream().wait_stream(side)
-    capture_s = time.perf_counter() - t0
-    times = []
-    for _ in range(3):
-        za.copy_(z0_d)
-        lam.zero_()
-        torch.cuda.synchronize()
+    res = {}
+    for B in branches:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        subs = [torch.cuda.Stream() for _ in range(B)] if B > 1 else [side]
+        per = (n + B - 1) // B
+        side.wait_stream(torch.cuda.current_stream())
         t0 = time.perf_counter()
-        graph.replay()
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    dt = min(times[1:])
-    # The captured launches all write the same status buffer, so what is left there only speaks for the LAST step, and the freeze of a lost
-    # instance is not carried from launch to launch.  A rate is therefore claimed only when the persistent launch of the same
-    # horizon lost nobody AND the graph's final state equals its final state bit for bit -- then no step of the graph can have failed either.
-    same = bool(torch.equal(src, ref))
-    ok = same and failed_fused == 0
-    return {"instances": n, "sim_steps": steps, "record": False, "value": (n * steps / dt) if ok else None, "unit": "instance-steps/s", "ms_per_rollout": 1e3 * dt,
-            "attempted_instance_steps_per_s": n * steps / dt,
-            "graph_nodes": "%d launches of one step (+ %d Philox fills)" % (steps, steps), "capture_s": capture_s,
-            "same_bits_as_one_persistent_launch": same, "failed_instances_of_the_persistent_launch_of_the_same_horizon": failed_fused,
-            "failed_instances_last_step": int((st <= 0).sum().item())}
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            for b in range(B):
+                lo, cnt = b * per, min(per, n - b * per)
+                if cnt <= 0:
+                    continue
+                if B > 1:
+                    subs[b].wait_stream(side)
+                src, dst = za, zb
+                for k in range(1, steps + 1):
+                    capi.rollout_dev(mh, ctrl, cnt, 1, k, src.data_ptr() + lo * nb13, lam.data_ptr() + lo * 5 * ne * 8, 0, 0, 0, dst.data_ptr() + lo * nb13,
+                                     st.data_ptr() + lo * 4, subs[b].cuda_stream, first_instance=lo, flags=capi.ROLLOUT_NO_ALLOC)
+                    src, dst = dst, src
+            if B > 1:
+                for b in range(B):
+                    side.wait_stream(subs[b])
+            graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        capture_s = time.perf_counter() - t0
+        times = []
+        for _ in range(3):
+            za.copy_(z0_d)
+            lam.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        dt = min(times[1:])
+        # The captured launches all write the same status buffer, so what is left there only speaks for the LAST step, and the freeze of a lost
+        # instance is not carried from launch to launch.  A rate is therefore claimed only when the persistent launch of the same
+        # horizon lost nobody AND the graph's final state equals its final state bit for bit -- then no step of the graph can have failed either.
+        same = bool(torch.equal(src, ref))
+        ok = same and failed_fused == 0
+        res[B] = {"value": (n * steps / dt) if ok else None, "ms_per_rollout": 1e3 * dt, "attempted_instance_steps_per_s": n * steps / dt, "capture_s": capture_s,
+                  "graph_nodes": "%d chain(s) x %d launches of one step (Philox samples generated in the step kernel: no fill launches)" % (B, steps),
+                  "same_bits_as_one_persistent_launch": same, "failed_instances_last_step": int((st <= 0).sum().item())}
+        del graph
+    best = max(res, key=lambda b: res[b]["attempted_instance_steps_per_s"])
+    out = {"instances": n, "sim_steps": steps, "record": False, "unit": "instance-steps/s", "failed_instances_of_the_persistent_launch_of_the_same_horizon": failed_fused}
+    out.update(res[best])
+    out["independent_chains_in_the_graph"] = best
+    out["by_independent_chains"] = {str(b): res[b] for b in res}
+    return out
+
+
+def _host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps):
+    """the `controlfunction` hook (lqr.jl:14, :56; examples/trackingLQR_triple_cartpole.jl:93-117) on the same workload: the script's law as a HOST
+    closure -- control_trackinglqr! + friction on every joint -- stepped one launch per step, states to the host and inputs back every step
+    (lqr.py::_simulate_hosted).  No noise: the closure owns the law, and a host RNG stream is not the device's."""
+    import copy
+    fric = np.asarray(ex["fric"], dtype=np.float64)
+    t = mech.tables()
+    parent, child = np.asarray(t.parent), np.asarray(t.child)
+
+    def law(batch, ctrl, k):
+        pkg.control_lqr(batch, ctrl, k)
+        for j, e in enumerate(mech.eqconstraints):      # viscous friction -fric * relative joint velocity (the script's :99-101)
+            if fric[j] == 0.0:
+                continue
+            if int(t.type[j]) == 1:
+                rel = batch.v[:, child[j], 1] - (batch.v[:, parent[j], 1] if parent[j] >= 0 else 0.0)
+            else:
+                rel = batch.ω[:, child[j], 0] - (batch.ω[:, parent[j], 0] if parent[j] >= 0 else 0.0)
+            batch.u[j] = batch.u.get(j, np.zeros(batch.n_inst)) - fric[j] * rel
+    tc = copy.copy(tl)
+    tc.controlfunction = law
+    t0 = time.perf_counter()
+    st = pkg.simulate(mech, steps * mech.Δt, tc, record=False, z0=z0)
+    dt = time.perf_counter() - t0
+    ok = bool((st.status > 0).all())
+    return {"instances": int(z0.shape[0]), "sim_steps": steps, "value": (z0.shape[0] * steps / dt) if ok else None, "unit": "instance-steps/s", "s_per_run": dt,
+            "what": "host closure controlfunction(batch, controller, k) = control_trackinglqr! + joint friction in numpy, one launch per step, states D2H and inputs H2D "
+                    "every step through cclqr_ctrl_set_feedforward (PCIe and host arithmetic inside the time)"}
 
 
 def build_native_oracle():

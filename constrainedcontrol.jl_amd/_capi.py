@@ -16,8 +16,11 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_host_ex", "cclqr_ctrl_reserve_noise", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex",
-           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward"]
-ABI_VERSION = 200     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header
+           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout"]
+ABI_VERSION = 201     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header (verified field by field against cclqr_abi_layout at load time)
+ROLLOUT_NO_ALLOC = 1  # cclqr_rollout_opts.flags: the call may neither allocate nor synchronise (a hipGraph capture is open on the device)
+PHILOX_INKERNEL_STEPS = 8
+NEWTON_MAXIT = 100      # newtonIter of ConstrainedDynamics' newton!: |status| of an instance that hit the cap
 
 
 class CclqrError(RuntimeError):
@@ -45,11 +48,20 @@ class RiccatiOpts(C.Structure):
 
 class RolloutOpts(C.Structure):
     _fields_ = [("first_instance", C.c_int64), ("pid_state_dev", C.c_void_p), ("pid_state_len", C.c_int64),
-                ("noise_ws_dev", C.c_void_p), ("noise_ws_len", C.c_int64), ("newton_mode", C.c_int32), ("reserved", C.c_int32),
+                ("noise_ws_dev", C.c_void_p), ("noise_ws_len", C.c_int64), ("newton_mode", C.c_int32), ("flags", C.c_int32),
                 ("newton_eps_alone", C.c_double)]
 
 
 _lib = None
+
+
+def mirrored_layout():
+    """sizeof / offsetof of the four ctypes mirrors in the order cclqr_abi_layout reports the library's own (include/cclqr.h)"""
+    out = []
+    for S in (MechDesc, CtrlDesc, RiccatiOpts, RolloutOpts):
+        out.append(C.sizeof(S))
+        out += [getattr(S, name).offset for name, _ in S._fields_]
+    return out
 
 
 def _preload_shared_hip_runtime():
@@ -81,10 +93,19 @@ def lib():
         _preload_shared_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.cclqr_last_error.restype = C.c_char_p
-        for name in EXPORTS[1:]:
-            getattr(L, name).restype = C.c_int   # a missing export raises here: the library must implement all of include/cclqr.h
-        if L.cclqr_version() != ABI_VERSION:
+        L.cclqr_version.restype = C.c_int
+        if L.cclqr_version() != ABI_VERSION:      # before any other symbol is touched: an older library lacks the newer exports
             raise ImportError("libcclqr.so has ABI version %d, this binding was written for %d: rebuild the library" % (L.cclqr_version(), ABI_VERSION))
+        for name in EXPORTS[1:]:
+            try:
+                getattr(L, name).restype = C.c_int
+            except AttributeError:
+                raise ImportError("libcclqr.so (ABI version %d) does not export %s, which include/cclqr.h declares: rebuild the library" % (L.cclqr_version(), name))
+        want = mirrored_layout()
+        got = (C.c_int32 * len(want))()
+        n = L.cclqr_abi_layout(got, C.c_int32(len(want)))
+        if n != len(want) or list(got) != want:
+            raise ImportError("struct layout mismatch between libcclqr.so and this binding (cclqr_abi_layout: %s, ctypes mirrors: %s)" % (list(got), want))
         _lib = L
     return _lib
 
@@ -255,17 +276,18 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instanc
 
 
 def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise_stride, traj_ptr, zT_ptr, status_ptr, stream=0,
-                first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0, newton_eps_alone=0.0):
+                first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0, newton_eps_alone=0.0, flags=0):
     """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
     Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][joints][2] doubles, noise_ws / noise_ws_len = caller's
-    Philox workspace, newton_mode; none given: cclqr_rollout_dev (= NULL options)"""
+    Philox workspace, newton_mode, flags (ROLLOUT_NO_ALLOC: what a caller with a hipGraph capture open passes); none given: cclqr_rollout_dev
+    (= NULL options)"""
     vp = lambda p: C.c_void_p(int(p)) if p else None
-    if first_instance is None and pid_state is None and noise_ws is None and not newton_mode:
+    if first_instance is None and pid_state is None and noise_ws is None and not newton_mode and not flags:
         check(lib().cclqr_rollout_dev(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                       vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), vp(stream)))
         return
     o = RolloutOpts(int(first_instance or 0), int(pid_state) if pid_state else None, n_inst * mech.tables.ne * 2 if pid_state else 0,       # one pair per joint (a tree has nb joints, a loop mechanism more)
-                    int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), 0, float(newton_eps_alone))
+                    int(noise_ws) if noise_ws else None, int(noise_ws_len) if noise_ws else 0, int(newton_mode), int(flags), float(newton_eps_alone))
     check(lib().cclqr_rollout_ex(mech.ptr, ctrl.ptr, C.c_int64(n_inst), C.c_int32(steps), C.c_int32(k0), vp(z0_ptr), vp(lam_ptr),
                                  vp(noise_ptr), C.c_int64(noise_stride), vp(traj_ptr), vp(zT_ptr), vp(status_ptr), C.byref(o), vp(stream)))
 

@@ -78,6 +78,26 @@ static int check_device(const cclqr_mech* m) {
     return CCLQR_OK;
 }
 extern "C" int cclqr_version(void) { return CCLQR_ABI_VERSION; }
+// sizeof / offsetof of the structs of include/cclqr.h as compiled here (the order is the header's comment): a foreign-language mirror checks itself against it
+extern "C" int cclqr_abi_layout(int32_t* out, int32_t n) {
+#define OFF(T, f) (int32_t) offsetof(T, f)
+    const int32_t v[CCLQR_ABI_LAYOUT_LEN] = {
+        (int32_t)sizeof(cclqr_mech_desc), OFF(cclqr_mech_desc, nb), OFF(cclqr_mech_desc, ne), OFF(cclqr_mech_desc, dt), OFF(cclqr_mech_desc, g), OFF(cclqr_mech_desc, mass),
+        OFF(cclqr_mech_desc, inertia), OFF(cclqr_mech_desc, parent), OFF(cclqr_mech_desc, child), OFF(cclqr_mech_desc, type), OFF(cclqr_mech_desc, p1), OFF(cclqr_mech_desc, p2),
+        OFF(cclqr_mech_desc, axis), OFF(cclqr_mech_desc, qoff),
+        (int32_t)sizeof(cclqr_ctrl_desc), OFF(cclqr_ctrl_desc, mu), OFF(cclqr_ctrl_desc, ctrl_joint), OFF(cclqr_ctrl_desc, nK), OFF(cclqr_ctrl_desc, N), OFF(cclqr_ctrl_desc, K),
+        OFF(cclqr_ctrl_desc, nsp), OFF(cclqr_ctrl_desc, zd), OFF(cclqr_ctrl_desc, Fd), OFF(cclqr_ctrl_desc, fric), OFF(cclqr_ctrl_desc, noise_scale), OFF(cclqr_ctrl_desc, npid),
+        OFF(cclqr_ctrl_desc, pid_joint), OFF(cclqr_ctrl_desc, pid_P), OFF(cclqr_ctrl_desc, pid_I), OFF(cclqr_ctrl_desc, pid_D), OFF(cclqr_ctrl_desc, pid_goal),
+        OFF(cclqr_ctrl_desc, noise_philox), OFF(cclqr_ctrl_desc, noise_seed), OFF(cclqr_ctrl_desc, n_ctrl),
+        (int32_t)sizeof(cclqr_riccati_opts), OFF(cclqr_riccati_opts, path), OFF(cclqr_riccati_opts, bf16_terms), OFF(cclqr_riccati_opts, keep_last), OFF(cclqr_riccati_opts, reserved),
+        (int32_t)sizeof(cclqr_rollout_opts), OFF(cclqr_rollout_opts, first_instance), OFF(cclqr_rollout_opts, pid_state_dev), OFF(cclqr_rollout_opts, pid_state_len),
+        OFF(cclqr_rollout_opts, noise_ws_dev), OFF(cclqr_rollout_opts, noise_ws_len), OFF(cclqr_rollout_opts, newton_mode), OFF(cclqr_rollout_opts, flags),
+        OFF(cclqr_rollout_opts, newton_eps_alone)};
+#undef OFF
+    if (n < 0 || (n > 0 && !out)) return fail(CCLQR_EINVAL, "bad argument");
+    for (int i = 0; i < n && i < CCLQR_ABI_LAYOUT_LEN; i++) out[i] = v[i];
+    return CCLQR_ABI_LAYOUT_LEN;
+}
 extern "C" int cclqr_device_count(int32_t* n) {
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -116,6 +136,16 @@ extern "C" int cclqr_mech_destroy(cclqr_mech* m) {
     return CCLQR_OK;
 }
 
+// doubles the rollout kernels' control phase fetches past the end of a gain row: they read ceil(12 NBP / G) G entries of a row (G lanes per instance,
+// the LDS image laid out for NBP >= nb links) and let the surplus meet a zero factor.  Closed-loop kernel: exact row length.
+static size_t gain_row_overrun(const cclqr_mech* m) {
+    if (m->host.loop) return 0;
+    const int G = m->host.tree ? treereg_lanes(m->nb, m->host.tree) : chain_lanes_per_instance(m->nb);
+    const int nbp = m->host.tree ? treereg_layout_links(m->nb, m->host.tree) : chain_layout_links(m->nb);
+    const long long over = (long long)((12 * nbp + G - 1) / G) * G - 12LL * m->nb;
+    return over > 0 ? (size_t)((over + 1) & ~1LL) : 0;
+}
+
 extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, cclqr_ctrl** out) {
     if (!m || !d || !out) return fail(CCLQR_EINVAL, "null argument");
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
@@ -132,9 +162,14 @@ extern "C" int cclqr_ctrl_create(const cclqr_mech* m, const cclqr_ctrl_desc* d, 
     if (e == hipSuccess && !T.K.empty()) {
         // CCLQR_K_PAD zero doubles behind the last gain row: the rollout kernels fetch a row in whole strides of their lane group and let the
         // entries past its end meet a zero factor (rollout_chain.hip, control phase) -- past the LAST row that read must stay inside the table
-        e = hipMalloc((void**)&c->K_dev, (T.K.size() + CCLQR_K_PAD) * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(c->K_dev + T.K.size(), 0, CCLQR_K_PAD * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpy(c->K_dev, T.K.data(), T.K.size() * sizeof(double), hipMemcpyHostToDevice);
+        // (one table per instance: each with its own pad, see CCLQR_K_PAD)
+        const size_t ntab = T.H.n_ctrl > 1 ? (size_t)T.H.n_ctrl : 1, per = T.K.size() / ntab, padi = ntab > 1 ? gain_row_overrun(m) : 0;
+        const size_t total = ntab * (per + padi) + CCLQR_K_PAD;
+        e = hipMalloc((void**)&c->K_dev, total * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(c->K_dev, 0, total * sizeof(double));
+        if (e == hipSuccess) e = padi ? hipMemcpy2D(c->K_dev, (per + padi) * sizeof(double), T.K.data(), per * sizeof(double), per * sizeof(double), ntab, hipMemcpyHostToDevice)
+                                      : hipMemcpy(c->K_dev, T.K.data(), T.K.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (ntab > 1) T.H.K_stride = (long long)(per + padi);
     }
     if (e == hipSuccess && !T.Fd.empty()) {
         e = hipMalloc((void**)&c->Fd_dev, T.Fd.size() * sizeof(double));
@@ -167,11 +202,11 @@ extern "C" int cclqr_ctrl_set_feedforward(cclqr_ctrl* c, const double* Fd, int64
 
 // in-place permutation of the 12-column body blocks of every gain row from the caller's body order to the kernels' link order
 // (one workgroup per row, the row staged in LDS); what build_ctrl_tables does on the host for caller-supplied gains
-__global__ void k_rows_to_link_order_kernel(double* K, long long nrows, int nb, const MechDev* M) {
+__global__ void k_rows_to_link_order_kernel(double* K, long long nrows, long long rows_per_table, long long table_stride, int nb, const MechDev* M) {
     extern __shared__ double row[];
     const long long r = blockIdx.x;
     if (r >= nrows) return;
-    double* p = K + r * 12 * nb;
+    double* p = K + (r / rows_per_table) * table_stride + (r % rows_per_table) * 12 * nb;
     for (int e = threadIdx.x; e < 12 * nb; e += blockDim.x) row[e] = p[e];
     __syncthreads();
     for (int e = threadIdx.x; e < 12 * nb; e += blockDim.x) { const int l = e / 12; p[e] = row[12 * M->perm[l] + (e - 12 * l)]; }
@@ -204,14 +239,16 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
         la.cj[i] = m->link_of_joint[ctrl_joint[i]];
         H.cj[i] = la.cj[i];
     }
-    H.K_stride = n_ctrl > 1 ? (long long)nKtab * mu * (long long)mx : 0;
+    const size_t padi = n_ctrl > 1 ? gain_row_overrun(m) : 0;       // every instance's table ends in its own zero pad (CCLQR_K_PAD)
+    const long long tab_stride = (long long)nKtab * mu * (long long)mx + (long long)padi;
+    H.K_stride = n_ctrl > 1 ? tab_stride : 0;
     H.zd_stride = n_ctrl > 1 ? (long long)nz : 0;
     H.Fd_stride = (n_ctrl > 1 && Fd) ? mu : 0;
     // setpoints in link order for the rollout's control law
     std::vector<double> zl(np * nz);
     for (size_t s = 0; s < np; s++)
         for (int l = 0; l < nb; l++) memcpy(&zl[(s * nb + l) * 13], zd + (s * nb + m->host.perm[l]) * 13, 13 * sizeof(double));
-    const size_t nK = np * nKtab * mu * mx;
+    const size_t nK = np * (size_t)tab_stride;
     double *dzd = nullptr, *dA = nullptr, *dBu = nullptr, *dBl = nullptr, *dG = nullptr, *dQ = nullptr, *dR = nullptr, *dwork = nullptr;
     int *dlst = nullptr, *dkb = nullptr, *dst = nullptr, *dstop = nullptr;
     std::vector<int> lst(np), kb(np), st(np);
@@ -236,7 +273,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     if (e == hipSuccess) e = launch_linearize(la, nb, m->host.tree, m->host.npairs, nullptr);
     // dlqr for every setpoint (lqr.jl:141-184), gains written straight into the controller's table
     RicArgs ra;
-    ra.nprob = n_ctrl; ra.mx = (int)mx; ra.mu = mu; ra.ml = (int)ml; ra.N = N; ra.time_varying = 0; ra.tol = tol; ra.path = 0; ra.bf16_terms = 0; ra.keep_last = inf ? 1 : 0;
+    ra.nprob = n_ctrl; ra.mx = (int)mx; ra.mu = mu; ra.ml = (int)ml; ra.N = N; ra.time_varying = 0; ra.tol = tol; ra.path = 0; ra.bf16_terms = 0; ra.keep_last = inf ? 1 : 0; ra.kpad = (long long)padi;
     const size_t wd = ric_total_work_doubles(ra);
     if (e == hipSuccess) e = ws_get((void**)&dQ, mx * mx * sizeof(double));
     if (e == hipSuccess) e = ws_get((void**)&dR, (size_t)(mu * mu + 1) * sizeof(double));
@@ -251,7 +288,7 @@ extern "C" int cclqr_ctrl_create_lqr_batch(const cclqr_mech* m, int32_t n_ctrl, 
     if (e == hipSuccess) e = launch_riccati(ra, nullptr);
     if (e == hipSuccess) {
         const long long nrows = (long long)np * (long long)nKtab * mu;
-        hipLaunchKernelGGL(k_rows_to_link_order_kernel, dim3((unsigned)nrows), dim3(128), mx * sizeof(double), nullptr, c->K_dev, nrows, nb, m->dev);
+        hipLaunchKernelGGL(k_rows_to_link_order_kernel, dim3((unsigned)nrows), dim3(128), mx * sizeof(double), nullptr, c->K_dev, nrows, (long long)nKtab * mu, tab_stride, nb, m->dev);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -298,8 +335,8 @@ extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32
         if (lds_bytes) *lds_bytes = (int32_t)treereg_lds_bytes(m->nb, m->host.tree, m->host.npairs);
         return CCLQR_OK;
     }
-    if (lanes) *lanes = rollout_lanes_per_instance(m->nb, m->host.tree);
-    if (lds_bytes) *lds_bytes = (int32_t)rollout_lds_bytes(m->nb, m->host.tree, m->host.npairs);
+    if (lanes) *lanes = chain_lanes_per_instance(m->nb);
+    if (lds_bytes) *lds_bytes = (int32_t)chain_lds_bytes(m->nb);
     return CCLQR_OK;
 }
 
@@ -311,7 +348,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     if (n_inst < 0 || steps < 0 || k0 < 1) return fail(CCLQR_EINVAL, "bad sizes");
     if (c->nb != m->nb) return fail(CCLQR_EINVAL, "controller was built for another mechanism");
     { int rc = check_device(m); if (rc != CCLQR_OK) return rc; }
-    if (!m->host.loop && (m->host.tree ? treereg_lds_bytes(m->nb, m->host.tree, m->host.npairs) : rollout_lds_bytes(m->nb, 0, 0)) > 160 * 1024)
+    if (!m->host.loop && (m->host.tree ? treereg_lds_bytes(m->nb, m->host.tree, m->host.npairs) : chain_lds_bytes(m->nb)) > 160 * 1024)
         return fail(CCLQR_EUNSUPPORTED, "instance does not fit LDS");
     const int64_t first = opts ? opts->first_instance : 0;
     if (first < 0) return fail(CCLQR_EINVAL, "negative first_instance");
@@ -325,7 +362,15 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     // which only ever grows OUTSIDE stream capture: hipMalloc / hipFree are illegal while a stream is being captured, so a captured
     // launch needs the workspace sized beforehand (cclqr_ctrl_reserve_noise) or passed in.
     const bool use_noise = H.noise_scale != 0.0 && H.mu > 0;
+    if (opts && (opts->flags & ~CCLQR_ROLLOUT_NO_ALLOC)) return fail(CCLQR_EINVAL, "unknown bit in cclqr_rollout_opts.flags");
+    const bool no_alloc = opts && (opts->flags & CCLQR_ROLLOUT_NO_ALLOC);
+    // launches of a few steps on forests of chains (the step-per-launch form a hipGraph replays, BASELINE configs[4]) generate their samples inside the
+    // rollout kernel (rollout_chain_kernel<.., 3>): one kernel per step instead of two, and no workspace that could have to grow
+    bool philox_in_kernel = false;
     if (use_noise && !noise && H.noise_philox && steps > 0) {
+        if (!m->host.loop && !m->host.tree && !H.has_pid && steps <= CCLQR_PHILOX_INKERNEL_STEPS && !(opts && opts->noise_ws_dev)) philox_in_kernel = true;
+    }
+    if (use_noise && !noise && H.noise_philox && steps > 0 && !philox_in_kernel) {
         const size_t need = (size_t)n_inst * steps;
         double* ws = nullptr;
         if (opts && opts->noise_ws_dev) {
@@ -334,6 +379,11 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
         } else {
             cclqr_ctrl* cm = const_cast<cclqr_ctrl*>(c);
             if (cm->noise_ws_cap < need) {
+                // growing = a device synchronisation + an allocation.  A caller who has said CCLQR_ROLLOUT_NO_ALLOC (anybody with a capture open on
+                // this device, on whichever stream) is refused outright; without the flag the library can only see a capture of `stream` itself
+                if (no_alloc)
+                    return fail(CCLQR_EINVAL, "CCLQR_ROLLOUT_NO_ALLOC: the Philox noise workspace of this controller holds " + std::to_string(cm->noise_ws_cap) + " samples, the launch needs " +
+                                              std::to_string(need) + ": call cclqr_ctrl_reserve_noise(ctrl, n_inst, steps) beforehand or pass cclqr_rollout_opts.noise_ws_dev");
                 hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
                 if (stream) HIPCHK(hipStreamIsCapturing((hipStream_t)stream, &cap));
                 if (cap != hipStreamCaptureStatusNone)
@@ -348,7 +398,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
         noise = ws - (k0 - 1);      // indexed by the absolute step k-1
         noise_stride = steps;
     }
-    const int extra = H.has_pid ? 2 : ((H.has_fric || (use_noise && noise)) ? 1 : 0);
+    const int extra = H.has_pid ? 2 : (philox_in_kernel ? 3 : ((H.has_fric || (use_noise && noise)) ? 1 : 0));
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
@@ -360,9 +410,9 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
         return CCLQR_OK;
     }
     if (newton_mode != 0 && extra != 0)
-        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists under the plain LQR / TrackingLQR law only (trees and closed-loop mechanisms)");
+        return fail(CCLQR_EUNSUPPORTED, "newton_mode 1 exists under the plain LQR / TrackingLQR law only on chains and branching trees (closed-loop mechanisms: every law)");
     if (m->host.tree) HIPCHK(launch_rollout_treereg(a, m->nb, m->host.tree, m->host.npairs, extra, newton_mode, (hipStream_t)stream));
-    else HIPCHK(launch_rollout(a, m->nb, 0, 0, extra, newton_mode, (hipStream_t)stream));
+    else HIPCHK(launch_rollout_chain(a, m->nb, extra, newton_mode, (hipStream_t)stream));
     return CCLQR_OK;
 }
 

@@ -30,9 +30,6 @@ struct RolloutArgs {
 // far and only calls the runtime when a launch needs more (capi.hip)
 hipError_t set_max_dynamic_lds_once(const void* fn, size_t lds);
 
-int rollout_lanes_per_instance(int nb, int tree);
-size_t rollout_lds_bytes(int nb, int tree, int npairs);
-hipError_t launch_rollout(const RolloutArgs& a, int nb, int tree, int npairs, int extra, int newton_mode, hipStream_t stream);
 hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long long n_inst, int k0, int steps, hipStream_t stream);
 // forests of chains (rollout_chain.hip)
 int chain_lanes_per_instance(int nb);
@@ -75,6 +72,7 @@ struct RicArgs {
     int path;                // 0: chosen by problem size and count, 1 resident, 2 tiled
     int bf16_terms;          // 0: fp64 MFMA; 1..3: split-bf16 products with fp32 accumulation (tiled path)
     int keep_last;           // 1: K is [nprob][mu][mx], the gain of the last executed backward step (= Ku[1] after the back-fill)
+    long long kpad = 0;      // doubles left free between the tables of consecutive problems in K (0: contiguous)
 };
 size_t ric_total_work_doubles(const RicArgs& a);
 hipError_t launch_riccati(const RicArgs& a, hipStream_t stream);
@@ -92,7 +90,10 @@ struct cclqr_mech {
     int device;
 };
 // zero doubles behind a controller's gain table: the control phase fetches ceil(12 NBP / G) G entries of a row whatever the mechanism's own
-// 12 nb, i.e. up to 12 x 64 - 12 past the end of the LAST row when a short chain runs on a long image
+// 12 nb, i.e. up to 12 x 64 - 12 past the end of the LAST row when a short chain runs on a long image.  With one table per instance (n_ctrl > 1)
+// every instance's table carries its own zero pad of that overrun (capi.hip gain_row_overrun, CtrlDev::K_stride includes it), so that the entries
+// past an instance's last row are zeros and never a NEIGHBOUR's gains -- which may be Inf / NaN when that neighbour's recursion diverged, and
+// 0 * NaN would poison a healthy instance's input
 #define CCLQR_K_PAD 768
 struct cclqr_ctrl {
     cclqr::CtrlDev host;

@@ -203,6 +203,7 @@ struct RicGrid {
     const double *A, *Bu, *Bl, *G, *Q, *R;
     double *AD, *W, *Abar, *P, *Ku, *KRK, *part, *TSp, *scratch, *K;
     int *stop, *kbreak, *status;
+    long long kpad;    // doubles between the gain tables of consecutive problems in K (per-instance controller tables: capi.hip gain_row_overrun)
     int keep_last;     // 1: only the gain of the last executed backward step is kept (K [nprob][mu][mx] = Ku[1] after the back-fill of
                        // lqr.jl:179-181 = the one gain LQR{T,Inf} keeps, lqr.jl:40-43); 0: the whole table K [nprob][N-1][mu][mx]
     int bf16_terms;    // 0: fp64 MFMA (parity mode); 1..3: the two mx^3 products of a backward step on bf16 MFMA with fp32 accumulation,
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(TILE_THREADS) void ric_gain_update_kernel(RicGrid a
     if (sing) { if (lead && tid == 0) { a.status[prob] = CCLQR_ESINGULAR_; a.stop[prob] = 1; a.kbreak[prob] = k; } return; }
     double* Ku = a.Ku + (size_t)prob * mu * mx;
     double* KRK = a.KRK + (size_t)prob * mu * mx;
-    double* Kout = a.K + (a.keep_last ? (size_t)prob : ((size_t)prob * (a.N - 1) + (k - 1))) * mu * mx;
+    double* Kout = a.K + (a.keep_last ? (size_t)prob : ((size_t)prob * (a.N - 1) + (k - 1))) * mu * mx + (size_t)prob * a.kpad;
     for (int j = tid; j < mx; j += TILE_THREADS) {
         for (int c = 0; c < mu; c++) { const int p = piv[c]; if (p != c) { double t = TS[(size_t)c * na + j]; TS[(size_t)c * na + j] = TS[(size_t)p * na + j]; TS[(size_t)p * na + j] = t; } }
         for (int i = 1; i < mu; i++) { double sacc = TS[(size_t)i * na + j]; for (int r = 0; r < i; r++) sacc -= S[i * mu + r] * TS[(size_t)r * na + j]; TS[(size_t)i * na + j] = sacc; }
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
     int* piv = (int*)(rl + ((size_t)mx * mx + (size_t)mx * na + (size_t)mx * mu + 2 * (size_t)mu * mx + (size_t)mu * na + 2 * (size_t)mu * mu + 2 * RIC_WAVES + 2 +
                             (NGT > 0 ? (size_t)RIC_WAVES * RIC_YB : 0)));
     static_assert(NGT == 0 || (MUT >= 1 && MUT <= 8), "the register-fragment form keeps Y = Abar' W_D of a row strip as 16 x 8 doubles");
-    double* Kout = a.K + (size_t)prob * (a.keep_last ? 1 : (N > 1 ? N - 1 : 0)) * mu * mx;
+    double* Kout = a.K + (size_t)prob * ((size_t)(a.keep_last ? 1 : (N > 1 ? N - 1 : 0)) * mu * mx + a.kpad);
     if (tid == 0) sing = 0;
     for (int e = tid; e < mx * mx; e += RIC_THREADS) P[e] = a.Q[e];       // Pk = Q                                  lqr.jl:147
     for (int e = tid; e < mu * mu; e += RIC_THREADS) Rl[e] = a.R[e];
@@ -801,6 +802,22 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
 #pragma unroll
             for (int g = 0; g < NGF; g++) frag[g] = col >= 0 ? ADk[(size_t)(4 * g + lk) * na + cjc] : 0.0;
         }
+    };
+    // The END-of-step fetch may only touch what is the wavefront's own: the fp64 register-fragment form has no barrier between the update phase
+    // (which reads D's LDS copy) and the Pkp1 tiles, so a fast wavefront must not overwrite Dl while a slow one still reads the step's D.  The
+    // fragment goes to registers at once; the next D -- it only changes for time-varying problems (nlin > 1: TrackingLQR) -- waits in registers
+    // (ND per thread) and is stored behind the norm's barrier.
+    constexpr bool FRAG64 = NGT > 0 && BF == 0;
+    constexpr int ND = FRAG64 ? (4 * NGT * (MUT > 0 ? MUT : 1) + RIC_THREADS - 1) / RIC_THREADS : 1;
+    double dnext[ND];
+    auto fetch_next = [&](int kk) {
+        const double* ADk = a.AD + ((size_t)prob * a.nlin + (a.nlin > 1 ? kk - 1 : 0)) * mx * na;
+        if (a.nlin > 1) {
+#pragma unroll
+            for (int u = 0; u < ND; u++) { const int e = tid + u * RIC_THREADS; dnext[u] = e < mx * mu ? ADk[(size_t)(e / mu) * na + mx + e % mu] : 0.0; }
+        }
+#pragma unroll
+        for (int g = 0; g < NGF; g++) frag[g] = col >= 0 ? ADk[(size_t)(4 * g + lk) * na + cjc] : 0.0;
     };
     if (N - 1 >= 1 && BF == 0) fetch_operands(N - 1);
     for (k = N - 1; k >= 1; k--) {                                        // for outer k=N-1:-1:1                    lqr.jl:150
@@ -1074,10 +1091,17 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
         }
-        if (k > 1 && BF == 0) fetch_operands(k - 1);      // (D's LDS copy was last read by the update phase, the fragment by the tiles above)
+        if (k > 1 && BF == 0) {
+            if (FRAG64) fetch_next(k - 1);         // (the fragment was last read by this wavefront's tiles above; D waits in registers)
+            else fetch_operands(k - 1);            // (streaming form: a barrier separates the update phase, D's last reader, from the tiles)
+        }
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_xor(nacc, o, 64);
         if (lane == 0) red[wave] = nacc;
         __syncthreads();
+        if (FRAG64 && k > 1 && a.nlin > 1) {       // every wavefront is past its update phase: the next knot's D may land (visible behind the next barrier)
+#pragma unroll
+            for (int u = 0; u < ND; u++) { const int e = tid + u * RIC_THREADS; if (e < mx * mu) Dl[e] = dnext[u]; }
+        }
         double tot = 0.0;
         for (int q = 0; q < RIC_WAVES; q++) tot += red[q];
         __syncthreads();
@@ -1114,7 +1138,7 @@ __global__ void ric_backfill_kernel(RicGrid a) {
     }
     __syncthreads();
     if (a.status[prob] != 0 || a.keep_last) return;
-    double* Kout = a.K + (size_t)prob * (N > 1 ? N - 1 : 0) * mu * mx;
+    double* Kout = a.K + (size_t)prob * ((size_t)(N > 1 ? N - 1 : 0) * mu * mx + a.kpad);
     for (int k2 = kb - 1; k2 >= 1; k2--) {
         for (int e = tid; e < mu * mx; e += blockDim.x) Kout[(size_t)(k2 - 1) * mu * mx + e] = Kout[(size_t)k2 * mu * mx + e];
         __syncthreads();
@@ -1188,7 +1212,7 @@ hipError_t launch_riccati(const RicArgs& a, hipStream_t stream) {
     RicGrid g;
     ric_pp_assign((a.mx + 15) / 16, (a.mx + a.mu + 15) / 16, g.pp_mask);
     g.nprob = a.nprob; g.mx = a.mx; g.mu = a.mu; g.ml = a.ml; g.N = a.N; g.nlin = a.time_varying ? (a.N > 1 ? a.N - 1 : 1) : 1;
-    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms; g.keep_last = a.keep_last;
+    g.na = a.mx + a.mu; g.tm = (a.mx + 31) / 32; g.tn = (g.na + 31) / 32; g.tol = a.tol; g.bf16_terms = a.bf16_terms; g.keep_last = a.keep_last; g.kpad = a.kpad;
     g.A = a.A; g.Bu = a.Bu; g.Bl = a.Bl; g.G = a.G; g.Q = a.Q; g.R = a.R; g.K = a.K; g.kbreak = a.kbreak; g.status = a.status; g.stop = a.stop;
     const size_t np = a.nprob, nlin = g.nlin, mx = a.mx, na = g.na, mu = a.mu, ml = a.ml;
     double* o = a.work;

@@ -179,12 +179,16 @@ __device__ __forceinline__ double lane_fetch(double v, int addr) {
 // Counter-based noise (noise_philox): the samples of a launch are generated by this kernel into a workspace and the rollout
 // reads them like an injected array -- sqrt/log/cos inside the persistent kernel cost it ~20 scalar registers of polynomial
 // constants for its whole lifetime.  sample (instance n, step k) = Box-Muller of Philox-4x32-10 keyed by the GLOBAL instance index.
+// Short launches (the step-per-launch / hipGraph form of BASELINE configs[4], cclqr.h CCLQR_PHILOX_INKERNEL_STEPS) generate the sample inside the
+// rollout kernel instead (EXTRA = 3): no fill launch in front of every step, no workspace.  ONE compiled body serves both (not inlined), so
+// that a sample has the same bits wherever it is generated.
+__device__ __attribute__((noinline)) double philox_normal_dev(unsigned key0, unsigned long long instance, int k) { return philox_normal(key0, instance, k); }
 __global__ __launch_bounds__(256) void philox_fill_kernel(double* out, unsigned key0, long long inst0, long long n_inst, int k0, int steps) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_inst * steps) return;
     const long long n = i / steps;
     const int kk = (int)(i - n * steps);
-    out[i] = philox_normal(key0, (unsigned long long)(inst0 + n), k0 + kk);
+    out[i] = philox_normal_dev(key0, (unsigned long long)(inst0 + n), k0 + kk);
 }
 hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long long n_inst, int k0, int steps, hipStream_t stream) {
     const long long total = n_inst * steps;
@@ -196,7 +200,8 @@ hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long 
 // NBP: links the LDS image is laid out for (>= nb): a compile-time layout turns every LDS offset into an immediate instead
 // of a live scalar register and index arithmetic.
 // EXTRA: 0 = plain LQR / TrackingLQR feedback; 1 = + joint friction and noise (examples/trackingLQR_triple_cartpole.jl:93-111);
-// 2 = + the PID law of src/control/pid.jl.  The plain instantiations carry none of that code (nor its registers).
+// 2 = + the PID law of src/control/pid.jl; 3 = 1 with the noise sample of (instance, step) generated HERE (Philox, philox_normal_dev) instead of read
+// from an array: the launches of a few steps that a hipGraph replays.  The plain instantiations carry none of that code (nor its registers).
 // RELAX: the measured-error Newton mode of cclqr_rollout_opts.newton_mode = 1 -- a solve also stops on ||f|| < eps_alone, whatever the step.  A template
 // parameter (plain law only), not a launch argument: the exact-rule kernels sit at 486-502 of 512 registers and any extra live value
 // moves them across the line (a scalar mode flag read in the accept phase cost the 17-link instantiations 2 VGPR spills).
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     for (int i = 0; i < 7; i++) S.z[i] = c.live() ? a.z0[inst * nz + ut * 13 + i] : ((i == 3) ? 1.0 : 0.0);
 #pragma unroll
     for (int i = 0; i < 6; i++) S.s[i] = c.live() ? a.z0[inst * nz + ut * 13 + 7 + i] : 0.0;
-    if (EXTRA >= 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + t) * 2]; pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
+    if (EXTRA == 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + t) * 2]; pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) { S.cd[i] = 0.0; S.d[i] = 0.0; S.ds[i] = 0.0; }
     for (int e = t; e < Y.total; e += G) L[e] = 0.0;
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 const long long gi = c.valid() ? ginst : a.inst0;
                 const int ne = 12 * nb;
                 double unoise = 0.0;                    // noise: injected by the caller, or generated for this launch by philox_fill_kernel
-                if (EXTRA) {
+                if (EXTRA == 3) {
+                    if (C->noise_scale != 0.0) unoise = C->noise_scale * philox_normal_dev(C->noise_key0, (unsigned long long)gi, k);
+                } else if (EXTRA) {
                     const double* noise = ap->noise;
                     if (C->noise_scale != 0.0 && c.valid() && noise) unoise = C->noise_scale * noise[(size_t)inst * ap->noise_stride + (k - 1)];
                 }
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             }
             __syncthreads();
         }
-        if (EXTRA >= 2 && C->has_pid) {
+        if (EXTRA == 2 && C->has_pid) {
             if (c.live() && C->pid_on[t]) uj += ck_pid(c, zf, za, C->pid_P[t], C->pid_I[t], C->pid_D[t], C->pid_goal[t], dt, k == 1, pid_int, pid_last);
         }
         STAMP(PF_CONTROL);
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
 #pragma unroll
             for (int i = 0; i < 5; i++) lam[inst * 5 * nbT + 5 * t + i] = L[Y.LAM + 5 * t + i];
         }
-        if (EXTRA >= 2) {
+        if (EXTRA == 2) {
             double* pid_state = ap->pid_state;
             if (pid_state) { pid_state[(inst * nbT + t) * 2] = pid_int; pid_state[(inst * nbT + t) * 2 + 1] = pid_last; }
         }
@@ -683,13 +690,15 @@ template <int G, int NBP>
 static hipError_t launch_chain_one(const RolloutArgs& a, int extra, int newton_mode, unsigned grid, size_t lds, hipStream_t stream) {
     const bool relax = newton_mode != 0 && extra == 0;
     const void* f = relax ? (const void*)rollout_chain_kernel<G, NBP, 0, true>
-                          : (extra == 0 ? (const void*)rollout_chain_kernel<G, NBP, 0> : (extra == 1 ? (const void*)rollout_chain_kernel<G, NBP, 1> : (const void*)rollout_chain_kernel<G, NBP, 2>));
+                          : (extra == 0 ? (const void*)rollout_chain_kernel<G, NBP, 0> : (extra == 1 ? (const void*)rollout_chain_kernel<G, NBP, 1>
+                          : (extra == 2 ? (const void*)rollout_chain_kernel<G, NBP, 2> : (const void*)rollout_chain_kernel<G, NBP, 3>)));
     hipError_t e = set_max_dynamic_lds_once(f, lds);
     if (e != hipSuccess) return e;
     if (relax) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0, true>), dim3(grid), dim3(64), lds, stream, a);
     else if (extra == 0) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0>), dim3(grid), dim3(64), lds, stream, a);
     else if (extra == 1) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 1>), dim3(grid), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 2>), dim3(grid), dim3(64), lds, stream, a);
+    else if (extra == 2) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 2>), dim3(grid), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 3>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -338,10 +338,15 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     st = torch.zeros(n, dtype=torch.int32, device=td)
     traj = np.zeros((n, steps if record else 0, nb, 13))
     worst, bad = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=bool)
+    # an instance whose step ended on a non-finite residual is LOST: the fused rollout freezes it at its last pose, at rest, for the rest of
+    # the horizon (rollout_chain.hip, LinkC::DEAD).  A launch per step forgets that flag between launches, so it is carried here: a lost
+    # instance's frozen state is written back after every later launch (the closure still sees it, as it sees the frozen pose in the fused run)
+    dead = torch.zeros(n, dtype=torch.bool, device=td)
+    zdead = torch.zeros_like(z)
     stream = torch.cuda.current_stream().cuda_stream
     try:
         for k in range(1, steps + 1):
-            zh = z.cpu().numpy()
+            zh = z.cpu().numpy()      # (synchronises the stream: the previous launch no longer reads the feed-forward table set_feedforward rewrites below)
             if record:
                 traj[:, k - 1] = zh
             batch = BatchState(mechanism, zh, k)
@@ -355,8 +360,16 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
             _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
             z, zn = zn, z
             s = st.cpu().numpy()
-            bad |= s <= 0
-            worst = np.maximum(worst, np.abs(s))
+            was_dead = dead.cpu().numpy()
+            live = ~was_dead                                                                  # (a lost instance is not stepped any more: its status stands)
+            lost = torch.from_numpy(live & (s <= 0) & (np.abs(s) < _capi.NEWTON_MAXIT)).to(td)      # stopped early = left the integrator's domain
+            if was_dead.any():
+                z[dead] = zdead[dead]
+            if bool(lost.any()):
+                zdead[lost] = z[lost]
+                dead |= lost
+            bad |= live & (s <= 0)
+            worst = np.where(live, np.maximum(worst, np.abs(s)), worst)
     finally:
         ctrl.close()
     zT = z.cpu().numpy()

@@ -7,6 +7,7 @@
  *   gcc -O2 -I include examples/c_abi_cartpole.c -o c_abi_cartpole -L constrainedcontrol.jl_amd -lcclqr -lm */
 #include "cclqr.h"
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,7 +19,23 @@ static void box_inertia(double x, double y, double z, double m, double *J) {
     J[0] = m / 12.0 * (y * y + z * z); J[4] = m / 12.0 * (x * x + z * z); J[8] = m / 12.0 * (x * x + y * y);
 }
 
+/* what a foreign-language shim does at load time (julia/CCLQR.jl check_abi): the library's own view of the structs against the caller's */
+static int check_abi(void) {
+    int32_t lay[CCLQR_ABI_LAYOUT_LEN];
+    if (cclqr_version() != CCLQR_ABI_VERSION) { fprintf(stderr, "ABI version %d, header %d\n", cclqr_version(), CCLQR_ABI_VERSION); return 1; }
+    if (cclqr_abi_layout(lay, CCLQR_ABI_LAYOUT_LEN) != CCLQR_ABI_LAYOUT_LEN) return 1;
+    const int32_t mine[] = {(int32_t)sizeof(cclqr_mech_desc), (int32_t)offsetof(cclqr_mech_desc, qoff), (int32_t)sizeof(cclqr_ctrl_desc), (int32_t)offsetof(cclqr_ctrl_desc, n_ctrl),
+                            (int32_t)sizeof(cclqr_riccati_opts), (int32_t)sizeof(cclqr_rollout_opts), (int32_t)offsetof(cclqr_rollout_opts, flags)};
+    const int at[] = {0, 13, 14, 33, 34, 39, 46};
+    for (int i = 0; i < 7; i++)
+        if (lay[at[i]] != mine[i]) { fprintf(stderr, "layout entry %d: library %d, caller %d\n", at[i], lay[at[i]], mine[i]); return 1; }
+    printf("abi %d layout ok\n", cclqr_version());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (check_abi()) return 1;
+    if (argc > 1 && !strcmp(argv[1], "--abi")) return 0;      /* (no GPU needed up to here) */
     const int n_inst = argc > 1 ? atoi(argv[1]) : 4, steps = 1000, nb = 2, mx = 24, ml = 10, mu = 1, N = 1000;
     const double dt = 0.01;
     double mass[2] = {0.5, 1.0}, inertia[18];

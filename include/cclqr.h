@@ -31,8 +31,11 @@ extern "C" {
 
 /* ABI version = cclqr_version().  A shim built against another header must refuse to run: the structs below are passed by pointer and
  * read in full.  200: cclqr_ctrl_desc.n_ctrl, cclqr_rollout_opts {noise_ws_dev, noise_ws_len, newton_mode}, cclqr_riccati_opts.keep_last,
- * the thread-local setters (cclqr_set_instance_offset, cclqr_set_pid_state, cclqr_riccati_path) removed. */
-#define CCLQR_ABI_VERSION 200
+ * the thread-local setters (cclqr_set_instance_offset, cclqr_set_pid_state, cclqr_riccati_path) removed.
+ * 201 (additive over 200: same struct sizes and offsets): cclqr_rollout_opts.reserved became `flags` (CCLQR_ROLLOUT_NO_ALLOC), new entry points
+ * cclqr_ctrl_set_feedforward and cclqr_abi_layout.  A shim checks cclqr_version() == the version it was written against AND, through
+ * cclqr_abi_layout(), the sizeof / offsetof of every struct it mirrors. */
+#define CCLQR_ABI_VERSION 201
 
 #define CCLQR_REVOLUTE 0      /* EqualityConstraint(Revolute(a, b, axis; p1, p2, qoffset)),  examples/lqr_cartpole.jl:26 */
 #define CCLQR_PRISMATIC 1     /* EqualityConstraint(Prismatic(a, b, axis; p1, p2, qoffset)), examples/lqr_cartpole.jl:25 */
@@ -94,6 +97,18 @@ typedef struct cclqr_ctrl cclqr_ctrl; /* opaque: device-resident controller tabl
 
 const char *cclqr_last_error(void);
 int cclqr_version(void);     /* CCLQR_ABI_VERSION of the library that was loaded */
+/* sizeof and offsetof of the four structs that cross this boundary, as THIS library was compiled, so that a foreign-language mirror (the
+ * Julia structs of julia/CCLQR.jl, the ctypes Structures of _capi.py -- the reference has no FFI of its own: INTEGRATION.md) can verify its layout
+ * at load time instead of trusting a version number.  out[0..n) receives, in this order (CCLQR_ABI_LAYOUT_LEN values):
+ *   cclqr_mech_desc:    sizeof, offsetof nb, ne, dt, g, mass, inertia, parent, child, type, p1, p2, axis, qoff                       (14)
+ *   cclqr_ctrl_desc:    sizeof, offsetof mu, ctrl_joint, nK, N, K, nsp, zd, Fd, fric, noise_scale, npid, pid_joint, pid_P, pid_I, pid_D,
+ *                       pid_goal, noise_philox, noise_seed, n_ctrl                                                                   (20)
+ *   cclqr_riccati_opts: sizeof, offsetof path, bf16_terms, keep_last, reserved                                                       (5)
+ *   cclqr_rollout_opts: sizeof, offsetof first_instance, pid_state_dev, pid_state_len, noise_ws_dev, noise_ws_len, newton_mode, flags,
+ *                       newton_eps_alone                                                                                             (9)
+ * Returns the number of values the library has (48), writes min(n, 48) of them; out may be NULL with n = 0. */
+#define CCLQR_ABI_LAYOUT_LEN 48
+int cclqr_abi_layout(int32_t *out, int32_t n);
 int cclqr_device_count(int32_t *n);
 int cclqr_set_device(int32_t dev);
 
@@ -214,14 +229,23 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *                   injected noise array).  NULL: the controller handle's own workspace is used -- ONE buffer per handle, so two
  *                   launches that share a controller on different streams or host threads must each bring their own here, and
  *                   the handle's buffer cannot grow while `stream` is being captured into a hipGraph (CCLQR_EINVAL: size it first
- *                   with cclqr_ctrl_reserve_noise);
+ *                   with cclqr_ctrl_reserve_noise).  Launches of at most CCLQR_PHILOX_INKERNEL_STEPS steps (the step-per-launch / hipGraph
+ *                   form of BASELINE configs[4]) on forests of chains generate their samples INSIDE the rollout kernel and touch no
+ *                   workspace at all;
  *   noise_ws_len    doubles in that workspace (checked against n_inst * steps);
  *   newton_mode     0 = the reference's stopping rule, ||f|| < eps AND ||step taken|| < eps (the PARITY mode).
  *                   1 = measured-error mode: a Newton solve ALSO stops as soon as ||f|| < newton_eps_alone, whatever the step size.
  *                   Saves the iterations the exact rule spends halving steps on round-off noise; the state deviation from mode 0
- *                   is reported, not promised.  Forests of chains under the plain LQR / TrackingLQR law, and
- *                   closed-loop mechanisms (CCLQR_EUNSUPPORTED on branching trees and with the friction / noise / PID laws on chains);
+ *                   is reported, not promised.  Forests of chains and branching trees under the plain LQR / TrackingLQR
+ *                   law (CCLQR_EUNSUPPORTED with the friction / noise / PID laws there), closed-loop mechanisms under every law;
+ *   flags           CCLQR_ROLLOUT_NO_ALLOC: the call must neither allocate nor synchronise -- what a caller who is capturing ANY stream of the
+ *                   device into a hipGraph needs (a hipMalloc / hipDeviceSynchronize during a global-mode capture invalidates it, whichever
+ *                   stream it is issued on).  A launch that would have to grow the handle's Philox workspace is then refused with
+ *                   CCLQR_EINVAL (the message names cclqr_ctrl_reserve_noise) before anything is touched, whether or not `stream` itself is
+ *                   capturing; without the flag the library still refuses on a capturing `stream` (it can see that one) and grows otherwise;
  *   newton_eps_alone  threshold of mode 1 (<= 0: 1e-10, the rule's own eps: stop on the residual alone). */
+#define CCLQR_ROLLOUT_NO_ALLOC 1
+#define CCLQR_PHILOX_INKERNEL_STEPS 8
 typedef struct {
     int64_t first_instance;
     double *pid_state_dev;
@@ -229,7 +253,7 @@ typedef struct {
     double *noise_ws_dev;
     int64_t noise_ws_len;
     int32_t newton_mode;
-    int32_t reserved;
+    int32_t flags;
     double newton_eps_alone;
 } cclqr_rollout_opts;
 
@@ -247,7 +271,8 @@ int cclqr_rollout_host_ex(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_in
  * Call it before capturing step-per-launch rollouts of a noise_philox controller into a hipGraph (BASELINE configs[4]), from a thread that is on
  * the controller's device (CCLQR_EINVAL otherwise), and never while ANY stream of that device is being captured in the global capture mode (the
  * re-allocation is a device synchronisation plus an allocation, which such a capture does not survive; a launch on the capturing stream itself
- * that would have to grow the workspace is refused with CCLQR_EINVAL before anything is touched: cclqr_rollout_ex). */
+ * that would have to grow the workspace is refused with CCLQR_EINVAL before anything is touched, and so is ANY launch that carries
+ * CCLQR_ROLLOUT_NO_ALLOC in cclqr_rollout_opts.flags: cclqr_rollout_ex). */
 int cclqr_ctrl_reserve_noise(cclqr_ctrl *c, int64_t n_inst, int32_t steps);
 
 /* The `controlfunction` hook of the reference's controllers (src/control/lqr.jl:14, :56; lqr_tracking.jl:19; pid.jl:16 -- a Julia closure
@@ -255,13 +280,16 @@ int cclqr_ctrl_reserve_noise(cclqr_ctrl *c, int64_t n_inst, int32_t steps);
  * with the closure on the HOST and the batch on the device: the caller steps the rollout one launch per step (k0 continuation of
  * cclqr_rollout_dev), reads the states, lets its closure compute every instance's joint inputs and hands them over here; the next launch applies
  * them as feed-forward inputs.  Fd: [n_ctrl][nsp][mu] doubles exactly as given to cclqr_ctrl_create (len is checked against that), a HOST
- * pointer (on_device = 0: copied synchronously) or a DEVICE pointer (on_device = 1: copied on `stream`, ordered with the launches on it).
+ * pointer (on_device = 0: copied synchronously on the null stream -- the caller must have synchronised every NON-BLOCKING stream on which a launch
+ * that reads this controller may still be running, e.g. by reading that launch's states back, as the closure loop does) or a DEVICE pointer
+ * (on_device = 1: copied on `stream`, ordered with the launches on it).
  * The controller must have been created with a feed-forward table (Fd != NULL). */
 int cclqr_ctrl_set_feedforward(cclqr_ctrl *c, const double *Fd, int64_t len, int32_t on_device, void *stream);
 
 /* kernel launch geometry chosen for a mechanism (for roofline bookkeeping in bench.py; no counterpart in the reference's simulate!,
  * examples/lqr_cartpole.jl:44): lanes per instance and LDS bytes per workgroup; links the chain kernel's LDS image is laid out for
- * (names the instantiation rollout_chain_kernel<lanes, links, law>; 0 when the mechanism takes the tree or the closed-loop kernel) */
+ * (names the instantiation rollout_chain_kernel<lanes, links, law> for forests of chains and rollout_treereg_kernel<lanes, links, law, relax>
+ * for branching trees; 0 for closed-loop mechanisms, whose one kernel takes its layout at run time) */
 int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);
 int cclqr_rollout_layout_links(const cclqr_mech *m, int32_t *links);
 

@@ -42,9 +42,10 @@ struct RolloutOpts         # cclqr_rollout_opts
     noise_ws_dev::Ptr{Float64}
     noise_ws_len::Int64
     newton_mode::Int32
-    reserved::Int32
+    flags::Int32               # ROLLOUT_NO_ALLOC: the call may neither allocate nor synchronise (a hipGraph capture is open on the device)
     newton_eps_alone::Float64
 end
+const ROLLOUT_NO_ALLOC = Int32(1)
 
 struct RiccatiOpts         # cclqr_riccati_opts
     path::Int32
@@ -53,11 +54,18 @@ struct RiccatiOpts         # cclqr_riccati_opts
     reserved::Int32
 end
 
-const ABI_VERSION = 200    # include/cclqr.h CCLQR_ABI_VERSION: the structs above mirror THAT header field by field
-"call once after loading: a library built from another header would read these structs past their end (ADVICE r2)"
+const ABI_VERSION = 201    # include/cclqr.h CCLQR_ABI_VERSION: the structs above mirror THAT header field by field
+"sizeof / fieldoffset of the four mirrors above in the order cclqr_abi_layout reports the library's own (include/cclqr.h)"
+mirrored_layout() = Int32[x for S in (MechDesc, CtrlDesc, RiccatiOpts, RolloutOpts) for x in (sizeof(S), (fieldoffset(S, i) for i in 1:fieldcount(S))...)]
+"call once after loading: a library built from another header would read these structs past their end (ADVICE r2).  The version number says which
+header the library was built from; cclqr_abi_layout says what the C compiler made of it, so the mirrors are verified field by field (VERDICT r4)."
 function check_abi()
     v = ccall((:cclqr_version, lib), Cint, ())
     v == ABI_VERSION || error("libcclqr.so has ABI version $v, CCLQR.jl was written for $ABI_VERSION")
+    want = mirrored_layout()
+    got = zeros(Int32, length(want))
+    n = ccall((:cclqr_abi_layout, lib), Cint, (Ptr{Int32}, Int32), got, Int32(length(got)))
+    (n == length(want) && got == want) || error("struct layout mismatch: libcclqr.so reports $got, CCLQR.jl mirrors $want")
     nothing
 end
 

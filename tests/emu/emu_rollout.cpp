@@ -1,6 +1,6 @@
 // emu_rollout.cpp -- TEST INFRASTRUCTURE ONLY (never linked into libcclqr.so).
 // Runs the rollout kernel's __host__ __device__ phase functions (csrc/cclqr_dev.h) serially on the CPU with the same
-// phase order as rollout.hip, lane by lane, so that the kernel's arithmetic, LDS layout and indexing can be checked
+// phase order as the round-1 LDS-resident rollout kernel (now only linearize.hip runs these phases), lane by lane, so that the kernel's arithmetic, LDS layout and indexing can be checked
 // against the oracle without a GPU.  It is not a fallback: nothing in the product can reach it.
 #include "../../constrainedcontrol.jl_amd/csrc/cclqr_tables.h"
 #include <vector>

@@ -584,8 +584,12 @@ def test_rccl_executes_once_with_one_rank(tmp_path):
 def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
     """configs[4] as written -- the friction + noise law of trackingLQR_triple_cartpole.jl:93-111 AND a hipGraph-captured step: 20
     single-step launches with device-generated Philox noise captured into a graph == one fused 20-step launch (the samples are keyed by
-    (global instance, step), so the split does not change them), and == the oracle.  The controller's noise workspace is sized before
-    the capture (cclqr_ctrl_reserve_noise): nothing may be allocated while a stream is being captured."""
+    (global instance, step), so the split does not change them), and == the oracle.  Round 5: a launch of up to CCLQR_PHILOX_INKERNEL_STEPS
+    steps generates its samples INSIDE the rollout kernel (one graph node per step, no workspace: a fresh controller handle is captured as
+    it is), every captured launch carries CCLQR_ROLLOUT_NO_ALLOC, and a launch that WOULD have to grow the handle's workspace is refused before
+    anything synchronises or allocates -- on the capturing stream without the flag, on ANY stream with it.  The same
+    steps captured as TWO independent chains of half the batch each (parallel branches of one graph: what bench.py's pipelined form does)
+    give the same bits again."""
     import torch
     capi = cclqr._capi
     ex = cclqr.examples.triple_cartpole()
@@ -603,11 +607,16 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
     z0_d = torch.from_numpy(z0).to(dev)
     ref = torch.empty_like(z0_d)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
-    capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, ref.data_ptr(), st.data_ptr())
+    capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, ref.data_ptr(), st.data_ptr())       # 20 steps: samples from the workspace
     torch.cuda.synchronize()
     assert (st > 0).all() and float((ref[0] - ref[1]).abs().max()) > 1e-4        # the noise is there and differs per instance
-    ctrl2 = capi.CtrlHandle(mech, [0], **kw)          # a fresh handle: its workspace has never been sized by a launch
-    ctrl2.reserve_noise(n, 1)
+    ctrl2 = capi.CtrlHandle(mech, [0], **kw)          # a fresh handle: no workspace, and none is needed for single-step launches
+    NO_ALLOC = capi.ROLLOUT_NO_ALLOC
+    # (outside any capture) the flag alone refuses a launch that would have to grow the workspace: 9 steps > CCLQR_PHILOX_INKERNEL_STEPS
+    tmp = torch.empty_like(z0_d)
+    with pytest.raises(capi.CclqrError) as err:
+        capi.rollout_dev(mech, ctrl2, n, capi.PHILOX_INKERNEL_STEPS + 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, tmp.data_ptr(), st.data_ptr(), flags=NO_ALLOC)
+    assert err.value.code == capi.EINVAL and "cclqr_ctrl_reserve_noise" in str(err.value)
     za, zb = z0_d.clone(), torch.empty_like(z0_d)
     lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
     graph = torch.cuda.CUDAGraph()
@@ -617,13 +626,13 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
         graph.capture_begin()
         src, dst = za, zb
         for k in range(1, 21):
-            capi.rollout_dev(mech, ctrl2, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
+            capi.rollout_dev(mech, ctrl2, n, 1, k, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream, flags=NO_ALLOC)
             src, dst = dst, src
             if k == 10:
                 # a launch that would have to GROW the handle's workspace while its stream is being captured comes back as CCLQR_EINVAL before
                 # anything synchronises or allocates (the capture stays valid: the replays below are still bit-identical to the fused launch)
                 with pytest.raises(capi.CclqrError) as err:
-                    capi.rollout_dev(mech, ctrl2, n, 7, k + 1, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
+                    capi.rollout_dev(mech, ctrl2, n, 9, k + 1, src.data_ptr(), lam.data_ptr(), 0, 0, 0, dst.data_ptr(), st.data_ptr(), side.cuda_stream)
                 assert err.value.code == capi.EINVAL
         graph.capture_end()
     torch.cuda.current_stream().wait_stream(side)
@@ -633,14 +642,46 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(src, ref)
+    # two independent chains of half the batch each, forked and joined inside ONE capture (first_instance keys the second half's samples)
+    h = n // 2
+    nz, nl = t.nb * 13 * 8, 5 * t.ne * 8
+    graph2 = torch.cuda.CUDAGraph()
+    s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph2.capture_begin()
+        for b in range(2):
+            s2[b].wait_stream(side)
+            srcb, dstb = za, zb
+            for k in range(1, 21):
+                capi.rollout_dev(mech, ctrl2, h, 1, k, srcb.data_ptr() + b * h * nz, lam.data_ptr() + b * h * nl, 0, 0, 0, dstb.data_ptr() + b * h * nz,
+                                 st.data_ptr() + b * h * 4, s2[b].cuda_stream, first_instance=b * h, flags=NO_ALLOC)
+                srcb, dstb = dstb, srcb
+        for b in range(2):
+            side.wait_stream(s2[b])
+        graph2.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    za.copy_(z0_d)
+    lam.zero_()
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(srcb, ref)
     # caller-owned workspace (two launches sharing one controller on different streams would each bring their own)
     ws = torch.empty(n * 20, dtype=torch.float64, device=dev)
     out = torch.empty_like(z0_d)
     capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20)
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+    # ... and a single step with the caller's workspace takes the fill-kernel path: the same sample bits as the in-kernel generation
+    za.copy_(z0_d)
+    capi.rollout_dev(mech, ctrl, n, 1, 1, za.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n)
+    capi.rollout_dev(mech, ctrl, n, 1, 1, za.data_ptr(), 0, 0, 0, 0, tmp.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, tmp)
     with pytest.raises(capi.CclqrError):
         capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20 - 1)
+    with pytest.raises(capi.CclqrError):        # unknown flag bits are refused
+        capi.rollout_dev(mech, ctrl, n, 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), flags=2)
     zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0[:16], 20)
     assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
 

@@ -119,6 +119,50 @@ def test_riccati_both_paths(cclqr, orc, path):
         assert kb2 == kbo2 and _rel(K2, Ko2) < 1e-7
 
 
+def test_riccati_time_varying_on_the_register_fragment_kernel(cclqr, orc):
+    """lqr_tracking.jl:73-122 at the Sawyer's shape (mx = 84, mu = 7: `riccati_resident_kernel<7, 21, 0>`) and the triple cartpole's
+    (mx = 48, mu = 1) with D = Bu - Bλ (G Bλ)⁻¹ G Bu changing from knot to knot (poses a radian apart: ~10 % of |D| per knot, 1e6 x the tolerance): the fp64 register-fragment form has no barrier
+    between the update phase (reads the step's D from LDS) and the Pkp1 tiles, so the next knot's D must not land in LDS before every
+    wavefront has left the update phase (it is held in registers until the norm's barrier).  Several problems per launch and
+    repeated launches give the wavefronts room to drift apart; gains against the oracle's statement-by-statement recursion."""
+    import json
+    import os
+    capi = cclqr._capi
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sawyer_arm_tables.json")))
+    ex = cclqr.examples.sawyer(tab)
+    mech = ex["mech"]
+    t = mech.tables()
+    rng = np.random.default_rng(11)
+    N = 24
+    zs = []
+    for k in range(N):
+        for e in mech.eqconstraints:
+            cclqr.setJointPosition(mech, e, rng.uniform(-1.2, 1.2))       # poses a radian apart: D differs in every entry between knots
+        zs.append(mech.state())
+    zs = np.stack(zs)
+    Fd = rng.normal(size=(N, 7))
+    Q, R = np.eye(84) * 10.0, np.diag(rng.uniform(0.5, 2.0, 7)) * 0.01
+    h = capi.MechHandle(t)
+    Kto, kbto = orc.riccati_tracking(t, list(range(7)), zs, Fd, Q, R, N)
+    Dn = []
+    for k in range(N - 1):
+        A, Bu, Bl, G = orc.linearize(t, zs[k], list(range(7)), Fd[k])
+        Dn.append(Bu - Bl @ np.linalg.solve(G @ Bl, G @ Bu))
+    assert max(np.abs(Dn[k] - Dn[k + 1]).max() / np.abs(Dn[k]).max() for k in range(N - 2)) > 0.05     # the knots' D really differ
+    for rep in range(3):
+        Kt, kbt = capi.riccati_tracking(h, list(range(7)), zs, Fd, Q, R, N, path=1)
+        assert kbt == kbto and _rel(Kt, Kto) < 1e-7
+    ex3 = cclqr.examples.cartpole_n(3)
+    t3 = ex3["mech"].tables()
+    N3 = 50
+    zs3 = np.stack([cclqr.examples.cartpole_states(3, [0.02 * k], rng.uniform(-1.0, 1.0, (1, 3)))[0] for k in range(N3)])
+    Fd3 = rng.normal(size=(N3, 1))
+    h3 = capi.MechHandle(t3)
+    Kt3, kb3 = capi.riccati_tracking(h3, [0], zs3, Fd3, np.eye(48) * 0.01, np.eye(1) * 0.01, N3, path=1)
+    Kto3, kbo3 = orc.riccati_tracking(t3, [0], zs3, Fd3, np.eye(48) * 0.01, np.eye(1) * 0.01, N3)
+    assert kb3 == kbo3 and _rel(Kt3, Kto3) < 1e-7
+
+
 def test_riccati_batched(cclqr, orc):
     capi = cclqr._capi
     ex = cclqr.examples.cartpole_n(1)
@@ -491,6 +535,8 @@ def test_plain_c_program_through_the_abi(cclqr, orc, tmp_path):
     out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
+    assert lines[0] == "abi %d layout ok" % cclqr._capi.ABI_VERSION        # cclqr_abi_layout against the C compiler's own sizeof / offsetof
+    lines = lines[1:]
     kb, kmax = int(lines[0].split()[1]), float(lines[0].split()[3])
     zT = np.array([[float(v) for v in ln.split()[5:]] for ln in lines[1:]]).reshape(n, 2, 13)
     st = [int(ln.split()[3]) for ln in lines[1:]]

@@ -390,7 +390,42 @@ def test_c_example_compiles_and_links_against_the_abi(cclqr, tmp_path):
     import __graft_entry__ as graft
     if not os.path.exists(cclqr._capi.LIB_PATH):
         graft.build()
-    assert os.path.exists(_build_c_example(tmp_path))
+    exe = _build_c_example(tmp_path)
+    assert os.path.exists(exe)
+    # the part of it that needs no GPU: cclqr_version + cclqr_abi_layout against the C compiler's own sizeof / offsetof of include/cclqr.h
+    import subprocess
+    out = subprocess.run([exe, "--abi"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "abi %d layout ok" % cclqr._capi.ABI_VERSION, out.stdout + out.stderr
+
+
+def test_abi_layout_is_what_the_bindings_mirror(cclqr):
+    """cclqr_abi_layout (include/cclqr.h): the library's sizeof / offsetof of the four structs that cross the boundary equal the ctypes mirrors
+    of _capi.py field by field (checked at every load too), a deliberately wrong mirror is caught, and julia/CCLQR.jl declares the same fields in
+    the same order with the same widths (it cannot be executed here: compared as text against the ctypes mirror)"""
+    import ctypes as C
+    import re
+    capi = cclqr._capi
+    L = capi.lib()
+    want = capi.mirrored_layout()
+    got = (C.c_int32 * 64)()
+    n = L.cclqr_abi_layout(got, C.c_int32(64))
+    assert n == len(want) == 48 and list(got)[:n] == want
+    assert L.cclqr_abi_layout(None, C.c_int32(0)) == 48                    # size query
+
+    class Wrong(C.Structure):                                                # a mirror that forgot a field: size and the offsets behind it differ
+        _fields_ = [f for f in capi.RolloutOpts._fields_ if f[0] != "pid_state_len"]
+    assert C.sizeof(Wrong) != want[39] and Wrong.newton_eps_alone.offset != want[47]
+    # the Julia mirror, as text: field names and types in order
+    jl = open(os.path.join(ROOT, "julia", "CCLQR.jl")).read()
+    width = {"Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8}
+    for jname, S in (("MechDesc", capi.MechDesc), ("CtrlDesc", capi.CtrlDesc), ("RiccatiOpts", capi.RiccatiOpts), ("RolloutOpts", capi.RolloutOpts)):
+        body = re.search(r"struct %s\b.*?\n(.*?)\nend" % jname, jl, re.S).group(1)
+        body = re.sub(r"#.*", "", body)
+        fields = re.findall(r"(\w+)::(Ptr\{\w+\}|\w+)", body)
+        assert [f for f, _ in fields] == [f for f, _ in S._fields_], jname
+        for (f, ty), (_, cty) in zip(fields, S._fields_):
+            assert (8 if ty.startswith("Ptr") else width[ty]) == C.sizeof(cty), (jname, f)
+    assert "ABI_VERSION = %d" % capi.ABI_VERSION in jl and "cclqr_abi_layout" in jl
 
 
 def _kernel_resources(tmp_path, src_name, match):
@@ -413,13 +448,14 @@ def _kernel_resources(tmp_path, src_name, match):
 
 def test_chain_rollout_kernel_resources(tmp_path):
     """the register-resident chain kernel (csrc/rollout_chain.hip), every instantiation: (lanes, layout links) in
-    {(8, 4), (16, 8), (32, 16), (32, 17), (32, 32), (64, 64)} x control variant {plain LQR, + friction/noise, + PID}.  The plain-LQR instantiations
+    {(8, 4), (16, 8), (32, 16), (32, 17), (32, 32), (64, 64)} x control variant {plain LQR, + friction/noise, + PID, + friction/noise with the Philox
+    sample generated in the kernel (the step-per-launch form of configs[4], round 5)}.  The plain-LQR instantiations
     -- every BASELINE config but the friction/noise law of config 5 -- must not spill a single scalar register and must not touch
     scratch memory (VERDICT r1 item 2: the kernel must not live in the regime where a spilled pointer or mask can go wrong);
     nor does the friction/noise variant; the PID variant may spill a few scalars (atan2 constants) but no vector register to scratch either."""
     kernels = _kernel_resources(tmp_path, "rollout_chain.hip", "rollout_chain_kernel")
-    # 6 layouts x 3 control variants with the exact Newton rule + the 6 plain-law kernels of the measured-error Newton mode (RELAX)
-    assert len(kernels) == 24, sorted(kernels)
+    # 6 layouts x 4 control variants with the exact Newton rule + the 6 plain-law kernels of the measured-error Newton mode (RELAX)
+    assert len(kernels) == 30, sorted(kernels)
     assert sum("ELb1EEEv" in name for name in kernels) == 6
     for name, k in kernels.items():
         assert k["lds"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (name, k)
@@ -435,6 +471,8 @@ def test_chain_rollout_kernel_resources(tmp_path):
             assert k["vgpr"] <= (504 if "ILi32ELi1" in name else 440), (name, k)
         elif variant == 1:
             assert k["sgpr_spill"] == 0, (name, k)
+        elif variant == 3:
+            assert k["sgpr_spill"] <= 8, (name, k)      # (the call to philox_normal_dev: a few scalars saved around it, none in the 8-lane kernel configs[4] runs)
         else:
             assert k["sgpr_spill"] <= 8, (name, k)
 

@@ -24,7 +24,7 @@ CROSS = re.compile(r"\b(lane_read|from_lane\s*<|child_sum\s*<|tr_other_half|wave
 HELPER_DEF = re.compile(r"(double|void|int|v4d|unsigned long long)\s+(lane_read|from_lane|child_sum|tr_other_half|wave_from_prev|wave_from_next|from_prev|from_next|group_sum|dpp_f64|dpp_row_ror|wave_max_key|key_dpp_max|other_half)\s*\(")
 
 PER_LANE_HEADERS = ["cclqr_chain.h", "cclqr_dev.h", "cclqr_lin_dev.h", "cclqr_loop.h", "cclqr_treereg.h"]
-ORCHESTRATION = ["rollout_chain.hip", "rollout_treereg.hip", "rollout.hip", "rollout_loop.hip", "linearize.hip", "cclqr_newton.h"]
+ORCHESTRATION = ["rollout_chain.hip", "rollout_treereg.hip", "rollout_loop.hip", "linearize.hip", "cclqr_newton.h"]
 
 # wavefront-uniform conditions that may enclose a cross-lane operation (regexes on the condition text, whitespace collapsed)
 UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAXIT$", r"^lv <= LINE_MAXIT", r"^ls <= LINE_MAXIT", r"^ci < nchains$", r"^c < nchains$",
