@@ -19,6 +19,8 @@
 #include "../../constrainedcontrol.jl_amd/csrc/cclqr_tables.h"
 
 namespace cclqr {
+// (capi.hip's helper, which the included launchers of rollout_chain.hip reference; never called here)
+hipError_t set_max_dynamic_lds_once(const void* fn, size_t lds) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
 
 struct MicroArgs {
     const MechDev* M;
