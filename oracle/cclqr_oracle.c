@@ -628,6 +628,7 @@ static int newton(const mech_t *M, const double *z, double *s, double *lam, work
         (void)halvings;
 #endif
         if (normf1 < NEWTON_EPS && nd < NEWTON_EPS) return it;
+        if (g_newton_variant == 2 && normf1 < NEWTON_EPS) return it;      /* MODEL of a residual-only stopping rule (the device's newton_mode = 1 at 1e-10) */
         normf0 = normf1;
     }
     return -NEWTON_MAXIT;

@@ -123,7 +123,9 @@ void orc_flops_reset(void);
 void orc_newton_stats(double *out64, int reset);
 /* residual at the start of every Newton iteration, binned (instrumented build only; layout at the definition) */
 void orc_newton_hist(double *out96, int reset);
-/* 0 (default) = the reference's rule; 1 = MODEL of the device's frozen-Jacobian iterations once ||f|| < eps (not a parity mode) */
+/* 0 (default) = the reference's rule, ||f|| < eps AND ||step taken|| < eps; 1 = MODEL of the device's frozen-Jacobian iterations once ||f|| < eps (not a
+ * parity mode); 2 = MODEL of a residual-only rule, ||f|| < eps alone (what tests/test_reference_fixtures.py compares the reference's Newton iteration counts
+ * with, next to rule 0, to say which of the two the un-vendored dependency follows) */
 void orc_set_newton_variant(int v);
 
 #ifdef __cplusplus

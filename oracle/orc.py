@@ -247,7 +247,7 @@ def newton_hist(reset=True):
 
 
 def set_newton_variant(v, flops=False):
-    """0 = the reference's rule (default); 1 = MODEL of the device's frozen-Jacobian iterations (not a parity mode)"""
+    """0 = the reference's rule (default); 1 = MODEL of the device's frozen-Jacobian iterations (not a parity mode); 2 = MODEL of a residual-only stopping rule"""
     lib(flops).orc_set_newton_variant(C.c_int(v))
 
 

@@ -11,6 +11,11 @@ k in {1, 2, 10, 100, last}.  This file consumes whatever is there:
   * the Storage-knot question of DESIGN.md 2 (lqr_tracking.jl:32-35 reads `storage.x[i][k]`): the rollout is compared under three readings --
     A: storage[k] is the state the controller sees at step k (what this repository records), B: one step later, C: positions one knot earlier than
     the velocities -- and the test says which one the reference follows;
+  * the STOPPING RULE of the dependency's newton! (round 5; SURVEY 8a-bis 'Tolerances' is recollection, and 45 % of the rollout kernel's cycles are
+    iterations that only serve the step-size half of it): `newton_iters` = the iterations the reference took in each of the first 20 controlled steps,
+    compared with the oracle's counts under its rule (||f|| < ε AND ||step taken|| < ε) and under a residual-only rule (||f|| < ε alone = the device's
+    `newton_mode = 1`); the test names the rule the reference follows and fails if it is not the one this repository treats as parity.
+    `newton_defaults` (ε, newtonIter, lineIter as newton! declares them) must be 1e-10, 100, 10; `versions` is printed;
   * on the HIP path (gpu): the same rollout and gains through the C-ABI.
 
 With no fixture present every test but the consumer's self-test is skipped.  The self-test writes a fixture in the exporter's format (Fortran-order
@@ -113,6 +118,55 @@ def knot_readings(traj, z_after_last, ref, ks):
     return err
 
 
+def newton_counts(orc, t, ctrl, z0, nsteps, rule):
+    """Newton iterations of each of the first nsteps controlled steps on the oracle under stopping rule `rule` (orc.set_newton_variant: 0 = both
+    tests, the parity rule; 2 = the residual alone)"""
+    orc.set_newton_variant(rule)
+    try:
+        z, lam, out = np.array(z0, dtype=np.float64), np.zeros(5 * t.ne), []
+        for k in range(1, nsteps + 1):
+            z, lam, it = orc.step(t, z, lam, orc.control(t, ctrl, z, k))
+            out.append(int(it))
+    finally:
+        orc.set_newton_variant(0)
+    return out
+
+
+def which_newton_rule(orc, t, ctrl, z0, ref_counts):
+    """-> (name of the rule whose counts are the reference's, report).  At the residual's round-off floor one noise-level decision can move a count
+    by one, so a rule "is" the reference's when at least 90 % of the steps agree exactly and no step differs by more than one iteration."""
+    ref = [int(c) for c in ref_counts]
+    rep = {"reference": ref}
+    verdict = []
+    for rule, label in ((0, "both tests: ||f|| < eps AND ||step taken|| < eps (the parity rule, newton_mode 0)"), (2, "the residual alone: ||f|| < eps (newton_mode 1 at 1e-10)")):
+        got = newton_counts(orc, t, ctrl, z0, len(ref), rule)
+        diff = [abs(a - b) for a, b in zip(got, ref)]
+        rep["rule_%d" % rule] = got
+        if sum(d == 0 for d in diff) >= 0.9 * len(ref) and max(diff) <= 1:
+            verdict.append(label)
+    rep["follows"] = verdict[0] if len(verdict) == 1 else ("undecided: both rules give these counts" if verdict else "neither rule")
+    return rep["follows"], rep
+
+
+def check_newton_facts(orc, fx, t, ctrl):
+    """what the exporter recorded about newton! itself: declared defaults, package versions, and the stopping rule by its iteration counts"""
+    rep = {}
+    if "versions" in fx:
+        v = np.asarray(fx["versions"]).astype(int).reshape(-1, 3)
+        rep["versions"] = {n: ".".join(str(int(x)) for x in row) for n, row in zip(("ConstrainedDynamics", "ConstrainedControl", "StaticArrays", "julia"), v)}
+    if "newton_defaults" in fx:
+        d = np.asarray(fx["newton_defaults"], dtype=np.float64).reshape(-1)
+        rep["newton_defaults"] = [float(x) for x in d]
+        for got, want, what in zip(d, (1e-10, 100.0, 10.0), ("eps", "newtonIter", "lineIter")):
+            assert np.isnan(got) or got == want, "newton!'s default %s is %g in the reference, %g here (cclqr_newton.h NEWTON_EPS / NEWTON_MAXIT / LINE_MAXIT)" % (what, got, want)
+    if "newton_iters" in fx:
+        rule, r = which_newton_rule(orc, t, ctrl, fx["z0"], fx["newton_iters"])
+        rep["newton_rule"] = r
+        assert rule.startswith("both tests") or rule.startswith("undecided"), (
+            "the reference's newton! follows %s: the parity mode of cclqr_rollout_opts.newton_mode is the wrong one (counts %r)" % (rule, r))
+    return rep
+
+
 def check_lqr_fixture(cclqr, orc, fx, name, rollout=None):
     """everything an LQR fixture (configs 1-4) pins; `rollout(t, ctrl_joints, K, N, zd, Fd, z0, steps) -> (traj, zT, status)` defaults to the oracle"""
     ex, z0_ours = _registry(cclqr)[name]()
@@ -165,6 +219,8 @@ def check_lqr_fixture(cclqr, orc, fx, name, rollout=None):
     assert rep["knot_readings"][best] < TOL_STATE, "no reading of the Storage knot reproduces the reference: %r" % rep["knot_readings"]
     assert best == "A", ("the reference's Storage holds another knot than this repository records (reading %s matches, DESIGN.md 2): "
                          "TrackingLQR setpoints are off by one step until lqr.py::Storage follows it -- %r" % (best, rep["knot_readings"]))
+    # 5. newton! itself: declared tolerances, versions, and WHICH stopping rule its iteration counts follow
+    rep.update(check_newton_facts(orc, fx, t, orc.ctrl_desc(nb, cj, K=Kr, N=N, zd=zd, Fd=Fd)))
     return rep
 
 
@@ -192,6 +248,7 @@ def check_tracking_fixture(cclqr, orc, fx, rollout_open=None):
     zT, traj, st = orc.rollout(t, oc, fx["z0"][None], len(U), record=True)
     rep["tracked_knot_readings"] = knot_readings(traj[0], zT[0], _storage(fx), ks)
     assert rep["tracked_knot_readings"]["A"] < 1e-6, rep
+    rep.update(check_newton_facts(orc, fx, t, oc))
     return rep
 
 
@@ -271,7 +328,11 @@ def test_consumer_on_a_fixture_written_from_the_oracle(cclqr, orc, tmp_path, mon
     ks = [1, 2, 10, 100, 1000]
     d = tmp_path / ("ref_" + name)
     d.mkdir()
+    octrl = orc.ctrl_desc(nb, [0], K=K, N=N, zd=zd)
+    iters_both, iters_res = newton_counts(orc, t, octrl, z0, 20, 0), newton_counts(orc, t, octrl, z0, 20, 2)
+    assert iters_both != iters_res and all(a >= b for a, b in zip(iters_both, iters_res))       # the step-size half of the rule costs iterations
     arrays = dict(z0=z0, dt=[t.dt], g=[t.g], A=A, Bu=Bu, Bl=Bl @ S_, G=T_ @ G, K_all=K, K_distinct_from=[kb], Q=Q, R=R, N=[N], zd=zd, Fd=[0.0],
+                  newton_iters=iters_both, newton_defaults=[1e-10, 100.0, 10.0], versions=[[0, 9, 5], [0, 3, 0], [1, 5, 0], [1, 8, 5]],
                   ctrl_joint_ids=[nb + 1], body_ids=list(range(1, nb + 1)), k_list=ks,
                   storage_x=traj[0][[k - 1 for k in ks]][:, :, 0:3], storage_q=-traj[0][[k - 1 for k in ks]][:, :, 3:7],      # (-q: the same orientation)
                   storage_v=traj[0][[k - 1 for k in ks]][:, :, 7:10], storage_w=traj[0][[k - 1 for k in ks]][:, :, 10:13])
@@ -283,6 +344,23 @@ def test_consumer_on_a_fixture_written_from_the_oracle(cclqr, orc, tmp_path, mon
     r = rep["knot_readings"]
     assert r["A"] == 0.0 and r["B"] > 1e-4 and r["C"] > 1e-4, r
     assert rep["gains_on_reference_matrices"] < 1e-12 and rep["A_projected"] < 1e-12
+    # the stopping rule: counts written under the parity rule are recognised as such, with the versions and declared tolerances reported ...
+    assert rep["newton_rule"]["follows"].startswith("both tests") and rep["newton_rule"]["rule_0"] == iters_both
+    assert rep["versions"]["ConstrainedDynamics"] == "0.9.5" and rep["newton_defaults"] == [1e-10, 100.0, 10.0]
+    # ... counts of a reference that stopped on the residual alone are told apart and FAIL (the parity mode would then be the wrong one) ...
+    res_only = dict(fx)
+    res_only["newton_iters"] = np.array(iters_res)
+    with pytest.raises(AssertionError, match="the residual alone"):
+        check_lqr_fixture(cclqr, orc, res_only, name)
+    # ... as does another tolerance, and counts that fit neither rule
+    other_eps = dict(fx)
+    other_eps["newton_defaults"] = np.array([1e-8, 100.0, 10.0])
+    with pytest.raises(AssertionError, match="default eps"):
+        check_lqr_fixture(cclqr, orc, other_eps, name)
+    neither = dict(fx)
+    neither["newton_iters"] = np.array(iters_both) + 3
+    with pytest.raises(AssertionError, match="neither rule"):
+        check_lqr_fixture(cclqr, orc, neither, name)
     # a fixture recorded one step later must be reported as reading B, not pass
     later = dict(fx)
     full = np.concatenate([traj[0], zT], axis=0)

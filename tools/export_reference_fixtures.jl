@@ -17,12 +17,20 @@
 #     (config 5) U[1000], storage0_* of the open-loop swing-up, K_all of the TrackingLQR, storage_* of the run under the PACKAGE's law
 #                                      control_trackinglqr! (lqr_tracking.jl:46-71): the script's own law adds friction and randn() noise,
 #                                      which cannot be reproduced; the friction / noise option of this repository is checked against its oracle
+#     newton_iters[20]                 Newton iterations the dependency's newton! takes in each of the first 20 controlled steps (round 5: the one
+#                                      recollected rule that costs 45 % of the rollout kernel -- does a solve stop on ||f|| < Îµ AND ||Î”s|| < Îµ, or on the
+#                                      residual alone?).  Measured without touching the solver's internals: the mechanism is deep-copied inside the control
+#                                      callback of every step (after the law has set its forces), and the copy is solved with newtonIter = 1, 2, ... until the
+#                                      solution equals the one of the default call bit for bit -- a converged newton! returns early, so that is its count
+#     newton_defaults[3]               Îµ, newtonIter, lineIter of newton! as its method declares them (NaN where the declaration could not be read)
+#     versions[4][3]                   major, minor, patch of ConstrainedDynamics, ConstrainedControl, StaticArrays, Julia
 #
 # tests/test_reference_fixtures.py consumes these directories when they exist (on the CPU oracle and on the HIP path) and answers, the moment a
 # file appears: do the gains agree, does the linear model agree, does the integrator agree, and WHICH KNOT does Storage record (DESIGN.md 2).
 using ConstrainedDynamics
 using ConstrainedControl
 using LinearAlgebra
+import Pkg
 
 const OUT = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
 
@@ -64,6 +72,84 @@ end
 distinct_from(K) = begin k = 1; while k < length(K) && K[k] === K[k+1]; k += 1; end; k end          # the converged gain is aliased: lqr.jl:179-181
 sample_ks(n) = unique(filter(k -> k <= n, [1, 2, 10, 100, n]))
 
+# ---------------------------------------------------------------- the stopping rule of the dependency's newton!, by observation
+const NEWTON_STEPS = 20
+# the solution a (copied) mechanism holds after newton! with an iteration cap: v+, Ï‰+ of every body (what lqr.jl:98-103 reads as vsol[2], Ï‰sol[2]) and,
+# where the constraint type has the field, the multipliers
+function solution_after(snapshot, cap)
+    m = deepcopy(snapshot)
+    ConstrainedDynamics.newton!(m, newtonIter = cap)
+    s = Float64[]
+    for b in m.bodies
+        append!(s, b.state.vsol[2]); append!(s, b.state.Ï‰sol[2])
+    end
+    for e in m.eqconstraints
+        hasproperty(e, :Î»sol) && append!(s, e.Î»sol[2])
+    end
+    return s
+end
+function newton_iterations(snapshot; maxit = 100)
+    ref = solution_after(snapshot, maxit)
+    for n = 1:maxit
+        solution_after(snapshot, n) == ref && return n
+    end
+    return maxit
+end
+# simulate! under `controller` for NEWTON_STEPS steps with a wrapper callback that keeps a copy of the mechanism as newton! is about to see it
+function newton_iteration_counts(mech, controller)
+    snaps = Vector{Any}(undef, NEWTON_STEPS)
+    storage = Storage{Float64}(Base.OneTo(NEWTON_STEPS), length(mech.bodies))
+    wrapped!(m, k) = begin
+        controller.control!(m, controller, k)                        # the plugin contract: lqr.jl:14, :89; lqr_tracking.jl:14, :46
+        snaps[k] = deepcopy(m)
+    end
+    simulate!(mech, storage, wrapped!, record = true)                 # the closure form of simulate!: trackingLQR_triple_cartpole.jl:46-53
+    # (if the dependency moves the inputs from the constraints onto the bodies between control! and newton!, a stand-alone newton! on the copy still
+    # does the same, because that transfer is part of evaluating the residual; should a version do it elsewhere, the counts below describe a step without
+    # its input -- tests/test_reference_fixtures.py then reports "neither rule" rather than a wrong answer)
+    return Int64[newton_iterations(snaps[k]) for k = 1:NEWTON_STEPS]
+end
+# Îµ, newtonIter, lineIter as the method of newton! declares them: read as NUMBERS out of the declaration (no source text is kept)
+function newton_defaults()
+    out = [NaN, NaN, NaN]
+    try
+        m = first(methods(ConstrainedDynamics.newton!))
+        file, line = String(m.file), m.line
+        txt = join(readlines(file)[line:min(line + 3, end)], " ")
+        for (i, key) in enumerate(["Îµ", "newtonIter", "lineIter"])
+            mt = match(Regex(key * "\\s*=\\s*([0-9.eE+-]+)"), txt)
+            mt === nothing || (out[i] = parse(Float64, mt.captures[1]))
+        end
+    catch err
+        @warn "newton! declaration not readable" err
+    end
+    return out
+end
+function package_versions()
+    v = zeros(Int64, 4, 3)
+    names = ["ConstrainedDynamics", "ConstrainedControl", "StaticArrays"]
+    try
+        for (uuid, info) in Pkg.dependencies()                        # (Julia >= 1.4; the reference's compat is 1.6 - 1.8, Project.toml:14)
+            i = findfirst(==(info.name), names)
+            (i === nothing || info.version === nothing) && continue
+            v[i, :] = [info.version.major, info.version.minor, info.version.patch]
+        end
+    catch err
+        @warn "package versions not readable" err
+    end
+    v[4, :] = [VERSION.major, VERSION.minor, VERSION.patch]
+    return v
+end
+function save_newton_facts(dir, mech, controller)
+    save(dir, "newton_defaults", newton_defaults())
+    save(dir, "versions", package_versions())
+    try       # on a COPY of the placed mechanism (bodies, multipliers, everything): the run the other arrays come from starts from an untouched one
+        save(dir, "newton_iters", newton_iteration_counts(deepcopy(mech), controller))
+    catch err
+        @warn "Newton iteration counts not recorded" err
+    end
+end
+
 function export_lqr(name, mech, bodyids, eqcids, Q, R, horizon, tend; xd, qd, FÏ„d = [[0.0] for _ in eqcids])
     dir = joinpath(OUT, "ref_" * name); mkpath(dir)
     nb = length(mech.bodies)
@@ -82,6 +168,7 @@ function export_lqr(name, mech, bodyids, eqcids, Q, R, horizon, tend; xd, qd, FÏ
     end
     save(dir, "zd", zd); save(dir, "Fd", [f[1] for f in FÏ„d])
     save(dir, "ctrl_joint_ids", Int64.(eqcids)); save(dir, "body_ids", Int64.(bodyids))
+    save_newton_facts(dir, mech, lqr)                                                             # (the controller holds ids, not the mechanism: lqr.jl:3-15)
     storage = simulate!(mech, tend, lqr, record = true)                                           # examples/lqr_cartpole.jl:44
     ks = sample_ks(length(storage.x[1]))
     x, q, v, w = storage_samples(storage, nb, ks)
@@ -207,6 +294,7 @@ let
     save(dir, "K_all", gains(lqr.K)); save(dir, "K_distinct_from", [distinct_from(lqr.K)])
     save(dir, "Q", cat(Q..., dims = (1, 2)) * mech.Î”t); save(dir, "R", cat(R..., dims = (1, 2)) * mech.Î”t)
     zero_pose!()
+    save_newton_facts(dir, mech, lqr)
     storage = Storage{Float64}(steps, 4)
     simulate!(mech, storage, lqr, record = true)
     x, q, v, w = storage_samples(storage, 4, ks)
