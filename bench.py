@@ -413,7 +413,7 @@ def extra_workloads(pkg, capi, torch, dev, setup_s, lqr, mx, mu, ml, T, args):
             more["chain_16_bodies_N15"] = chain_rate(pkg, capi, torch, dev, 15, args.instances, args.sim_steps, count)
         more.update(other_configs(pkg, capi, torch, dev, count))
         more["branching_tree_14_bodies"] = tree14_rate(pkg, capi, torch, dev, count)
-        more["deltabot_closed_loops"] = deltabot_rate(pkg, capi, torch, dev)
+        more["deltabot_closed_loops"] = deltabot_rate(pkg, capi, torch, dev, count=count)
     except Exception as e:        # the extra lines never take the headline line down with them
         more["other_configs_error"] = repr(e)
     m = mu + ml
@@ -526,11 +526,35 @@ def deltabot_workload(pkg, capi, n=32768):
     return mh, ctrl, np.tile(z00[None], (n, 1, 1)), "rollout_loop_kernel<%d>" % ((5 * t.ne + 7) // 8)
 
 
-def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200):
-    """No roofline figure: the checker of this kernel is oracle/loops.py (numpy dense-KKT), which has no flop counter."""
+def deltabot_flops_per_instance_step(pkg, n_sample=2, steps=8):
+    """algorithmic fp64 flops of one instance-step of the deltabot workload, counted on the dense-KKT checker (oracle/loops.py flops_per_step: the tree
+    oracle's own bookkeeping for the evaluations, measured on liborc_flops.so, + the dense Schur assembly and LU a loop needs; iterations and line-search
+    evaluations counted under the parity stopping rule) on n_sample instances x steps steps under the SAME law: u = scale_i Fd - K dz"""
+    from oracle import loops
+    ex = pkg.examples.deltabot()
+    lm = loops.from_tables(ex["mech"].tables())
+    z00 = ex["mech"].state()
+    cj = [ex["mech"].joint_index(e) for e in ex["eqcids"]]
+    rng = np.random.default_rng(0)
+    K = rng.normal(size=(1, 2, 12 * lm.nb)) * 0.05
+    scale = rng.uniform(0.97, 1.03, 32768)
+    tot, cnt = 0.0, 0
+    for i in range(n_sample):
+        z, lam = z00.copy(), np.zeros(lm.nrows)
+        for k in range(steps):
+            u = np.zeros(len(lm.joints))
+            u[cj] = scale[i] * ex["Fd"].reshape(2) - K[0] @ loops.state_error(z, z00)
+            fl, z, lam, its = loops.flops_per_step(lm, z, lam, u, ctrl_flops=2.0 * 2 * 12 * lm.nb)
+            tot += fl; cnt += 1
+    return tot / cnt
+
+
+def deltabot_rate(pkg, capi, torch, dev, n=32768, steps=200, count=True):
+    """Roofline figure since round 5: the checker of this kernel (oracle/loops.py, numpy dense-KKT) got a flop counter -- see deltabot_flops_per_instance_step."""
     mh, ctrl, z0, kern = deltabot_workload(pkg, capi, n)
     lanes, lds = mh.geometry()
-    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, False, kernel=kern), lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
+    f = deltabot_flops_per_instance_step(pkg) if count else None
+    out = dict(_timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, False, f_step=f, kernel=kern), lanes_per_instance=lanes, lds_bytes_per_workgroup=lds,
                workload="lqr_deltabot.jl as a batch: %d deltabots (5 bodies, 7 joints, 35 constraint rows of rank 28) x %d steps, feedback on the two actuated "
                         "joints, record=false: the closed-loop kernel with the register-resident Gauss-Jordan solve of round 4 (4.6 M inst-steps/s with the "
                         "LDS-resident complete-pivoting solve of rounds 2-3)" % (n, steps))

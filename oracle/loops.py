@@ -238,3 +238,98 @@ def from_tables(t):
     joints = [Joint(int(t.type[j]), int(t.parent[j]), int(t.child[j]), t.axis[j], t.p1[j], t.p2[j], t.qoff[j]) for j in range(t.ne)]
     return LoopMechanism(t.mass, t.inertia.reshape(t.nb, 3, 3), joints, dt=t.dt, g=t.g)
 
+
+
+# ------------------------------------------------------------------------------------------------ flop count of a loop mechanism's step (bench.py roofline)
+def step_with_the_parity_rule(lm, z, lam, u, eps=1e-10, maxit=100, line_maxit=10):
+    """LoopMechanism.step with the stopping rule and line search of the tree oracle's newton() (stop when ||f|| < eps AND the step taken
+    alpha ||dx|| < eps; halve while ||f|| grows, at most 10 times) -- the rule the device kernels follow -- so that its iteration and evaluation COUNTS
+    are the ones a step of the reference algorithm takes.  Returns (z_next, lam, iterations, residual evaluations).  Same converged point as step()."""
+    z = np.asarray(z, float).reshape(lm.nb, 13)
+    F, tau = lm.input_wrenches(z, u)
+    Gk = [lm._blocks(j, z)[1:] for j in lm.joints]
+    ns = 6 * lm.nb
+    x = np.concatenate([z[:, 7:13].ravel(), np.asarray(lam, float)])
+    f = lambda xx: lm.residual(z, xx[:ns].reshape(lm.nb, 6), xx[ns:], F, tau, Gk)
+    r = f(x)
+    n0, evals = np.linalg.norm(r), 1
+    for it in range(1, maxit + 1):
+        h = 1e-6
+        Jm = np.zeros((len(r), len(x)))
+        for i in range(len(x)):
+            e = np.zeros(len(x)); e[i] = h
+            Jm[:, i] = (f(x + e) - f(x - e)) / (2 * h)
+        dx = np.linalg.lstsq(Jm, r, rcond=1e-10)[0]
+        evals += 1                                   # the evaluation WITH Jacobians of this iteration (the differences above stand in for the analytic blocks)
+        alpha = 1.0
+        for ls in range(line_maxit + 1):
+            rt = f(x - alpha * dx)
+            evals += 1
+            n1 = np.linalg.norm(rt)
+            if n1 > n0 and ls < line_maxit:
+                alpha *= 0.5
+            else:
+                break
+        x, r = x - alpha * dx, rt
+        if n1 < eps and alpha * np.linalg.norm(dx) < eps:
+            return lm._next(z, x[:ns].reshape(lm.nb, 6)), x[ns:], it, evals
+        n0 = n1
+    raise RuntimeError("dense-KKT Newton (parity rule) did not converge")
+
+
+def flops_model(lm):
+    """fp64 flops of the pieces of one Newton iteration on a loop mechanism, by the SAME bookkeeping as the instrumented tree oracle (cclqr_oracle.c FL(...)):
+    the joint evaluations are MEASURED on liborc_flops.so (orc_constraints = the residual-only evaluation, orc_joint_blocks = the evaluation with Jacobians
+    + two Q_to_phi of 120), the body terms are the constants of residual() there (next_pose 20 + residual 40 + two 3x3 products 30 + two cross products 18 =
+    108, Jacobian + 30 + 54), and the linear solve -- which the tree oracle does by the body/joint LDU and a loop cannot -- is priced as what it is
+    algebraically: D_b^-1 per body, W = G_v D^-1 per (joint, side), one 5 x 5 block of S = G_v D^-1 G_k' per ordered pair of joints that share a body,
+    a dense LU of the m x m Schur complement (2/3 m^3 + 2 m^2, m = constraint rows) and the body back-substitution.  -> dict of counts"""
+    L = orc.lib(True)
+    z = np.zeros((lm.nb, 13)); z[:, 3] = 1.0
+    f_eval0 = f_eval1 = 0.0
+    sides = 0
+    pair_blocks = 0
+    around = [0] * lm.nb
+    for j in lm.joints:
+        hp = j.parent >= 0
+        sides += 2 if hp else 1
+        around[j.child] += 1
+        if hp:
+            around[j.parent] += 1
+        kind = PRISMATIC if j.kind == FIXED_ORIENTATION else j.kind
+        xa = np.zeros(3); qa = np.array([1.0, 0, 0, 0]); xb = np.array([0.1, 0.2, 0.3]); qb = rotx(0.3)
+        g, Ga, Gb = np.zeros(5), np.zeros((5, 6)), np.zeros((5, 6))
+        orc.flops_reset()
+        L.orc_joint_blocks(C.c_int32(kind), _p(j.p1), _p(j.p2), _p(j.axis), _p(j.qoff), _p(xa) if hp else None, _p(qa) if hp else None, _p(xb), _p(qb), _p(g), _p(Ga), _p(Gb))
+        fjb = orc.flops_get()
+        frac = j.rows / 5.0                                              # a FixedOrientation keeps three of the five rows
+        f_eval1 += frac * ((fjb - 240.0) + 36.0 * (2 if hp else 1) + 30.0)  # joint_eval(jac) + Q_to_omega per side + assembly, as residual(jac = 1) does
+        f_eval0 += frac * (fjb - 240.0 - 105.0)                          # joint_eval(jac = 0): FL(15) instead of FL(120), same rotations / quaternion products
+        f_eval0 += frac * (120.0 if hp else 60.0); f_eval1 += frac * (120.0 if hp else 60.0)      # d -= G_k' lambda
+    pair_blocks = sum(n * n for n in around)
+    m = lm.nrows
+    out = {
+        "residual_evaluation": 108.0 * lm.nb + f_eval0 + 2.0 * (6 * lm.nb + m) + 1.0,
+        "evaluation_with_jacobians": (108.0 + 84.0) * lm.nb + f_eval1 + 2.0 * (6 * lm.nb + m) + 1.0,
+        "trial_point": 2.0 * (6 * lm.nb + m),
+        "schur_assembly": 45.0 * lm.nb + 105.0 * sides + 300.0 * pair_blocks + 60.0 * sides,
+        "dense_lu_solve": 2.0 / 3.0 * m ** 3 + 2.0 * m * m,
+        "back_substitution": 60.0 * sides + 42.0 * lm.nb,
+        "step_norm": 2.0 * (6 * lm.nb + m),
+        "rows_m": m, "ordered_joint_pairs_sharing_a_body": pair_blocks,
+    }
+    out["newton_iteration_without_line_search"] = out["evaluation_with_jacobians"] + out["schur_assembly"] + out["dense_lu_solve"] + out["back_substitution"] + out["step_norm"]
+    return out
+
+
+def flops_per_step(lm, z, lam, u, ctrl_flops=0.0):
+    """counted iterations / evaluations of step_with_the_parity_rule x flops_model: the algorithmic fp64 flops of ONE step from (z, lam) under inputs u;
+    returns (flops, z_next, lam_next, iterations).  Fixed per step: the joint Jacobians at the current knot (one evaluation with Jacobians of every joint), the
+    input wrenches (30 per driven joint, as apply_input) and the control law (2 mu 12 nb, passed in)."""
+    fm = flops_model(lm)
+    zn, ln, its, evals = step_with_the_parity_rule(lm, z, lam, u)
+    fixed = fm["evaluation_with_jacobians"] - (108.0 + 84.0) * lm.nb + 30.0 * float(np.count_nonzero(u)) + ctrl_flops
+    # evals = 1 (initial) + per iteration: 1 with Jacobians + (1 + halvings) residual-only trials
+    trials = evals - 1 - its
+    fl = fixed + fm["residual_evaluation"] + its * fm["newton_iteration_without_line_search"] + trials * (fm["residual_evaluation"] + fm["trial_point"])
+    return fl, zn, ln, its
