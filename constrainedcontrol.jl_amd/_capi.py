@@ -7,6 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcclqr.so")
+if os.environ.get("CCLQR_LIB_VARIANT", "base") != "base":      # experiment builds of tools/gpu_*_ab.sh (make variant / ricvariant): never set by the product
+    LIB_PATH = os.path.join(_HERE, "libcclqr_%s.so" % os.environ["CCLQR_LIB_VARIANT"])
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 

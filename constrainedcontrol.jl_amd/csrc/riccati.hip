@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
         }
+        RSTAMP(RP_NORM);       // (diagnostic build: wavefront 0's own Pkp1 tiles end here; RP_PP below = operand prefetch, norm reduction, barrier waits)
         if (k > 1 && BF == 0) {
             if (FRAG64) fetch_next(k - 1);         // (the fragment was last read by this wavefront's tiles above; D waits in registers)
             else fetch_operands(k - 1);            // (streaming form: a barrier separates the update phase, D's last reader, from the tiles)

@@ -29,5 +29,5 @@ m = mu + ml
 F = 4 * mx**3 + 4 * mx**2 * m + 2 * mx * (ml**2 + m**2) + 2 / 3 * m**3 + 2 / 3 * ml**3
 kbs = np.atleast_1d(kb); done = (N - np.maximum(kbs, 1) + 1).sum()
 print("%s mx=%d mu=%d ml=%d nprob=%d N=%d: %.3fs total, %.3f ms/backward-step/problem-wave, kbreak %s, %.1f GFLOP/s (F_ric=%.3g)" % (name, mx, mu, ml, nprob, N, dt, 1e3 * dt / max(1, N - kbs.min()), kbs[:3], F * done / dt / 1e9, F))
-for i, n in enumerate(["W = P [A'|D]", "D'W, mu x mu solve, Ku", "Abar, P Abar updates", "Abar'(P Abar) + norm", "(unused)"]):
+for i, n in enumerate(["W = P [A'|D]", "D'W, mu x mu solve, Ku", "Abar, P Abar updates", "prefetch, norm, barriers", "Pkp1 tiles of wavefront 0"]):
     print("  %-24s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / steps))
