@@ -273,7 +273,7 @@ def main():
                    "instances_per_gpu": n_inst, "sim_steps": T, "record": record, "parallelism": "instances sharded x%d" % world,
                    "lanes_per_instance": lanes, "lds_bytes_per_workgroup": lds_bytes, "launches_per_rollout": chunks},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "rollout_chain_kernel<%d, %d, 0, false>" % (lanes, mh.layout_links()),
+                     "traffic": traffic, "kernel": kernel_name(mh),
                      "kernel_ms": kern_ms_launch, "launches_per_rollout": chunks, "algorithmic_bytes_per_instance_step": bs,
                      "kernel_source_sha": kernel_source_sha()},
         "collection": {"mode": (args.collect if world > 1 else "single GPU: nothing leaves the device"),
@@ -434,7 +434,9 @@ def kernel_name(mh, extra=0):
     lanes, _ = mh.geometry()
     par = np.asarray(mh.tables.parent)
     branching = mh.tables.ne == mh.tables.nb and (np.bincount(par[par >= 0], minlength=1) > 1).any()
-    return "%s<%d, %d, %d, false>" % ("rollout_treereg_kernel" if branching else "rollout_chain_kernel", lanes, mh.layout_links(), extra)
+    if branching:
+        return "rollout_treereg_kernel<%d, %d, %d, false>" % (lanes, mh.layout_links(), extra)
+    return "rollout_chain_kernel<%d, %d, %d, false, %d, %d>" % ((lanes, mh.layout_links(), extra) + mh.lanes_per_link())
 
 
 def flops_per_instance_step(t, octrl_kw, z0, steps, n_sample=4):

@@ -18,7 +18,7 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_host_ex", "cclqr_ctrl_reserve_noise", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex",
-           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout"]
+           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout", "cclqr_rollout_lanes_per_link"]
 ABI_VERSION = 201     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header (verified field by field against cclqr_abi_layout at load time)
 ROLLOUT_NO_ALLOC = 1  # cclqr_rollout_opts.flags: the call may neither allocate nor synchronise (a hipGraph capture is open on the device)
 PHILOX_INKERNEL_STEPS = 8
@@ -165,6 +165,12 @@ class MechHandle:
         n = C.c_int32(0)
         check(lib().cclqr_rollout_layout_links(self.ptr, C.byref(n)))
         return n.value
+
+    def lanes_per_link(self):
+        """(lanes that work for one link, links per sub-lane group) of the chain kernel's instantiation; (1, lanes per instance) elsewhere"""
+        kl, nl = C.c_int32(0), C.c_int32(0)
+        check(lib().cclqr_rollout_lanes_per_link(self.ptr, C.byref(kl), C.byref(nl)))
+        return kl.value, nl.value
 
     def close(self):
         if self.ptr:

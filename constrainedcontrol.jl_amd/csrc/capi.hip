@@ -327,6 +327,20 @@ extern "C" int cclqr_rollout_layout_links(const cclqr_mech* m, int32_t* links) {
     return CCLQR_OK;
 }
 
+extern "C" int cclqr_rollout_lanes_per_link(const cclqr_mech* m, int32_t* lanes_per_link, int32_t* links_per_group) {
+    if (!m) return fail(CCLQR_EINVAL, "null argument");
+    int kl = 1, nl = 64;
+    if (m->host.loop) nl = 64;
+    else if (m->host.tree) nl = treereg_lanes(m->nb, m->host.tree);
+    else {
+        kl = chain_lanes_per_link(m->nb);
+        nl = kl == 1 ? chain_lanes_per_instance(m->nb) : (m->nb <= 2 ? 2 : chain_layout_links(m->nb));
+    }
+    if (lanes_per_link) *lanes_per_link = kl;
+    if (links_per_group) *links_per_group = nl;
+    return CCLQR_OK;
+}
+
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
     if (m->host.loop) { if (lanes) *lanes = 64; if (lds_bytes) *lds_bytes = (int32_t)loop_lds_bytes(m->nb, m->nj); return CCLQR_OK; }

@@ -51,14 +51,18 @@ struct LinkC {
     static const int DEAD = 64, BAD = 128;     // set by the rollout loop (see there)
     static const int FRIC = 256;               // the own joint has viscous friction (friction/noise variant)
     HD bool has_fric() const { return (flags & FRIC) != 0; }
+    static const int PRIM = 512;               // the lane is the PRIMARY one of its link's KL lanes (several lanes per link: below); always set when KL = 1
+    HD bool prim() const { return (flags & PRIM) != 0; }
     HD bool dead() const { return (flags & DEAD) != 0; }
     HD bool bad() const { return (flags & BAD) != 0; }
     HD void set_valid(bool v) { flags |= v ? (16 | ((flags & 1) << 5)) : 0; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LINK_FLAGS_FRESH(c) asm volatile("" : "+v"((c).flags))
+#define LANE_INT_FRESH(x) asm volatile("" : "+v"(x))       // the same for any per-lane integer a predicate is formed from
 #else
 #define LINK_FLAGS_FRESH(c) ((void)0)
+#define LANE_INT_FRESH(x) ((void)0)
 #endif
 
 HD void link_load_consts(LinkC& c, const MechDev* M, int t, int nb, double dt) {
@@ -425,6 +429,186 @@ HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L
                 rr = g[r] - (c.sxb * xd + bd) - (ad - c.sxa * xa);
             }
             L[Y.R + 5 * j + r] = rr;
+        }
+    }
+}
+
+// ================================================================== SEVERAL LANES PER LINK (round 5)
+// A mechanism that leaves lanes of its lane group idle (2 links in 8 lanes, 4 in 8, 7 in 16, 16 in 32) gives every link KL = 3 or 2 lanes at
+// UNCHANGED occupancy -- the same instances per wavefront, the same LDS image -- and deals the row-separable work of an evaluation with Jacobians
+// to them: the five rows of the joint's (g, G_v D^-1) and the Schur rows / right-hand side built from them.  Lane = w NL + l (sub-lane w of
+// link l, NL links per sub-lane group), so that the parent link still is one lane below and every neighbour vector moves by the same wave shifts.
+// Everything that is not row-separable -- the body evaluation, rotation matrices, relative quaternion, the 3 x 3 products -- is computed by all
+// lanes of a link (sharing it would cost ~40 doubles of exchange per evaluation), so no exchange between sub-lanes is needed at all; only the
+// PRIMARY sub-lane (w = 0) writes the link's private LDS slots and contributes the body's residual to the norm.
+// Row slots of a lane (uniform code, per-lane selectors -- rows 0, 1 are translational-kind, 3, 4 rotational-kind, row 2 either, by joint type):
+//   KL = 3:  w < 2: slot A = row w (translational kind), slot B = row 3 + w (rotational kind);  w = 2: row 2, computed in BOTH kinds through the two
+//            slots' code and merged into slot A (slot B then is empty)                                              -> 2 row units per lane (5 rows: 6)
+//   KL = 2:  slots A, B as above, and slot C = row 2 in both kinds on sub-lane 0 (empty on sub-lane 1)                -> 4 row units per lane
+// Measured on the 17-body chain (where it does NOT pay, because there the split costs occupancy: profiles/r05/stageA_*): same norms and Schur blocks
+// to 4e-16 relative, 941 instead of 1563 vector instructions per evaluation and wavefront.
+template <int KL> struct SubRows { static const int NR = KL == 3 ? 2 : 3; };
+struct SubSel {
+    double sa[3], sb[3], s2[3];     // selectors of slot A (translational kind), slot B (rotational kind), row 2
+    int w;                          // sub-lane
+    int ia, ib, ic;                 // row numbers of the slots inside a 5-row block (-1: the slot is empty on this lane)
+};
+// selector of constraint row `row` of the owned joint, row a RUN-TIME number (row_sel above wants a compile-time one)
+HD void row_sel_rt(const LinkC& c, int row, double* s) {
+    const bool rev = c.rev();
+    const bool unit = rev ? row < 3 : row >= 2;
+    const int e = rev ? row : row - 2, v = rev ? row - 3 : row;
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = unit ? (i == e ? 1.0 : 0.0) : c.V12[3 * (v & 1) + i];
+}
+template <int KL>
+HD void sub_setup(const LinkC& c, int w, SubSel& Q) {
+    Q.w = w;
+    const bool mid = KL == 3 && w == 2;                  // the lane of row 2 (KL = 3)
+    row_sel_rt(c, 2, Q.s2);
+    row_sel_rt(c, mid ? 2 : (w & 1), Q.sa);
+    row_sel_rt(c, mid ? 2 : 3 + (w & 1), Q.sb);
+    Q.ia = mid ? 2 : w;
+    Q.ib = mid ? -1 : 3 + w;
+    Q.ic = (KL == 2 && w == 0) ? 2 : -1;
+}
+// the lane's rows of the joint's g and of W = G_v D^-1 in sparse form (slot s: g[s], XT[s] -- zero for a rotational row --, PB[s], PA[s]); same
+// formulas as joint_eval_sparse<true>.  Na / Nb: N D_R^-1 of the parent / own body.
+template <int KL>
+HD void joint_eval_rows(const LinkC& c, const SubSel& Q, const double* xa, const double* qa, const double* xb, const double* qb, const double* Na, const double* Nb,
+                        double* g, double (*XT)[3], double (*PB)[3], double (*PA)[3]) {
+    constexpr int NR = SubRows<KL>::NR;
+    double Ra[9], Rb[9], rp[3], wv[3], RaTw[3], gT[3];
+    rotmat(qa, Ra); rotmat(qb, Rb);
+    mv3(Rb, c.p2, rp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) wv[i] = xb[i] + rp[i] - xa[i];
+    mtv3(Ra, wv, RaTw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) gT[i] = RaTw[i] - c.p1[i];
+    double qac[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, rel[4], e[4];
+    qmul(qac, qb, rel);
+    qmul(rel, c.qoc, e);
+    double RaTRb[9], PTb[9], PRb[9];
+    mtm3(Ra, Rb, RaTRb);
+    {
+        const double* p = c.p2;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double a = RaTRb[i * 3], b = RaTRb[i * 3 + 1], cc = RaTRb[i * 3 + 2];
+            PTb[i * 3 + 0] = -2.0 * (b * p[2] - cc * p[1]);
+            PTb[i * 3 + 1] = -2.0 * (cc * p[0] - a * p[2]);
+            PTb[i * 3 + 2] = -2.0 * (a * p[1] - b * p[0]);
+        }
+    }
+    {
+        const double s = rel[0], x = rel[1], y = rel[2], z = rel[3];
+        const double os = c.qoc[0], ox = c.qoc[1], oy = c.qoc[2], oz = c.qoc[3];
+        const double Lr[3][4] = {{x, s, -z, y}, {y, z, s, -x}, {z, -y, x, s}};
+        const double Rc[4][3] = {{-ox, -oy, -oz}, {os, oz, -oy}, {-oz, os, ox}, {oy, -ox, os}};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) PRb[i * 3 + j] = Lr[i][0] * Rc[0][j] + Lr[i][1] * Rc[1][j] + Lr[i][2] * Rc[2][j] + Lr[i][3] * Rc[3][j];
+    }
+    const double PTa[9] = {0, -2 * RaTw[2], 2 * RaTw[1], 2 * RaTw[2], 0, -2 * RaTw[0], -2 * RaTw[1], 2 * RaTw[0], 0};
+    const double PRa[9] = {-e[0], -e[3], e[2], e[3], -e[0], -e[1], -e[2], e[1], -e[0]};
+    const bool rot2 = !c.rev();                          // row 2 is rotational for a prismatic joint
+    double pb3[NR][3], pa3[NR][3];
+    {   // slot A as a translational row, slot B as a rotational row
+        const double a0 = Q.sa[0], a1 = Q.sa[1], a2 = Q.sa[2], b0 = Q.sb[0], b1 = Q.sb[1], b2 = Q.sb[2];
+        const double vT = a0 * gT[0] + a1 * gT[1] + a2 * gT[2], vR = b0 * e[1] + b1 * e[2] + b2 * e[3];
+        int wq = Q.w;
+        LANE_INT_FRESH(wq);                               // (the predicate is formed here, per evaluation -- not once per launch and kept as a lane mask)
+        const bool merge = KL == 3 && wq == 2;           // the lane of row 2: slot A keeps the kind the joint type selects, slot B is empty
+        const bool rot = merge && rot2;
+        g[0] = rot ? vR : vT;
+        g[1] = merge ? 0.0 : vR;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double xt = a0 * Ra[k * 3] + a1 * Ra[k * 3 + 1] + a2 * Ra[k * 3 + 2];
+            const double ptb = a0 * PTb[k] + a1 * PTb[3 + k] + a2 * PTb[6 + k], pta = a0 * PTa[k] + a1 * PTa[3 + k] + a2 * PTa[6 + k];
+            const double prb = b0 * PRb[k] + b1 * PRb[3 + k] + b2 * PRb[6 + k], pra = b0 * PRa[k] + b1 * PRa[3 + k] + b2 * PRa[6 + k];
+            XT[0][k] = rot ? 0.0 : xt;
+            pb3[0][k] = rot ? prb : ptb; pa3[0][k] = rot ? pra : pta;
+            XT[1][k] = 0.0;
+            pb3[1][k] = merge ? 0.0 : prb; pa3[1][k] = merge ? 0.0 : pra;
+        }
+    }
+    if (KL == 2) {   // slot C: row 2 in both kinds (sub-lane 0; zeroed elsewhere)
+        int icq = Q.ic;
+        LANE_INT_FRESH(icq);
+        const bool have = icq >= 0;
+        const double s0 = Q.s2[0], s1 = Q.s2[1], s2 = Q.s2[2];
+        const double vT = s0 * gT[0] + s1 * gT[1] + s2 * gT[2], vR = s0 * e[1] + s1 * e[2] + s2 * e[3];
+        g[NR - 1] = have ? (rot2 ? vR : vT) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double xt = s0 * Ra[k * 3] + s1 * Ra[k * 3 + 1] + s2 * Ra[k * 3 + 2];
+            const double ptb = s0 * PTb[k] + s1 * PTb[3 + k] + s2 * PTb[6 + k], pta = s0 * PTa[k] + s1 * PTa[3 + k] + s2 * PTa[6 + k];
+            const double prb = s0 * PRb[k] + s1 * PRb[3 + k] + s2 * PRb[6 + k], pra = s0 * PRa[k] + s1 * PRa[3 + k] + s2 * PRa[6 + k];
+            XT[NR - 1][k] = (have && !rot2) ? xt : 0.0;
+            pb3[NR - 1][k] = have ? (rot2 ? prb : ptb) : 0.0; pa3[NR - 1][k] = have ? (rot2 ? pra : pta) : 0.0;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NR; s++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            PB[s][k] = pb3[s][0] * Nb[k] + pb3[s][1] * Nb[3 + k] + pb3[s][2] * Nb[6 + k];
+            const double na = pa3[s][0] * Na[k] + pa3[s][1] * Na[3 + k] + pa3[s][2] * Na[6 + k];
+            PA[s][k] = c.has_a() ? na : 0.0;
+        }
+}
+// the lane's rows of S_jj, S_jp, S_jc and r_j (ck_schur_rows for the rows of its slots; element (r, q) of a block at 5 q + r)
+template <int KL>
+HD void ck_schur_rows_sub(const LinkC& c, const SubSel& Q, int j, bool store, const Lay& Y, double* L, const double* g, const double (*XT)[3], const double (*PB)[3],
+                          const double (*PA)[3], const double* d, const double* pd) {
+    constexpr int NR = SubRows<KL>::NR;
+    const double sx = c.sxb + c.sxa;
+    const int jp = c.has_a() ? j - 1 : j, jc = c.has_c() ? j + 1 : j;
+    int idx[3] = {Q.ia, Q.ib, Q.ic};
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        // (the "slot is empty" tests are made per column, where the stores are: hoisted out of the loop they are three 64-bit lane masks in scalar registers)
+        LANE_INT_FRESH(idx[0]); LANE_INT_FRESH(idx[1]); LANE_INT_FRESH(idx[2]);
+        const int o = gk_row(q), ob = q < 3 ? 3 : 0;
+        double kx[3] = {0, 0, 0}, kpx[3] = {0, 0, 0}, kcx[3] = {0, 0, 0}, kb[3], ka[3], kpb[3], kca[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (q < 3) { kx[i] = L[Y.GKA + GKSZ * j + o + i]; kpx[i] = L[Y.GKA + GKSZ * jp + o + i]; kcx[i] = L[Y.GKA + GKSZ * jc + o + i]; }
+            kb[i] = L[Y.GKA + GKSZ * j + o + ob + i]; ka[i] = L[Y.GKA + GKSZ * j + o + ob + 3 + i];
+            kpb[i] = L[Y.GKA + GKSZ * jp + o + ob + i]; kca[i] = L[Y.GKA + GKSZ * jc + o + ob + 3 + i];
+        }
+#pragma unroll
+        for (int s = 0; s < NR; s++) {
+            const bool xpart = q < 3 && s != 1;          // slot B is a rotational row: no x part
+            double ojj = PB[s][0] * kb[0] + PB[s][1] * kb[1] + PB[s][2] * kb[2] + (PA[s][0] * ka[0] + PA[s][1] * ka[1] + PA[s][2] * ka[2]);
+            double ojp = PA[s][0] * kpb[0] + PA[s][1] * kpb[1] + PA[s][2] * kpb[2];
+            double ojc = PB[s][0] * kca[0] + PB[s][1] * kca[1] + PB[s][2] * kca[2];
+            if (xpart) {
+                ojj += sx * (XT[s][0] * kx[0] + XT[s][1] * kx[1] + XT[s][2] * kx[2]);
+                ojp -= c.sxa * (XT[s][0] * kpx[0] + XT[s][1] * kpx[1] + XT[s][2] * kpx[2]);
+                ojc -= c.sxb * (XT[s][0] * kcx[0] + XT[s][1] * kcx[1] + XT[s][2] * kcx[2]);
+            }
+            if (store && idx[s] >= 0) {
+                L[Y.SJJ + 25 * j + 5 * q + idx[s]] = ojj;
+                if (c.has_a()) L[Y.SJP + 25 * j + 5 * q + idx[s]] = ojp;
+                if (c.has_c()) L[Y.SPJ + 25 * jc + 5 * q + idx[s]] = ojc;
+            }
+        }
+        SCHED_FENCE();      // (as in ck_schur_rows; measured without it: same registers, same time)
+    }
+    if (store) {
+#pragma unroll
+        for (int s = 0; s < NR; s++) {
+            const double bd = PB[s][0] * d[3] + PB[s][1] * d[4] + PB[s][2] * d[5], ad = PA[s][0] * pd[3] + PA[s][1] * pd[4] + PA[s][2] * pd[5];
+            double rr = g[s] - bd - ad;
+            if (s != 1) {
+                const double xd = XT[s][0] * d[0] + XT[s][1] * d[1] + XT[s][2] * d[2], xa = XT[s][0] * pd[0] + XT[s][1] * pd[1] + XT[s][2] * pd[2];
+                rr = g[s] - (c.sxb * xd + bd) - (ad - c.sxa * xa);
+            }
+            if (idx[s] >= 0) L[Y.R + 5 * j + idx[s]] = rr;
         }
     }
 }

@@ -34,6 +34,7 @@ hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long 
 // forests of chains (rollout_chain.hip)
 int chain_lanes_per_instance(int nb);
 int chain_layout_links(int nb);
+int chain_lanes_per_link(int nb);
 size_t chain_lds_bytes(int nb);
 hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream);
 // closed-loop mechanisms (rollout_loop.hip)

@@ -47,8 +47,10 @@ struct LinkS {
 // With JAC the Schur complement rows of the point go straight to LDS: W = G_v D^-1 only lives inside this function.
 // (The full-step trial is evaluated with JAC on the speculation that it is accepted; if it is not, the accepted point is
 // evaluated again, which overwrites these rows.)
-template <int G, bool JAC>
-__device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, double dt PROF_ARG) {
+// KL > 1 (several lanes per link, cclqr_chain.h): t is the LINK of the lane (its sub-lane is Q.w); with Jacobians the lane evaluates the rows of its slots only
+// and builds their Schur rows, the body's share of the norm comes from the primary sub-lane alone.  KL = 1: the code of rounds 2-4, unchanged.
+template <int G, bool JAC, int KL = 1>
+__device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const Lay& Y, double* L, double alpha, bool active, double dt, const SubSel& Q PROF_ARG) {
     double part = 0.0;
     double NB[9], g[5], xq[7];
     LINK_FLAGS_FRESH(c);
@@ -59,7 +61,8 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
 #pragma unroll
         for (int k = 0; k < 6; k++) { cf[k] = L[Y.C + 6 * t + k] - alpha * S.cd[k]; sv[k] = S.s[k] - alpha * S.ds[k]; cTR[k] = L[Y.D + 6 * t + k]; }
         part = ck_body_eval<JAC>(c, S.z, sv, cf, cTR, cTR + 3, dt, xq, S.d, DINV, NB);
-        if (JAC) {
+        if (KL > 1 && !c.prim()) part = 0.0;
+        if (JAC && (KL == 1 || c.prim())) {
 #pragma unroll
             for (int k = 0; k < 9; k++) L[Y.DINV + 9 * t + k] = DINV[k];
         }
@@ -72,19 +75,42 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
 #pragma unroll
         for (int i = 0; i < 7; i++) pxq[i] = (i == 3) ? 1.0 : 0.0;
     }
-    double wXT[3][3], wPB[5][3], wPA[5][3];
-    if (active) {
-        joint_eval_sparse<JAC>(c, pxq, pxq + 3, xq, xq + 3, pNB, NB, g, wXT, wPB, wPA);
+    if (JAC && KL > 1) {
+        constexpr int NR = SubRows<KL>::NR;
+        double gs[NR], sXT[NR][3], sPB[NR][3], sPA[NR][3];
+        if (active) {
+            joint_eval_rows<KL>(c, Q, pxq, pxq + 3, xq, xq + 3, pNB, NB, gs, sXT, sPB, sPA);
 #pragma unroll
-        for (int i = 0; i < 5; i++) part += g[i] * g[i];
-    }
-    STAMP(PF_EVAL_JOINT);
-    LINK_FLAGS_FRESH(c);
-    if (JAC) {
+            for (int i = 0; i < NR; i++) part += gs[i] * gs[i];
+        }
+        STAMP(PF_EVAL_JOINT);
+        LINK_FLAGS_FRESH(c);
         double pd[6];
         from_prev<6>(S.d, pd);
-        ck_schur_rows(c, t, active, Y, L, wXT, wPB, wPA, g, S.d, pd);
+        ck_schur_rows_sub<KL>(c, Q, t, active, Y, L, gs, sXT, sPB, sPA, S.d, pd);
         STAMP(PF_SCHUR_S);
+    } else {
+        double wXT[3][3], wPB[5][3], wPA[5][3];
+        if (active) {
+            joint_eval_sparse<JAC>(c, pxq, pxq + 3, xq, xq + 3, pNB, NB, g, wXT, wPB, wPA);
+            if (KL == 1) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) part += g[i] * g[i];
+            } else {                                     // (residual-only evaluation with several lanes per link: every lane computes all rows, one counts)
+                double pj = 0.0;
+#pragma unroll
+                for (int i = 0; i < 5; i++) pj += g[i] * g[i];
+                part += c.prim() ? pj : 0.0;
+            }
+        }
+        STAMP(PF_EVAL_JOINT);
+        LINK_FLAGS_FRESH(c);
+        if (JAC) {
+            double pd[6];
+            from_prev<6>(S.d, pd);
+            ck_schur_rows(c, t, active, Y, L, wXT, wPB, wPA, g, S.d, pd);
+            STAMP(PF_SCHUR_S);
+        }
     }
     const double nrm = sqrt(group_sum<G>(part));
     STAMP(PF_EVAL_MAP);
@@ -99,7 +125,7 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
 struct TrialIn { double z[7], s[6], ds[6], cd[6]; };
 __device__ __forceinline__ double other_half(double v) { return __shfl_xor(v, 32, 64); }
 // ||f|| of the owning group at the trial points s - a ds (constraint forces C - a cd) for a = a1 and a = a2; Lc = LDS image of the instance
-template <int G>
+template <int G, int KL = 1>
 __device__ __forceinline__ void chain_eval2(LinkC& c, const TrialIn& T, const double* Lc, int t, const Lay& Y, double a1, double a2, bool active, double dt,
                                             double& n1, double& n2) {
     double part1 = 0.0, part2 = 0.0, xq1[7], xq2[7];
@@ -132,6 +158,7 @@ __device__ __forceinline__ void chain_eval2(LinkC& c, const TrialIn& T, const do
 #pragma unroll
         for (int i = 0; i < 5; i++) { part1 += g1[i] * g1[i]; part2 += g2[i] * g2[i]; }
     }
+    if (KL > 1 && !c.prim()) { part1 = 0.0; part2 = 0.0; }      // (several lanes per link: every lane of a link has evaluated the same residual, one counts)
     n1 = sqrt(group_sum<G>(part1));
     n2 = sqrt(group_sum<G>(part2));
 }
@@ -141,7 +168,7 @@ __device__ __forceinline__ void chain_eval2(LinkC& c, const TrialIn& T, const do
 // wavefront of eight see a search go to the 10th halving) while the groups whose search has ended sit idle.  So the idle groups evaluate
 // further step lengths of the instances still searching (group_assist below): ||f|| at ONE step length, for any group's lanes, of the
 // instance whose trial state is T and whose LDS image is Lc.  Same functions, same order as chain_eval<G, false>.
-template <int G>
+template <int G, int KL = 1>
 __device__ __forceinline__ double chain_eval1(LinkC& c, const TrialIn& T, const double* Lc, int t, const Lay& Y, double a1, bool active, double dt) {
     double part1 = 0.0, xq1[7];
     LINK_FLAGS_FRESH(c);
@@ -169,6 +196,7 @@ __device__ __forceinline__ double chain_eval1(LinkC& c, const TrialIn& T, const 
 #pragma unroll
         for (int i = 0; i < 5; i++) part1 += g1[i] * g1[i];
     }
+    if (KL > 1 && !c.prim()) part1 = 0.0;
     return sqrt(group_sum<G>(part1));
 }
 // value of lane `addr / 4` of the wavefront (ds_bpermute: the LDS crossbar, no memory access)
@@ -205,10 +233,16 @@ hipError_t launch_philox_fill(double* out, unsigned key0, long long inst0, long 
 // RELAX: the measured-error Newton mode of cclqr_rollout_opts.newton_mode = 1 -- a solve also stops on ||f|| < eps_alone, whatever the step.  A template
 // parameter (plain law only), not a launch argument: the exact-rule kernels sit at 486-502 of 512 registers and any extra live value
 // moves them across the line (a scalar mode flag read in the accept phase cost the 17-link instantiations 2 VGPR spills).
-template <int G, int NBP, int EXTRA, bool RELAX = false>
+// KL, NL: several lanes per link (cclqr_chain.h "SEVERAL LANES PER LINK"): lane t of a group is sub-lane w = t / NL of link tl = t % NL; a mechanism of at most NL
+// links whose lane group has KL NL <= G lanes.  KL = 1 (NL = G): one lane per link, the kernels of rounds 2-4, bit for bit.
+template <int G, int NBP, int EXTRA, bool RELAX = false, int KL = 1, int NL = G>
 __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
+    static_assert(KL >= 1 && KL <= 3 && KL * NL <= G && (KL > 1 || NL == G) && (KL == 1 || NL <= NBP), "lane group too small for KL lanes per link");
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
+    const int w = KL > 1 ? t / NL : 0;                      // sub-lane of the lane's link
+    const int tl = KL > 1 ? t - NL * w : t;                 // the link the lane works for (LDS slots, tables)
+    const int tc = KL > 1 ? (w < KL ? tl : -2) : t;         // ... for comparisons with a link number (no match on a lane without a link)
     const int64_t inst = (int64_t)blockIdx.x * (64 / G) + grp;
     const MechDev* M = a.M;
     const CtrlDev* C = a.C;
@@ -219,11 +253,14 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     const int nz = 13 * nb;
 
     LinkC c;
-    link_load_consts(c, M, t, nb, dt);
-    if (EXTRA && C->has_fric && c.on()) { c.fric = C->fric[t]; if (c.fric != 0.0) c.flags |= LinkC::FRIC; }
+    link_load_consts(c, M, (KL > 1 && w >= KL) ? CCLQR_MAXL : tl, nb, dt);
+    if (KL == 1 || w == 0) c.flags |= LinkC::PRIM;
+    SubSel Q;
+    if (KL > 1) sub_setup<KL>(c, w < KL ? w : 0, Q);
+    if (EXTRA && C->has_fric && c.on()) { c.fric = C->fric[tl]; if (c.fric != 0.0) c.flags |= LinkC::FRIC; }
     c.set_valid(inst < a.n_inst);
     const long long ginst = a.inst0 + inst;     // global instance index: selects the controller table when there is one per instance
-    const int ut = c.on() ? M->perm[t] : 0;      // user body index of the owned link
+    const int ut = c.on() ? M->perm[tl] : 0;      // user body index of the owned link
 
     LinkS S;
     double pid_int = 0.0, pid_last = 0.0;
@@ -231,14 +268,14 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     for (int i = 0; i < 7; i++) S.z[i] = c.live() ? a.z0[inst * nz + ut * 13 + i] : ((i == 3) ? 1.0 : 0.0);
 #pragma unroll
     for (int i = 0; i < 6; i++) S.s[i] = c.live() ? a.z0[inst * nz + ut * 13 + 7 + i] : 0.0;
-    if (EXTRA == 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + t) * 2]; pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
+    if (EXTRA == 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + tl) * 2]; pid_last = a.pid_state[(inst * nb + tl) * 2 + 1]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) { S.cd[i] = 0.0; S.d[i] = 0.0; S.ds[i] = 0.0; }
     for (int e = t; e < Y.total; e += G) L[e] = 0.0;
     __syncthreads();
-    if (c.live() && a.lam && a.k0 > 1) {
+    if (c.live() && (KL == 1 || c.prim()) && a.lam && a.k0 > 1) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = a.lam[inst * 5 * nb + 5 * t + i];
+        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * tl + i] = a.lam[inst * 5 * nb + 5 * tl + i];
     }
 
 #ifdef CCLQR_PROFILE
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         LINK_FLAGS_FRESH(c);
         double* const traj_out = ap->traj;
         if (traj_out) {     // Storage row of this step, staged through LDS in user body order so that the HBM stores coalesce
-            if (c.live()) {
+            if (c.live() && (KL == 1 || c.prim())) {
 #pragma unroll
                 for (int i = 0; i < 7; i++) L[Y.Z + 13 * ut + i] = S.z[i];
 #pragma unroll
@@ -297,9 +334,11 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         if (gate) {
             if (c.live()) {
                 double dz[12];
-                ck_control_error(zf, C->zd + ginst * C->zd_stride + (size_t)ksp * nz + 13 * t, dz);
+                ck_control_error(zf, C->zd + ginst * C->zd_stride + (size_t)ksp * nz + 13 * tl, dz);
+                if (KL == 1 || c.prim()) {
 #pragma unroll
-                for (int i = 0; i < 12; i++) L[Y.DZ + 12 * t + i] = dz[i];
+                    for (int i = 0; i < 12; i++) L[Y.DZ + 12 * tl + i] = dz[i];
+                }
                 if (EXTRA && C->has_fric && c.has_fric()) uj = ck_friction(c, zf, za);
             }
             __syncthreads();
@@ -351,21 +390,21 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                             const double s = group_sum<G>(part);
                             double u = fd[j] - s;
                             if (EXTRA) u += unoise;
-                            if (t == cjv[j]) uj += u;
+                            if (tc == cjv[j]) uj += u;
                         }
                     }
                 } else {                                     // feed-forward only (OpenLoop, a host closure's inputs)
                     for (int i = 0; i < mu; i++) {
                         double u = Fp ? Fp[i] : 0.0;
                         if (EXTRA) u += unoise;
-                        if (t == C->cj[i]) uj += u;
+                        if (tc == C->cj[i]) uj += u;
                     }
                 }
             }
             __syncthreads();
         }
         if (EXTRA == 2 && C->has_pid) {
-            if (c.live() && C->pid_on[t]) uj += ck_pid(c, zf, za, C->pid_P[t], C->pid_I[t], C->pid_D[t], C->pid_goal[t], dt, k == 1, pid_int, pid_last);
+            if (c.live() && C->pid_on[tl]) uj += ck_pid(c, zf, za, C->pid_P[tl], C->pid_I[tl], C->pid_D[tl], C->pid_goal[tl], dt, k == 1, pid_int, pid_last);
         }
         STAMP(PF_CONTROL);
         LINK_FLAGS_FRESH(c);
@@ -383,20 +422,20 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             double gk[5], kXT[3][3], kPB[5][3], kPA[5][3], lam[5];
             joint_eval_sparse<true>(c, za, za + 3, zf, zf + 3, nullptr, nullptr, gk, kXT, kPB, kPA);
 #pragma unroll
-            for (int i = 0; i < 5; i++) lam[i] = L[Y.LAM + 5 * t + i];
-            if (c.live()) {
-                gk_store(t, Y, L, kXT, kPB, kPA);
+            for (int i = 0; i < 5; i++) lam[i] = L[Y.LAM + 5 * tl + i];
+            if (c.live() && (KL == 1 || c.prim())) {
+                gk_store(tl, Y, L, kXT, kPB, kPA);
 #pragma unroll
-                for (int i = 0; i < 6; i++) L[Y.D + 6 * t + i] = cTR[i];
+                for (int i = 0; i < 6; i++) L[Y.D + 6 * tl + i] = cTR[i];
             }
             double own[6], par[6], cpar[6];
             jac_t_apply(c, kXT, kPB, kPA, lam, own, par);
             from_next<6>(par, cpar);
 #pragma unroll
             for (int i = 0; i < 6; i++) S.cd[i] = 0.0;
-            if (c.live()) {
+            if (c.live() && (KL == 1 || c.prim())) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) L[Y.C + 6 * t + i] = own[i] + (c.has_c() ? cpar[i] : 0.0);
+                for (int i = 0; i < 6; i++) L[Y.C + 6 * tl + i] = own[i] + (c.has_c() ? cpar[i] : 0.0);
             }
         }
         __syncthreads();
@@ -407,7 +446,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         const bool go = c.valid() && !c.dead();
         bool done = !go, failed = false;
         int its = 0;
-        double normf0 = chain_eval<G, true>(c, S, t, Y, L, 0.0, c.live() && !done, dt PROF_PASS);
+        double normf0 = chain_eval<G, true, KL>(c, S, tl, Y, L, 0.0, c.live() && !done, dt, Q PROF_PASS);
         __syncthreads();
         const int nchains = M->nchains;
         for (int iter = 1; iter <= NEWTON_MAXIT; iter++) {
@@ -468,19 +507,19 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 // through, so that they are dead -- 66 registers free -- while the solve runs
                 const MechDev* Mq = ap->M;
                 asm volatile("" : "+s"(Mq));
-                link_reload_consts(c, Mq, t, nb, dt);
+                link_reload_consts(c, Mq, tl, nb, dt);
             }
 #endif
             {   // multiplier step from LDS, body solve
                 double own[6], par[6], cpar[6], dl[5], pdn = 0.0;
 #pragma unroll
-                for (int r = 0; r < 5; r++) dl[r] = L[Y.DL + 5 * t + r];
-                gk_t_apply(c, t, Y, L, dl, own, par);
+                for (int r = 0; r < 5; r++) dl[r] = L[Y.DL + 5 * tl + r];
+                gk_t_apply(c, tl, Y, L, dl, own, par);
                 from_next<6>(par, cpar);
                 if (active) {
                     double DINV[9];
 #pragma unroll
-                    for (int i = 0; i < 9; i++) DINV[i] = L[Y.DINV + 9 * t + i];
+                    for (int i = 0; i < 9; i++) DINV[i] = L[Y.DINV + 9 * tl + i];
 #pragma unroll
                     for (int i = 0; i < 6; i++) S.cd[i] = own[i] + (c.has_c() ? cpar[i] : 0.0);
                     ck_body_solve(c, S.d, S.cd, DINV, S.ds);
@@ -488,6 +527,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     for (int i = 0; i < 6; i++) pdn += S.ds[i] * S.ds[i];
 #pragma unroll
                     for (int i = 0; i < 5; i++) pdn += dl[i] * dl[i];
+                    if (KL > 1 && !c.prim()) pdn = 0.0;
                 }
                 nd = sqrt(group_sum<G>(pdn));
             }
@@ -499,7 +539,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             double alpha = 1.0, normf1 = 0.0;
             bool ls_done = done, jac_ok = true;
             {
-                const double nf = chain_eval<G, true>(c, S, t, Y, L, 1.0, active, dt PROF_PASS);
+                const double nf = chain_eval<G, true, KL>(c, S, tl, Y, L, 1.0, active, dt, Q PROF_PASS);
                 if (!ls_done) {
                     normf1 = nf;
                     if (!(normf1 > normf0)) ls_done = true;
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                     const double* Lc = helping ? lds + (1 - grp) * Y.total : L;
                     const int l0 = helping ? lv + 2 : lv;
                     double n1, n2;
-                    chain_eval2<G>(c, T, Lc, t, Y, ldexp(1.0, -l0), ldexp(1.0, -(l0 + 1)), c.on() && (mine || helping) && l0 <= LINE_MAXIT, dt, n1, n2);
+                    chain_eval2<G, KL>(c, T, Lc, tl, Y, ldexp(1.0, -l0), ldexp(1.0, -(l0 + 1)), c.on() && (mine || helping) && l0 <= LINE_MAXIT, dt, n1, n2);
                     PCOUNT(PF_EVALS);
                     const double h1 = other_half(n1), h2 = other_half(n2);
                     if (mine) {
@@ -576,7 +616,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
 #pragma unroll
                         for (int i = 0; i < 6; i++) { T.s[i] = lane_fetch(S.s[i], fa); T.ds[i] = lane_fetch(S.ds[i], fa); T.cd[i] = lane_fetch(S.cd[i], fa); }
                     }
-                    const double nf = chain_eval1<G>(c, T, lds + src * Y.total, t, Y, ldexp(1.0, -l0), c.on() && work, dt);
+                    const double nf = chain_eval1<G, KL>(c, T, lds + src * Y.total, tl, Y, ldexp(1.0, -l0), c.on() && work, dt);
                     PCOUNT(PF_EVALS);
                     if (count == NG) {                                                            // (uniform) everybody searches: one level each, the group's own result
                         if (mine) {
@@ -600,10 +640,19 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
             bool need_jac = false;
             if (!done) {
                 if (c.live()) {
+                    if (KL == 1) {
 #pragma unroll
-                    for (int i = 0; i < 6; i++) { S.s[i] -= alpha * S.ds[i]; L[Y.C + 6 * t + i] -= alpha * S.cd[i]; S.cd[i] = 0.0; S.ds[i] = 0.0; }
+                        for (int i = 0; i < 6; i++) { S.s[i] -= alpha * S.ds[i]; L[Y.C + 6 * t + i] -= alpha * S.cd[i]; S.cd[i] = 0.0; S.ds[i] = 0.0; }
 #pragma unroll
-                    for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] -= alpha * L[Y.DL + 5 * t + i];
+                        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] -= alpha * L[Y.DL + 5 * t + i];
+                    } else {      // every lane of a link moves its own copy of the iterate; the link's LDS slots are the primary lane's to update
+#pragma unroll
+                        for (int i = 0; i < 6; i++) { S.s[i] -= alpha * S.ds[i]; if (c.prim()) L[Y.C + 6 * tl + i] -= alpha * S.cd[i]; S.cd[i] = 0.0; S.ds[i] = 0.0; }
+                        if (c.prim()) {
+#pragma unroll
+                            for (int i = 0; i < 5; i++) L[Y.LAM + 5 * tl + i] -= alpha * L[Y.DL + 5 * tl + i];
+                        }
+                    }
                 }
                 its = iter;
                 if (normf1 < NEWTON_EPS && alpha * nd < NEWTON_EPS) done = true;
@@ -613,7 +662,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
                 need_jac = !done && !jac_ok;
             }
             STAMP(PF_ACCEPT);
-            if (__any(need_jac)) chain_eval<G, true>(c, S, t, Y, L, 0.0, c.live() && need_jac, dt PROF_PASS);
+            if (__any(need_jac)) chain_eval<G, true, KL>(c, S, tl, Y, L, 0.0, c.live() && need_jac, dt, Q PROF_PASS);
             __syncthreads();
         }
         const bool conv = done && !failed;
@@ -640,7 +689,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
 #endif
     // ---------------- final state, multipliers, status
     __syncthreads();
-    if (c.live()) {
+    if (c.live() && (KL == 1 || c.prim())) {
 #pragma unroll
         for (int i = 0; i < 7; i++) L[Y.Z + 13 * ut + i] = S.z[i];
 #pragma unroll
@@ -655,16 +704,16 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         for (int e = t; e < nz; e += G) zT[inst * nz + e] = L[Y.Z + e];
         if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
     }
-    if (c.live()) {
+    if (c.live() && (KL == 1 || c.prim())) {
         const int nbT = ap->M->nb;      // read again here rather than kept in a scalar register through the launch
         double* lam = ap->lam;
         if (lam) {
 #pragma unroll
-            for (int i = 0; i < 5; i++) lam[inst * 5 * nbT + 5 * t + i] = L[Y.LAM + 5 * t + i];
+            for (int i = 0; i < 5; i++) lam[inst * 5 * nbT + 5 * tl + i] = L[Y.LAM + 5 * tl + i];
         }
         if (EXTRA == 2) {
             double* pid_state = ap->pid_state;
-            if (pid_state) { pid_state[(inst * nbT + t) * 2] = pid_int; pid_state[(inst * nbT + t) * 2 + 1] = pid_last; }
+            if (pid_state) { pid_state[(inst * nbT + tl) * 2] = pid_int; pid_state[(inst * nbT + tl) * 2 + 1] = pid_last; }
         }
     }
 }
@@ -686,20 +735,37 @@ int chain_layout_links(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ?
 
 size_t chain_lds_bytes(int nb) { return (size_t)(64 / chain_lanes_per_instance(nb)) * make_chain_layout(chain_layout_links(nb)).total * sizeof(double); }
 
-template <int G, int NBP>
+template <int G, int NBP, int KL = 1, int NL = G>
 static hipError_t launch_chain_one(const RolloutArgs& a, int extra, int newton_mode, unsigned grid, size_t lds, hipStream_t stream) {
     const bool relax = newton_mode != 0 && extra == 0;
-    const void* f = relax ? (const void*)rollout_chain_kernel<G, NBP, 0, true>
-                          : (extra == 0 ? (const void*)rollout_chain_kernel<G, NBP, 0> : (extra == 1 ? (const void*)rollout_chain_kernel<G, NBP, 1>
-                          : (extra == 2 ? (const void*)rollout_chain_kernel<G, NBP, 2> : (const void*)rollout_chain_kernel<G, NBP, 3>)));
+    const void* f = relax ? (const void*)rollout_chain_kernel<G, NBP, 0, true, KL, NL>
+                          : (extra == 0 ? (const void*)rollout_chain_kernel<G, NBP, 0, false, KL, NL> : (extra == 1 ? (const void*)rollout_chain_kernel<G, NBP, 1, false, KL, NL>
+                          : (extra == 2 ? (const void*)rollout_chain_kernel<G, NBP, 2, false, KL, NL> : (const void*)rollout_chain_kernel<G, NBP, 3, false, KL, NL>)));
     hipError_t e = set_max_dynamic_lds_once(f, lds);
     if (e != hipSuccess) return e;
-    if (relax) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0, true>), dim3(grid), dim3(64), lds, stream, a);
-    else if (extra == 0) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0>), dim3(grid), dim3(64), lds, stream, a);
-    else if (extra == 1) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 1>), dim3(grid), dim3(64), lds, stream, a);
-    else if (extra == 2) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 2>), dim3(grid), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 3>), dim3(grid), dim3(64), lds, stream, a);
+    if (relax) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0, true, KL, NL>), dim3(grid), dim3(64), lds, stream, a);
+    else if (extra == 0) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 0, false, KL, NL>), dim3(grid), dim3(64), lds, stream, a);
+    else if (extra == 1) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 1, false, KL, NL>), dim3(grid), dim3(64), lds, stream, a);
+    else if (extra == 2) hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 2, false, KL, NL>), dim3(grid), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((rollout_chain_kernel<G, NBP, 3, false, KL, NL>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
+}
+
+// lanes per link of the instantiation a mechanism of nb links runs on.  Only the 1- and 2-link mechanisms (pendulum, cartpole, acrobot: 2 of 8 lanes own a link)
+// get several -- three.  TWO lanes per link were built for every group with lanes to spare (3-4 links in 8 lanes, 5-8 in 16, 9-16 in 32), measured and NOT
+// shipped: the joint rows get cheaper (11.0 k -> 9.6 k cycles per step on the tracking triple cartpole) but the Schur rows do not (25.7 k -> 25.5 k) -- that phase is
+// bound by its ~180 LDS instructions per evaluation, which every lane issues whatever rows it keeps, not by its multiply-adds -- and the whole step moves by
+// < 0.5 % while the order of summation (hence noise-floor decisions of the stopping rule) changes (profiles/r05/lanes_per_link_*).
+// -DCHAIN_ONE_LANE_PER_LINK: one lane per link everywhere, -DCHAIN_TWO_LANES_PER_LINK: the measured-and-rejected shapes, both for A/B timing
+int chain_lanes_per_link(int nb) {
+#if defined(CHAIN_ONE_LANE_PER_LINK)
+    (void)nb;
+    return 1;
+#elif defined(CHAIN_TWO_LANES_PER_LINK)
+    return nb <= 2 ? 3 : (nb <= 16 ? 2 : 1);
+#else
+    return nb <= 2 ? 3 : 1;
+#endif
 }
 
 hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream) {
@@ -714,13 +780,24 @@ hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int new
         const Lay Y = make_chain_layout(nbp);
         if (Y.DL + 5 * (nbp + 1) > Y.total || Y.R + 5 * (nbp + 1) > Y.total) return hipErrorInvalidValue;
     }
+    const int kl = chain_lanes_per_link(nb);
     switch (chain_layout_links(nb)) {
+#if defined(CHAIN_TWO_LANES_PER_LINK)
+        case 4: return nb <= 2 ? launch_chain_one<8, 4, 3, 2>(a, extra, newton_mode, grid, lds, stream) : launch_chain_one<8, 4, 2, 4>(a, extra, newton_mode, grid, lds, stream);
+        case 8: return launch_chain_one<16, 8, 2, 8>(a, extra, newton_mode, grid, lds, stream);
+        case 16: return launch_chain_one<32, 16, 2, 16>(a, extra, newton_mode, grid, lds, stream);
+#elif defined(CHAIN_ONE_LANE_PER_LINK)
         case 4: return launch_chain_one<8, 4>(a, extra, newton_mode, grid, lds, stream);
         case 8: return launch_chain_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
         case 16: return launch_chain_one<32, 16>(a, extra, newton_mode, grid, lds, stream);
+#else
+        case 4: return nb <= 2 ? launch_chain_one<8, 4, 3, 2>(a, extra, newton_mode, grid, lds, stream) : launch_chain_one<8, 4>(a, extra, newton_mode, grid, lds, stream);
+        case 8: return launch_chain_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
+        case 16: return launch_chain_one<32, 16>(a, extra, newton_mode, grid, lds, stream);
+#endif
         case 17: return launch_chain_one<32, 17>(a, extra, newton_mode, grid, lds, stream);
         case 32: return launch_chain_one<32, 32>(a, extra, newton_mode, grid, lds, stream);
-        default: return launch_chain_one<64, 64>(a, extra, newton_mode, grid, lds, stream);
+        default: (void)kl; return launch_chain_one<64, 64>(a, extra, newton_mode, grid, lds, stream);
     }
 }
 

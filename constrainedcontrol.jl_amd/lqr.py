@@ -341,8 +341,8 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     # an instance whose step ended on a non-finite residual is LOST: the fused rollout freezes it at its last pose, at rest, for the rest of
     # the horizon (rollout_chain.hip, LinkC::DEAD).  A launch per step forgets that flag between launches, so it is carried here: a lost
     # instance's frozen state is written back after every later launch (the closure still sees it, as it sees the frozen pose in the fused run)
-    dead = torch.zeros(n, dtype=torch.bool, device=td)
-    zdead = torch.zeros_like(z)
+    dead = np.zeros(n, dtype=bool)
+    zdead = None                      # device copy of the lost instances' frozen states, made when the first one is lost
     stream = torch.cuda.current_stream().cuda_stream
     try:
         for k in range(1, steps + 1):
@@ -360,13 +360,16 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
             _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
             z, zn = zn, z
             s = st.cpu().numpy()
-            was_dead = dead.cpu().numpy()
-            live = ~was_dead                                                                  # (a lost instance is not stepped any more: its status stands)
-            lost = torch.from_numpy(live & (s <= 0) & (np.abs(s) < _capi.NEWTON_MAXIT)).to(td)      # stopped early = left the integrator's domain
-            if was_dead.any():
-                z[dead] = zdead[dead]
-            if bool(lost.any()):
-                zdead[lost] = z[lost]
+            live = ~dead                                                                       # (a lost instance is not stepped any more: its status stands)
+            lost = live & (s <= 0) & (np.abs(s) < _capi.NEWTON_MAXIT)                          # stopped early = left the integrator's domain
+            if dead.any():
+                idx = torch.from_numpy(np.flatnonzero(dead)).to(td)
+                z[idx] = zdead[idx]
+            if lost.any():
+                if zdead is None:
+                    zdead = torch.zeros_like(z)
+                idx = torch.from_numpy(np.flatnonzero(lost)).to(td)
+                zdead[idx] = z[idx]
                 dead |= lost
             bad |= live & (s <= 0)
             worst = np.where(live, np.maximum(worst, np.abs(s)), worst)

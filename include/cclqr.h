@@ -292,6 +292,11 @@ int cclqr_ctrl_set_feedforward(cclqr_ctrl *c, const double *Fd, int64_t len, int
  * for branching trees; 0 for closed-loop mechanisms, whose one kernel takes its layout at run time) */
 int cclqr_rollout_geometry(const cclqr_mech *m, int32_t *lanes_per_instance, int32_t *lds_bytes_per_workgroup);
 int cclqr_rollout_layout_links(const cclqr_mech *m, int32_t *links);
+/* lanes that work for ONE link and links per sub-lane group of the chain kernel's instantiation (rollout_chain_kernel<lanes, links, law, relax, lanes_per_link,
+ * links_per_group>): a forest of chains that leaves lanes of its lane group idle (1-2 links in 8 lanes: 3 lanes per link; 3-4 in 8, 5-8 in 16, 9-16 in 32: 2) deals
+ * the constraint rows of an evaluation to them at unchanged occupancy; 1 and the lane count for longer chains, branching trees and closed loops.  Bookkeeping
+ * for bench.py like the two above (no counterpart in the reference's simulate!, examples/lqr_cartpole.jl:44). */
+int cclqr_rollout_lanes_per_link(const cclqr_mech *m, int32_t *lanes_per_link, int32_t *links_per_group);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ static void cr_level_emu(int G, int cs, int cn, const cclqr::Lay& Y, double* L) 
     for (int t = 0; t < G; t++) if (K[t].act()) cr_store_b<W>(K[t], L, reinterpret_cast<const double(*)[5]>(tc[t].data()));
 }
 
+int g_lanes_per_link = 1;      // emu_chain_set_lanes_per_link: 2 / 3 = the evaluations with Jacobians go through the row-split forms of cclqr_chain.h
 struct LinkS { double z[7], s[6], ds[6], cd[6], d[6]; };
 struct LaneTmp { double xq[7], NB[9], g[5], wXT[3][3], wPB[5][3], wPA[5][3]; double part; };
 
@@ -61,6 +62,50 @@ double chain_eval(Inst& I, double alpha, bool active) {
             if (JAC) for (int k = 0; k < 9; k++) L[Y.DINV + 9 * t + k] = DINV[k];
         }
     }
+    if (JAC && g_lanes_per_link > 1) {
+        // several lanes per link (cclqr_chain.h): every sub-lane w of a link evaluates the rows of its slots and writes their Schur rows; together they
+        // must cover every entry the one-lane form writes (the LDS image starts as signalling NaNs)
+        for (int t = 0; t < G; t++) {
+            const LinkC& c = I.c[t];
+            if (!(active && c.on())) continue;
+            const double* pxq = c.has_a() ? I.T[t - 1].xq : ORIGIN13;
+            const double* pNB = c.has_a() ? I.T[t - 1].NB : I.T[t].NB;
+            const double* pd = c.has_a() ? I.S[t - 1].d : I.S[t].d;
+            for (int w = 0; w < g_lanes_per_link; w++) {
+                SubSel Q;
+                double g3[3], XT[3][3], PB[3][3], PA[3][3];
+                if (g_lanes_per_link == 3) {
+                    sub_setup<3>(c, w, Q);
+                    joint_eval_rows<3>(c, Q, pxq, pxq + 3, I.T[t].xq, I.T[t].xq + 3, pNB, I.T[t].NB, g3, XT, PB, PA);
+                    for (int i = 0; i < SubRows<3>::NR; i++) I.T[t].part += g3[i] * g3[i];
+                } else {
+                    sub_setup<2>(c, w, Q);
+                    joint_eval_rows<2>(c, Q, pxq, pxq + 3, I.T[t].xq, I.T[t].xq + 3, pNB, I.T[t].NB, g3, XT, PB, PA);
+                    for (int i = 0; i < SubRows<2>::NR; i++) I.T[t].part += g3[i] * g3[i];
+                }
+            }
+        }
+        for (int t = 0; t < G; t++) {     // (all evaluations first: a link's Schur rows read the parent's residual, as the kernel's wave shift does)
+            const LinkC& c = I.c[t];
+            if (!(active && c.on())) continue;
+            const double* pxq = c.has_a() ? I.T[t - 1].xq : ORIGIN13;
+            const double* pNB = c.has_a() ? I.T[t - 1].NB : I.T[t].NB;
+            const double* pd = c.has_a() ? I.S[t - 1].d : I.S[t].d;
+            for (int w = 0; w < g_lanes_per_link; w++) {
+                SubSel Q;
+                double g3[3], XT[3][3], PB[3][3], PA[3][3];
+                if (g_lanes_per_link == 3) {
+                    sub_setup<3>(c, w, Q);
+                    joint_eval_rows<3>(c, Q, pxq, pxq + 3, I.T[t].xq, I.T[t].xq + 3, pNB, I.T[t].NB, g3, XT, PB, PA);
+                    ck_schur_rows_sub<3>(c, Q, t, true, Y, L, g3, XT, PB, PA, I.S[t].d, pd);
+                } else {
+                    sub_setup<2>(c, w, Q);
+                    joint_eval_rows<2>(c, Q, pxq, pxq + 3, I.T[t].xq, I.T[t].xq + 3, pNB, I.T[t].NB, g3, XT, PB, PA);
+                    ck_schur_rows_sub<2>(c, Q, t, true, Y, L, g3, XT, PB, PA, I.S[t].d, pd);
+                }
+            }
+        }
+    } else {
     for (int t = 0; t < G; t++) {
         LaneTmp& T = I.T[t];
         const LinkC& c = I.c[t];
@@ -77,11 +122,14 @@ double chain_eval(Inst& I, double alpha, bool active) {
             const double* pd = c.has_a() ? I.S[t - 1].d : I.S[t].d;
             ck_schur_rows(c, t, true, Y, L, I.T[t].wXT, I.T[t].wPB, I.T[t].wPA, I.T[t].g, I.S[t].d, pd);
         }
+    }
     double acc = 0.0;
     for (int t = 0; t < G; t++) acc += I.T[t].part;
     return sqrt(acc);
 }
 }  // namespace
+
+extern "C" void emu_chain_set_lanes_per_link(int kl) { g_lanes_per_link = (kl == 2 || kl == 3) ? kl : 1; }
 
 extern "C" int emu_chain_rollout(const cclqr_mech_desc* md, const cclqr_ctrl_desc* cd, int64_t n_inst, int steps, int k0, const double* z0,
                                  const double* noise, double* traj, double* zT, int* status, int G_override) {

@@ -55,6 +55,34 @@ def test_emulated_rollout_matches_oracle(cclqr, orc, emu, n_links, steps, hangin
     assert np.abs(zT - zT_o).max() < 1e-10
 
 
+@pytest.mark.parametrize("n_links,kl,hanging", [(1, 3, False), (1, 2, False), (3, 2, False), (7, 2, True), (15, 2, True), (16, 3, True)])
+def test_emulated_rollout_with_several_lanes_per_link(cclqr, orc, emu, n_links, kl, hanging):
+    """round 5: mechanisms that leave lanes of their lane group idle give a link KL = 2 or 3 lanes and deal the rows of the joint evaluation and of the
+    Schur complement to them (cclqr_chain.h joint_eval_rows / ck_schur_rows_sub).  The emulator runs every evaluation with Jacobians through those forms --
+    all sub-lanes of a link one after the other, into an LDS image that starts as signalling NaNs, so an entry that no sub-lane writes poisons the
+    solve -- and the rollout must equal the oracle's as the one-lane form does (prismatic cart + revolute links: both row layouts; with a parent and without)."""
+    ex = cclqr.examples.cartpole_n(n_links)
+    t = ex["mech"].tables()
+    zd = hanging_setpoint(cclqr, n_links) if hanging else upright_setpoint(n_links)
+    rng = np.random.default_rng(14)
+    steps = 40 if n_links < 8 else 15
+    K = rng.normal(size=(steps + 19, 1, 12 * t.nb)) * 0.05
+    phi = rng.uniform(-1, 1, (2, n_links)) * (0.3 if hanging else 0.3 / 3 ** n_links)
+    if hanging:
+        phi[:, 0] += np.pi
+    z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, 2), phi)
+    octrl = orc.ctrl_desc(t.nb, [0], K=K, N=steps + 20, zd=zd)
+    zT_o, traj_o, st_o = orc.rollout(t, octrl, z0, steps, record=True)
+    emu.emu_chain_set_lanes_per_link(C.c_int(kl))
+    try:
+        zT, traj, st = emu_rollout(emu, orc, t, octrl, z0, steps)
+    finally:
+        emu.emu_chain_set_lanes_per_link(C.c_int(1))
+    # (Newton iteration counts: at the residual's round-off floor one decision of the stopping rule may move with the rows' order of summation)
+    assert (st_o > 0).all() and (st > 0).all() and np.abs(st - st_o).max() <= 1
+    assert np.abs(traj - traj_o).max() < 1e-10 and np.abs(zT - zT_o).max() < 1e-10
+
+
 def test_emulated_tracking_friction_noise(cclqr, orc, emu):
     ex = cclqr.examples.triple_cartpole()
     t = ex["mech"].tables()

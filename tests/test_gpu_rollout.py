@@ -686,6 +686,19 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
     assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
 
 
+def test_lanes_per_link_of_the_chain_instantiations(cclqr):
+    """cclqr_rollout_lanes_per_link: mechanisms of 1-2 links (2 of their 8 lanes own a link) run three lanes per link (rollout_chain_kernel<8, 4, law, relax, 3, 2>,
+    round 5: the rows of an evaluation with Jacobians dealt to a link's lanes at unchanged occupancy); everything else one lane per link"""
+    capi = cclqr._capi
+    for n_links, want in ((1, (3, 2)), (3, (1, 8)), (7, (1, 16)), (15, (1, 32)), (16, (1, 32)), (40, (1, 64))):
+        mech = capi.MechHandle(cclqr.examples.cartpole_n(n_links)["mech"].tables())
+        assert mech.lanes_per_link() == want, (n_links, mech.lanes_per_link())
+        mech.close()
+    pend = capi.MechHandle(cclqr.examples.pendulum()["mech"].tables())
+    assert pend.lanes_per_link() == (3, 2)
+    pend.close()
+
+
 def test_newton_mode_residual_only_is_a_measured_error_option(cclqr, orc):
     """cclqr_rollout_opts.newton_mode = 1 (stop on ||f|| < eps alone): NOT the parity mode.  The default stays the exact rule (= the
     oracle, checked here once more); the option's deviation from it is MEASURED and printed (2e-8 over these 200 steps under random

@@ -249,6 +249,38 @@ def test_custom_controlfunction_closure(cclqr, orc):
         cclqr.simulate(mech, 0.1, lqr_host, z0=z0, fric=fric)
 
 
+def test_custom_controlfunction_keeps_a_lost_instance_frozen(cclqr, orc):
+    """the fused rollout freezes an instance whose step ended on a non-finite residual (at its last pose, at rest, flagged) for the rest of the
+    horizon; the step-per-launch path of a host `controlfunction` forgets that flag between launches, so lqr.py carries it: the lost instance's frozen
+    state is restored after every later launch and its status stands.  A closure that hands instance 3 a NaN input at step 5 loses exactly that instance;
+    the others equal the run without the poison bit for bit."""
+    ex = cclqr.examples.cartpole_n(1)
+    mech = ex["mech"]
+    ids = [cclqr.getid(b) for b in ex["bodies"]]
+    rng = np.random.default_rng(6)
+    z0 = cclqr.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, 8), rng.uniform(0.0, 0.3, (8, 1)))
+
+    def law(batch, lqr, k):
+        cclqr.control_lqr(batch, lqr, k)
+
+    def law_poisoned(batch, lqr, k):
+        u = cclqr.control_lqr(batch, lqr, k)[:, 0].copy()
+        if k == 5:
+            u[3] = np.nan
+        cclqr.setForce(batch, mech.eqconstraints[0], u)
+
+    mk = lambda f: cclqr.LQR(mech, ids, [cclqr.getid(ex["ctrl"][0])], ex["Q"], ex["R"], 10.0, xd=ex["xd"], controlfunction=f)
+    clean = cclqr.simulate(mech, 0.4, mk(law), z0=z0)
+    lost = cclqr.simulate(mech, 0.4, mk(law_poisoned), z0=z0)
+    others = [i for i in range(8) if i != 3]
+    assert np.array_equal(lost.z[others], clean.z[others]) and np.array_equal(lost.status[others], clean.status[others])
+    assert lost.status[3] < 0 and (clean.status > 0).all()
+    # frozen from the step it was lost in: the pose of knot 5 (what step 5 started from), at rest, in every later record and in the final state
+    for k in range(5, 40):
+        assert np.array_equal(lost.z[3, k, :, 0:7], lost.z[3, 4, :, 0:7]) and not lost.z[3, k, :, 7:].any()
+    assert np.array_equal(lost.zT[3, :, 0:7], lost.z[3, 4, :, 0:7]) and not lost.zT[3, :, 7:].any()
+
+
 def test_lqr_pendulum_inf_horizon(cclqr, orc):
     """examples/lqr_pendulum.jl: horizon = Inf -> K = [Ku[1]] (lqr.jl:40-43), always-on feedback (lqr.jl:116-139)"""
     ex = cclqr.examples.pendulum()

@@ -565,3 +565,23 @@ def test_deltabot_holding_torque_is_the_references_number():
     h0, eps = z0[4, 2], 1e-6
     tau_vw = (V(h0 + eps) - V(h0 - eps)) / (angles(h0 + eps)[1] - angles(h0 - eps)[1]) / 2.0
     assert abs(abs(tau_vw) - 6.7879484) < 1e-6
+
+
+def test_loop_mechanism_flop_model(orc):
+    """oracle/loops.py flops_per_step (bench.py's roofline line of the closed-loop kernel): the step it counts on -- the dense-KKT Newton with the PARITY stopping
+    rule and line search -- ends at the same point as the plain dense-KKT step, takes at least as many iterations (the step-size half of the rule), and the
+    count is the sum of its parts: evaluations measured on the instrumented tree oracle, the dense Schur assembly and LU priced by their sizes"""
+    from oracle import loops
+    lm, z, u = loops.deltabot()
+    fm = loops.flops_model(lm)
+    assert fm["rows_m"] == 33 and fm["ordered_joint_pairs_sharing_a_body"] == 25           # 5 bodies with 2, 2, 2, 2, 3 joints around them: 4 * 4 + 9
+    assert fm["dense_lu_solve"] == pytest.approx(2 / 3 * 33 ** 3 + 2 * 33 ** 2)
+    assert 0 < fm["residual_evaluation"] < fm["evaluation_with_jacobians"] < fm["newton_iteration_without_line_search"]
+    lam = np.zeros(lm.nrows)
+    zz = z.copy()
+    for k in range(3):
+        fl, z2, lam2, its = loops.flops_per_step(lm, zz, lam, u * 0.98)
+        z1, lam1, it1 = lm.step(zz, lam, u * 0.98)
+        assert np.abs(z2 - z1).max() < 1e-12 and its >= it1 and its <= it1 + 2
+        assert fl > its * fm["newton_iteration_without_line_search"] and fl < (its + 1) * fm["newton_iteration_without_line_search"] + 12 * fm["residual_evaluation"]
+        zz, lam = z2, lam2

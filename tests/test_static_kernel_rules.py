@@ -44,7 +44,9 @@ UNIFORM = [r"^!?__any\(", r"^!?__all\(", r"^kk < nsteps$", r"^iter <= NEWTON_MAX
            # stop on s_pi -- a __shared__ word written by thread 0 and read by everyone behind a barrier
            r"^int o = PROJ_THREADS / 2; o > 0; o >>= 1$", r"^int k = 0; k < ml", r"^s_pi < 0$",
            # rollout_loop.hip loop_solve: mr = 5 M->nj; `rank` and the pivot it stops on come out of wave_max_key (v_readlane 63: the same in every lane)
-           r"^int k = 0; k < mr", r"^int k = rank - 1; k >= 0", r"^it <= ", r"^nsteps", r"^steps", r"^mode", r"^int kk = ", r"^rank < ", r"^int e = t; e < Y\.total"]
+           r"^int k = 0; k < mr", r"^int k = rank - 1; k >= 0", r"^it <= ", r"^nsteps", r"^steps", r"^mode", r"^int kk = ", r"^rank < ", r"^int e = t; e < Y\.total",
+           # rollout_chain.hip chain_eval (round 5): KL = lanes per link, a template parameter
+           r"^JAC && KL > 1$", r"^KL (>|==) \d$"]
 
 
 def strip_comments(txt):

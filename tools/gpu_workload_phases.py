@@ -6,7 +6,7 @@ import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package(); capi = pkg._capi
-capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libcclqr_prof.so")
+capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ.get("CCLQR_PROF_LIB", "libcclqr_prof.so"))
 import torch, bench
 cfg = sys.argv[1] if len(sys.argv) > 1 else "sawyer_cfg4"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400

@@ -93,10 +93,11 @@ __global__ __launch_bounds__(64, WPS) void micro_eval_linklane(MicroArgs a) {
     micro_forces(c, S, t, Y, L, M, dt, true);
     micro_direction(S, t);
     __syncthreads();
+    SubSel Qnone;      // (one lane per link: unused)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < a.reps; r++) {
         const double alpha = 1e-3 * (r + 1);
-        const double nrm = chain_eval<G, true>(c, S, t, Y, L, alpha, c.live(), dt);
+        const double nrm = chain_eval<G, true>(c, S, t, Y, L, alpha, c.live(), dt, Qnone);
         __syncthreads();
         if (t == 0 && c.valid()) a.norms[inst * a.reps + r] = nrm;
     }

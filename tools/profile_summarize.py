@@ -8,7 +8,7 @@ src, rnd = sys.argv[1], sys.argv[2]                     # e.g. gpurun_out/prof_r
 tag = sys.argv[3] if len(sys.argv) > 3 else "bench"
 # argv[4]: where the summary goes.  Default profiles/<round>/ (run here, on files merged back from the box); tools/profile_round.sh passes
 # gpurun_out/<dir>/summary so that it runs ON THE BOX and only the summaries travel back (the raw counter CSVs are tens of MiB)
-KERNEL = "rollout_chain_kernel<32, 17, 0, false>"
+KERNEL = "rollout_chain_kernel<32, 17, 0, false, 1, 32>"
 WAVES, STEPS, NINST = 4096.0, 1000.0, 8192.0
 dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
