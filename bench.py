@@ -637,7 +637,7 @@ def other_configs(pkg, capi, torch, dev, count=True):
     return out
 
 
-def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne, branches=(1, 4)):
+def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne, branches=(1, 2, 4)):
     """configs[4]'s "hipGraph-captured step": `steps` single-step launches (state and multipliers round-trip HBM between them, the Philox sample
     generated inside the step kernel) captured once and replayed.  branches = 1: ONE chain of launches over the whole batch -- every step waits for
     the slowest wavefront of the step before (the Newton iteration counts of the noise-floor line searches are heavy-tailed), which a persistent
