@@ -610,7 +610,14 @@ __device__ __forceinline__ bool gain_in_registers(int j, bool owner, int mx, int
 #pragma unroll
     for (int c = 0; c < MU; c++) {
         ok = ok && (Sr[c][c] > 0.0);
+#ifdef RIC_IEEE_DIV
         const double pinv = 1.0 / Sr[c][c];
+#else
+        // the pivot's reciprocal (v_rcp_f64 + two Newton steps, ~1 ulp: cclqr_dev.h fast_rcp) is kept in the pivot's place and MULTIPLIES in the back
+        // substitution: 14 IEEE division sequences (~ 100 dependent cycles each) sat on the critical path of every backward step between two barriers
+        const double pinv = fast_rcp(Sr[c][c]);
+        Sr[c][c] = pinv;
+#endif
 #pragma unroll
         for (int r = c + 1; r < MU; r++) Sr[r][c] *= pinv;
 #pragma unroll
@@ -629,7 +636,11 @@ __device__ __forceinline__ bool gain_in_registers(int j, bool owner, int mx, int
     for (int i = MU - 1; i >= 0; i--) {
 #pragma unroll
         for (int r = i + 1; r < MU; r++) x[i] -= Sr[i][r] * x[r];
+#ifdef RIC_IEEE_DIV
         x[i] = x[i] / Sr[i][i];
+#else
+        x[i] = x[i] * Sr[i][i];
+#endif
     }
 #pragma unroll
     for (int q = 0; q < MU; q++) { Ku[q * mx + j] = x[q]; Kdst[(size_t)q * mx + j] = x[q]; }   // Ku[k][i] = Kk[i:i,:]  lqr.jl:162-164
@@ -868,8 +879,17 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 const int ic = iok ? li : mu - 1, jc = jok ? j0 + li : na - 1;
                 const v4d acc = wave_tile16_db(mx >> 2, Dl + lk * mu + ic, 4 * mu, W + lk * na + jc, 4 * na);
                 if (jok) {
+                    const int j = j0 + li;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const int row = lk + 4 * r; if (row < mu) TS[row * na + j0 + li] = acc[r]; }
+                    for (int r = 0; r < 4; r++) {
+                        const int row = lk + 4 * r;
+                        if (row < mu) {
+                            TS[row * na + j] = acc[r];
+#ifndef RIC_S_SEPARATE
+                            if (j >= mx) S[row * mu + (j - mx)] = Rl[row * mu + (j - mx)] + acc[r];      // S = R + D'PkD (lqr.jl:152-153) leaves with the tile that holds D'W_D: no pass, no barrier of its own
+#endif
+                        }
+                    }
                 }
             }
         } else {
@@ -881,8 +901,13 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
             }
         }
         __syncthreads();
-        for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];       // S = R + D'PkD   lqr.jl:152-153
-        __syncthreads();
+#ifndef RIC_S_SEPARATE
+        if (mu > 16)
+#endif
+        {
+            for (int e = tid; e < mu * mu; e += RIC_THREADS) S[e] = Rl[e] + TS[(e / mu) * na + mx + e % mu];       // S = R + D'PkD   lqr.jl:152-153
+            __syncthreads();
+        }
         bool in_regs = false;
         if (MUT > 0) {                 // mu x mu system in registers (mu <= 7: every BASELINE config), see gain_in_registers
             double* Kdst = Kout + (a.keep_last ? 0 : (size_t)(k - 1) * mu * mx);
@@ -926,8 +951,8 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 for (int q = 0; q < mu; q++) { const double v = TS[q * na + j]; Ku[q * mx + j] = v; Kout[(a.keep_last ? 0 : (size_t)(k - 1) * mu * mx) + (size_t)q * mx + j] = v; }   // lqr.jl:162-164 (keep_last: one slot, the last step's gain stays)
                 for (int q = 0; q < mu; q++) { double sacc = 0.0; for (int r = 0; r < mu; r++) sacc += Rl[q * mu + r] * TS[r * na + j]; KRK[q * mx + j] = sacc; }
             }
+            __syncthreads();
         }
-        __syncthreads();
         RSTAMP(RP_GAIN);
         if (NGT > 0) {
             // Pk Abar = W_A' - W_D Kuk (in LDS) ; Abar = A' - D Kuk (= A-Bu*Kuk-Bλ*Kλk, lqr.jl:169): the wavefront's column strip of it, as the
