@@ -175,11 +175,15 @@ __device__ void wg_lu_solve(int n, MP LU, int lda, const int* piv, double* B, in
 // so a time-invariant problem computes them once.  Only Ku is stored by the reference (lqr.jl:162-164), Kλ is never formed.
 
 #ifdef CCLQR_PROFILE
-enum { RP_PA, RP_GAIN, RP_UPD, RP_PP, RP_NORM, RP_STEPS, RP_N };
+enum { RP_PA, RP_GAIN, RP_UPD, RP_PP, RP_NORM, RP_STEPS, RP_WAVE_W = 8, RP_WAVE_PP = 16, RP_N = 24 };      // RP_WAVE_*: per wavefront (block 0), cycles inside its own W / Pkp1 tiles
 static __device__ unsigned long long g_rprof[RP_N];
+#define RWAVE(c, t0_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_rprof[(c) + (threadIdx.x >> 6)] += __builtin_readcyclecounter() - (t0_); } while (0)
+#define RNOW() __builtin_readcyclecounter()
 #define RSTAMP(c) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t1_ = __builtin_readcyclecounter(); g_rprof[c] += t1_ - rt0; rt0 = t1_; } } while (0)
 #else
 #define RSTAMP(c)
+#define RWAVE(c, t0_)
+#define RNOW() 0ull
 #endif
 
 #define RIC_MU_REG 7   // the mu x mu system of a backward step is solved in registers up to this many inputs (8: spills under the 256-register budget)
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         }
         if (NGT > 0) {
             // W = Pk [A' | D]   (Pk symmetric): the wavefront's column block, its share of the row tiles; A operand from LDS, B from registers
+            const unsigned long long rw0 = RNOW(); (void)rw0;
             if (col >= 0) {
                 for (int rt = tlo; rt < thi; rt++) {
                     const int i0 = rt << 4;
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                     }
                 }
             }
+            RWAVE(RP_WAVE_W, rw0);
         } else {
             // W = Pk [A' | D]   (Pk symmetric)
             for (int tile = wave; tile < t16m * t16n; tile += RIC_WAVES) {
@@ -1035,6 +1041,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
         RSTAMP(RP_UPD);
         // Pkp1 = Q + Kuk'*R*Kuk + Abar'*(Pk*Abar), over Pk; |Pk - Pkp1|^2 on the way                                lqr.jl:170-176
         double nacc = 0.0;
+        const unsigned long long rp0 = RNOW(); (void)rp0;
         if (NGT > 0) {
             if (pp_col) {        // tiles (row strip i0 = col * 16, column tile ct) of the SYMMETRIC Pkp1 that ric_pp_assign dealt to this wavefront, each
                                  // mirrored into (ct, col): A operand from registers (Abar fragment), B operand Pk Abar from LDS
@@ -1116,6 +1123,7 @@ __global__ __launch_bounds__(RIC_THREADS) void riccati_resident_kernel(RicGrid a
                 }
             }
         }
+        RWAVE(RP_WAVE_PP, rp0);
         RSTAMP(RP_NORM);       // (diagnostic build: wavefront 0's own Pkp1 tiles end here; RP_PP below = operand prefetch, norm reduction, barrier waits)
         if (k > 1 && BF == 0) {
             if (FRAG64) fetch_next(k - 1);         // (the fragment was last read by this wavefront's tiles above; D waits in registers)

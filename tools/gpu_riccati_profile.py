@@ -19,7 +19,7 @@ else:
 mx, mu, ml = A.shape[0], Bu.shape[1], Bl.shape[1]
 Q = np.eye(mx) * 0.01; R = np.eye(mu) * 0.01
 rep = lambda M: np.tile(M[None], (nprob, 1, 1))
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 24)()
 capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, 3)   # warm
 capi.lib().cclqr_ric_prof_read(buf, 1)
 t0 = time.time(); K, kb = capi.riccati(rep(A), rep(Bu), rep(Bl), rep(G), Q, R, N); dt = time.time() - t0
@@ -31,3 +31,5 @@ kbs = np.atleast_1d(kb); done = (N - np.maximum(kbs, 1) + 1).sum()
 print("%s mx=%d mu=%d ml=%d nprob=%d N=%d: %.3fs total, %.3f ms/backward-step/problem-wave, kbreak %s, %.1f GFLOP/s (F_ric=%.3g)" % (name, mx, mu, ml, nprob, N, dt, 1e3 * dt / max(1, N - kbs.min()), kbs[:3], F * done / dt / 1e9, F))
 for i, n in enumerate(["W = P [A'|D]", "D'W, mu x mu solve, Ku", "Abar, P Abar updates", "prefetch, norm, barriers", "Pkp1 tiles of wavefront 0"]):
     print("  %-24s %6.2f%%  %9.0f cycles/step" % (n, 100 * v[i] / tot, v[i] / steps))
+if v.size >= 24:
+    print("  per wavefront, cycles per step inside its own tiles:  W " + " ".join("%5.0f" % (x / steps) for x in v[8:16]) + "   Pkp1 " + " ".join("%5.0f" % (x / steps) for x in v[16:24]))
