@@ -375,20 +375,34 @@ HD void ck_next_pose(const double* z, const double* s, double dt, double* xq) {
 //   S_jc = W_b[j] Gk_a[c]'                      -> SPJ[c]      (c = j+1, when has_c: "S_{parent,child}" of the child's slot)
 //   r_j  = g_j - W_b d_b - W_a d_a              -> R[j]        (pd = residual of the parent body, from the parent lane)
 // One column q of the three blocks at a time.
+// the G_k operands of column q of the three blocks (own, parent's and child's joint): 21 doubles (12 for the rotational columns q = 3, 4)
+struct SchurCol { double kx[3], kpx[3], kcx[3], kb[3], ka[3], kpb[3], kca[3]; };
+HD void schur_col_load(SchurCol& K, int q, int j, int jp, int jc, const Lay& Y, const double* L) {
+    const int o = gk_row(q), ob = q < 3 ? 3 : 0;   // offset of PB inside the row
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (q < 3) { K.kx[i] = L[Y.GKA + GKSZ * j + o + i]; K.kpx[i] = L[Y.GKA + GKSZ * jp + o + i]; K.kcx[i] = L[Y.GKA + GKSZ * jc + o + i]; }
+        else { K.kx[i] = 0.0; K.kpx[i] = 0.0; K.kcx[i] = 0.0; }
+        K.kb[i] = L[Y.GKA + GKSZ * j + o + ob + i]; K.ka[i] = L[Y.GKA + GKSZ * j + o + ob + 3 + i];
+        K.kpb[i] = L[Y.GKA + GKSZ * jp + o + ob + i]; K.kca[i] = L[Y.GKA + GKSZ * jc + o + ob + 3 + i];
+    }
+}
+// PF: the operands of column q + 1 are requested before column q is computed (two operand sets live: + 42 registers, which the 8- and 16-lane instantiations
+// have and the 17-link one does not -- there it was measured slower, DESIGN_HISTORY 9b).  The phase is a chain of five load -> compute -> store stages at one
+// wavefront per SIMD; without the prefetch every stage pays its LDS round trip in full.  Same arithmetic either way.
+template <bool PF = false>
 HD void ck_schur_rows(const LinkC& c, int j, bool store, const Lay& Y, double* L, const double (*wXT)[3], const double (*wPB)[3],
                       const double (*wPA)[3], const double* g, const double* d, const double* pd) {
     const double sx = c.sxb + c.sxa;
     const int jp = c.has_a() ? j - 1 : j, jc = c.has_c() ? j + 1 : j;
+    SchurCol KA, KB;
+    if (PF) schur_col_load(KA, 0, j, jp, jc, Y, L);
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-        const int o = gk_row(q), ob = q < 3 ? 3 : 0;   // offset of PB inside the row
-        double kx[3] = {0, 0, 0}, kpx[3] = {0, 0, 0}, kcx[3] = {0, 0, 0}, kb[3], ka[3], kpb[3], kca[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            if (q < 3) { kx[i] = L[Y.GKA + GKSZ * j + o + i]; kpx[i] = L[Y.GKA + GKSZ * jp + o + i]; kcx[i] = L[Y.GKA + GKSZ * jc + o + i]; }
-            kb[i] = L[Y.GKA + GKSZ * j + o + ob + i]; ka[i] = L[Y.GKA + GKSZ * j + o + ob + 3 + i];
-            kpb[i] = L[Y.GKA + GKSZ * jp + o + ob + i]; kca[i] = L[Y.GKA + GKSZ * jc + o + ob + 3 + i];
-        }
+        SchurCol& K = PF ? ((q & 1) ? KB : KA) : KA;
+        if (!PF) schur_col_load(K, q, j, jp, jc, Y, L);
+        else if (q < 4) { schur_col_load((q & 1) ? KA : KB, q + 1, j, jp, jc, Y, L); SCHED_FENCE(); }
+        const double *kx = K.kx, *kpx = K.kpx, *kcx = K.kcx, *kb = K.kb, *ka = K.ka, *kpb = K.kpb, *kca = K.kca;
         double ojj[5], ojp[5], ojc[5];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
@@ -561,25 +575,23 @@ HD void joint_eval_rows(const LinkC& c, const SubSel& Q, const double* xa, const
         }
 }
 // the lane's rows of S_jj, S_jp, S_jc and r_j (ck_schur_rows for the rows of its slots; element (r, q) of a block at 5 q + r)
-template <int KL>
+template <int KL, bool PF = false>
 HD void ck_schur_rows_sub(const LinkC& c, const SubSel& Q, int j, bool store, const Lay& Y, double* L, const double* g, const double (*XT)[3], const double (*PB)[3],
                           const double (*PA)[3], const double* d, const double* pd) {
     constexpr int NR = SubRows<KL>::NR;
     const double sx = c.sxb + c.sxa;
     const int jp = c.has_a() ? j - 1 : j, jc = c.has_c() ? j + 1 : j;
     int idx[3] = {Q.ia, Q.ib, Q.ic};
+    SchurCol KA, KB;
+    if (PF) schur_col_load(KA, 0, j, jp, jc, Y, L);
 #pragma unroll
     for (int q = 0; q < 5; q++) {
         // (the "slot is empty" tests are made per column, where the stores are: hoisted out of the loop they are three 64-bit lane masks in scalar registers)
         LANE_INT_FRESH(idx[0]); LANE_INT_FRESH(idx[1]); LANE_INT_FRESH(idx[2]);
-        const int o = gk_row(q), ob = q < 3 ? 3 : 0;
-        double kx[3] = {0, 0, 0}, kpx[3] = {0, 0, 0}, kcx[3] = {0, 0, 0}, kb[3], ka[3], kpb[3], kca[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            if (q < 3) { kx[i] = L[Y.GKA + GKSZ * j + o + i]; kpx[i] = L[Y.GKA + GKSZ * jp + o + i]; kcx[i] = L[Y.GKA + GKSZ * jc + o + i]; }
-            kb[i] = L[Y.GKA + GKSZ * j + o + ob + i]; ka[i] = L[Y.GKA + GKSZ * j + o + ob + 3 + i];
-            kpb[i] = L[Y.GKA + GKSZ * jp + o + ob + i]; kca[i] = L[Y.GKA + GKSZ * jc + o + ob + 3 + i];
-        }
+        SchurCol& K = PF ? ((q & 1) ? KB : KA) : KA;
+        if (!PF) schur_col_load(K, q, j, jp, jc, Y, L);
+        else if (q < 4) { schur_col_load((q & 1) ? KA : KB, q + 1, j, jp, jc, Y, L); SCHED_FENCE(); }
+        const double *kx = K.kx, *kpx = K.kpx, *kcx = K.kcx, *kb = K.kb, *ka = K.ka, *kpb = K.kpb, *kca = K.kca;
 #pragma unroll
         for (int s = 0; s < NR; s++) {
             const bool xpart = q < 3 && s != 1;          // slot B is a rotational row: no x part

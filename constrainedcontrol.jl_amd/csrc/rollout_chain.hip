@@ -87,7 +87,9 @@ __device__ __forceinline__ double chain_eval(LinkC& c, LinkS& S, int t, const La
         LINK_FLAGS_FRESH(c);
         double pd[6];
         from_prev<6>(S.d, pd);
-        ck_schur_rows_sub<KL>(c, Q, t, active, Y, L, gs, sXT, sPB, sPA, S.d, pd);
+        // (the next column's operands are requested ahead on the three-lane shape, which has the registers: cartpole 160.0 -> 163.0 M; measured 0 / - 0.3 % on the
+        // one-lane 8- and 16-lane kernels -- tracking cfg5, Sawyer -- which therefore keep the plain form)
+        ck_schur_rows_sub<KL, (KL == 3)>(c, Q, t, active, Y, L, gs, sXT, sPB, sPA, S.d, pd);
         STAMP(PF_SCHUR_S);
     } else {
         double wXT[3][3], wPB[5][3], wPA[5][3];
