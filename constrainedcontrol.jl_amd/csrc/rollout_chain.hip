@@ -241,6 +241,9 @@ template <int G, int NBP, int EXTRA, bool RELAX = false, int KL = 1, int NL = G>
 __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     static_assert(KL >= 1 && KL <= 3 && KL * NL <= G && (KL > 1 || NL == G) && (KL == 1 || NL <= NBP), "lane group too small for KL lanes per link");
+#if defined(CHAIN_DIAG_EXIT) && CHAIN_DIAG_EXIT == 1
+    if (a.steps == 0) return;                                // (diagnostic build, tools/gpu_launch_overhead.py: what a launch costs with NO kernel body)
+#endif
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
     const int w = KL > 1 ? t / NL : 0;                      // sub-lane of the lane's link
     const int tl = KL > 1 ? t - NL * w : t;                 // the link the lane works for (LDS slots, tables)
@@ -261,6 +264,9 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     if (KL > 1) sub_setup<KL>(c, w < KL ? w : 0, Q);
     if (EXTRA && C->has_fric && c.on()) { c.fric = C->fric[tl]; if (c.fric != 0.0) c.flags |= LinkC::FRIC; }
     c.set_valid(inst < a.n_inst);
+#if defined(CHAIN_DIAG_EXIT) && CHAIN_DIAG_EXIT == 3
+    if (a.steps == 0) { if (t == 0 && c.valid()) a.status[inst] = (int)(c.m + c.J[8] + c.sxa + c.qoc[3] + c.V12[5] + c.p1[2] + c.p2[2] + c.axis[2]); return; }      // (diagnostic: link constants only)
+#endif
     const long long ginst = a.inst0 + inst;     // global instance index: selects the controller table when there is one per instance
     const int ut = c.on() ? M->perm[tl] : 0;      // user body index of the owned link
 
@@ -273,13 +279,27 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     if (EXTRA == 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + tl) * 2]; pid_last = a.pid_state[(inst * nb + tl) * 2 + 1]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) { S.cd[i] = 0.0; S.d[i] = 0.0; S.ds[i] = 0.0; }
+#if defined(CHAIN_DIAG_EXIT) && CHAIN_DIAG_EXIT == 4
+    if (a.steps == 0) { if (t == 0 && c.valid()) a.status[inst] = (int)(S.z[0] + S.s[5] + c.m); return; }      // (diagnostic: constants + state)
+#endif
+#ifdef CHAIN_LDS_ZERO_FILL
     for (int e = t; e < Y.total; e += G) L[e] = 0.0;
     __syncthreads();
-    if (c.live() && (KL == 1 || c.prim()) && a.lam && a.k0 > 1) {
+#endif
+    // What the Newton phases read before they have written it is the multiplier block only (tests/emu/emu_chain.cpp runs every phase function on an
+    // LDS image poisoned with signalling NaNs but for LAM): zero, or the caller's warm start.  Everything else in the image is discarded by a
+    // select wherever a phase reads past what was produced (ck_tri_back / cr_back), so it is not cleared: at one step per launch (configs[4]'s
+    // graph mode) clearing 601 doubles per instance was 2.3 of the launch's 6.5 us (profiles/r05/launch_overhead.json).
+    if (c.on() && (KL == 1 || c.prim())) {
+        const bool warm = c.live() && a.lam && a.k0 > 1;
 #pragma unroll
-        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * tl + i] = a.lam[inst * 5 * nb + 5 * tl + i];
+        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * tl + i] = warm ? a.lam[inst * 5 * nb + 5 * tl + i] : 0.0;
     }
+    __syncthreads();
 
+#if defined(CHAIN_DIAG_EXIT) && CHAIN_DIAG_EXIT == 2
+    if (a.steps == 0) { if (t == 0 && c.valid()) a.status[inst] = (int)(S.z[0] + L[Y.LAM + 5 * tl]); return; }      // (diagnostic: prologue only)
+#endif
 #ifdef CCLQR_PROFILE
     Prof prof;
     prof.start();
@@ -690,6 +710,21 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     prof.flush();
 #endif
     // ---------------- final state, multipliers, status
+#ifdef CHAIN_DIRECT_FINAL_STORE
+    asm volatile("" : "+s"(ap));
+    LINK_FLAGS_FRESH(c);
+    if (c.live() && (KL == 1 || c.prim())) {
+        double* zT = ap->zT;
+#pragma unroll
+        for (int i = 0; i < 7; i++) zT[inst * nz + 13 * ut + i] = S.z[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zT[inst * nz + 13 * ut + 7 + i] = S.s[i];
+    }
+    if (c.valid()) {
+        int* status = ap->status;
+        if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
+    }
+#else
     __syncthreads();
     if (c.live() && (KL == 1 || c.prim())) {
 #pragma unroll
@@ -706,6 +741,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         for (int e = t; e < nz; e += G) zT[inst * nz + e] = L[Y.Z + e];
         if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
     }
+#endif
     if (c.live() && (KL == 1 || c.prim())) {
         const int nbT = ap->M->nb;      // read again here rather than kept in a scalar register through the launch
         double* lam = ap->lam;

@@ -473,7 +473,8 @@ def test_chain_rollout_kernel_resources(tmp_path):
             # its first pass -- the same v_accvgpr moves as the ~230 values it places there itself, never memory (scratch == 0 above): the
             # 32-lane kernels with the reduction level and the two-level / partner-assisted line search carry up to 8 of them, the rest none
             # (the 8- and 16-lane kernels carry up to 8 since their line search hands trial points to idle groups: TrialIn, round 4)
-            assert k["vgpr_spill"] <= (8 if (reduction_level or G <= 16) else 0), (name, k)
+            # (the measured-error 8-lane kernel: 12 since the prologue stopped clearing the LDS image)
+            assert k["vgpr_spill"] <= (16 if G == 8 else 8 if (reduction_level or G <= 16) else 0), (name, k)
             # the instantiations with the odd-even reduction level (32 lanes, <= 17 links) park more values in AGPRs around it
             assert k["vgpr"] <= (504 if reduction_level else 440), (name, k)
         elif variant == 1:
