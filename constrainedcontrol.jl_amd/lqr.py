@@ -297,13 +297,20 @@ def state_error(batch, controller, k):
     """Δz [n_inst][12 nb] of lqr.jl:92-103 / lqr_tracking.jl:49-62 about the controller's setpoint of step k (bodies in mechanism order)"""
     zd = controller.zd
     d = zd[min(k - 1, zd.shape[0] - 1)] if zd.shape[0] > 1 else zd[0]
-    z = batch.z
-    qd = d[:, 3:7] * np.array([1.0, -1.0, -1.0, -1.0])
-    s0, v0 = qd[:, 0], qd[:, 1:]
-    s1, v1 = z[:, :, 3], z[:, :, 4:7]
-    qe = s0[None, :, None] * v1 + s1[:, :, None] * v0[None] + np.cross(np.broadcast_to(v0[None], v1.shape), v1)      # vector part of qd \ q
-    dz = np.concatenate([z[:, :, 0:3] - d[None, :, 0:3], z[:, :, 7:10] - d[None, :, 7:10], qe, z[:, :, 10:13] - d[None, :, 10:13]], axis=2)
-    return dz.reshape(z.shape[0], -1)
+    zt = batch.z.transpose(1, 2, 0)             # [nb][13][n_inst]
+    nb, n = zt.shape[0], zt.shape[2]
+    # One [n_inst] plane per component: the batch that simulate hands a closure is stored that way (_simulate_hosted), so every operand below is a
+    # contiguous run of n_inst numbers (an instance-major array goes through the same code as strided planes, a few times slower)
+    dzt = np.empty((nb, 12, n))
+    np.subtract(zt[:, 0:3], d[:, 0:3, None], out=dzt[:, 0:3])
+    np.subtract(zt[:, 7:10], d[:, 7:10, None], out=dzt[:, 3:6])
+    np.subtract(zt[:, 10:13], d[:, 10:13, None], out=dzt[:, 9:12])
+    s0, ax, ay, az = d[:, 3, None], -d[:, 4, None], -d[:, 5, None], -d[:, 6, None]           # qd' = (s0, a): the conjugate of the setpoint's quaternion
+    s1, bx, by, bz = zt[:, 3], zt[:, 4], zt[:, 5], zt[:, 6]
+    dzt[:, 6] = s0 * bx + s1 * ax + (ay * bz - az * by)                                      # vector part of qd \ q = s0 b + s1 a + a x b
+    dzt[:, 7] = s0 * by + s1 * ay + (az * bx - ax * bz)
+    dzt[:, 8] = s0 * bz + s1 * az + (ax * by - ay * bx)
+    return dzt.reshape(12 * nb, n).T
 
 
 def control_lqr(batch, lqr, k):
@@ -315,7 +322,7 @@ def control_lqr(batch, lqr, k):
         dz = state_error(batch, lqr, k)
         K = lqr.K[0] if lqr.N <= 0 else lqr.K[min(k - 1, lqr.K.shape[0] - 1)]
         Fd = lqr.Fd[min(k - 1, lqr.Fd.shape[0] - 1)] if lqr.Fd.shape[0] > 1 else lqr.Fd[0]
-        u = Fd[None, :] - dz @ K.reshape(mu, -1).T
+        u = Fd[None, :] - (K.reshape(mu, -1) @ dz.T).T     # (this association: [mu][12 nb] x [12 nb][n_inst] is a row-major product whichever way Δz is stored)
         for i, e in enumerate(lqr.eqcids):
             setForce(batch, e, u[:, i])
     return u
@@ -344,22 +351,34 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     dead = np.zeros(n, dtype=bool)
     zdead = None                      # device copy of the lost instances' frozen states, made when the first one is lost
     stream = torch.cuda.current_stream().cuda_stream
+    # The states reach the closure through one page-locked buffer, transposed on the device to one [n_inst] plane per state component: BatchState.z
+    # is a [n_inst][nb][13] VIEW of it (valid during the call: the next step overwrites it), so that a closure's numpy slices z[:, b, i] are contiguous
+    # runs of n_inst numbers.  The recorded trajectory is copied instance-major in a second transfer.
+    zt_pinned = torch.empty((nb, 13, n), dtype=torch.float64, pin_memory=True)
+    zh = zt_pinned.numpy().transpose(2, 0, 1)
+    za_pinned = torch.empty(z.shape, dtype=torch.float64, pin_memory=True) if record else None
+    U_pinned = torch.zeros((n, len(joints)), dtype=torch.float64, pin_memory=True)
+    U, U_dev = U_pinned.numpy(), torch.zeros((n, len(joints)), dtype=torch.float64, device=td)
+    st_pinned = torch.zeros(n, dtype=torch.int32, pin_memory=True)
     try:
         for k in range(1, steps + 1):
-            zh = z.cpu().numpy()      # (synchronises the stream: the previous launch no longer reads the feed-forward table set_feedforward rewrites below)
+            zt_pinned.copy_(z.permute(1, 2, 0))     # (synchronises the stream: the previous launch no longer reads the feed-forward table set_feedforward rewrites below)
             if record:
-                traj[:, k - 1] = zh
+                za_pinned.copy_(z)
+                traj[:, k - 1] = za_pinned.numpy()
             batch = BatchState(mechanism, zh, k)
             controller.controlfunction(batch, controller, k)
-            U = np.zeros((n, len(joints)))
+            U[:] = 0.0
             for j, u in batch.u.items():
                 if j not in slot:
                     raise ValueError("setForce on a constraint without a degree of freedom")
                 U[:, slot[j]] = u
-            ctrl.set_feedforward(U)
+            U_dev.copy_(U_pinned, non_blocking=True)      # (page-locked -> device on the launch's stream; the table is replaced device to device behind it)
+            ctrl.set_feedforward(dev_ptr=U_dev.data_ptr(), length=U_dev.numel(), stream=stream)
             _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
             z, zn = zn, z
-            s = st.cpu().numpy()
+            st_pinned.copy_(st)                            # (waits for the step: U_pinned may be rewritten after this)
+            s = st_pinned.numpy()
             live = ~dead                                                                       # (a lost instance is not stepped any more: its status stands)
             lost = live & (s <= 0) & (np.abs(s) < _capi.NEWTON_MAXIT)                          # stopped early = left the integrator's domain
             if dead.any():
