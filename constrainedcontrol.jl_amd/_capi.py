@@ -18,9 +18,10 @@ _ERRNAME = {EINVAL: "CCLQR_EINVAL", ESINGULAR: "CCLQR_ESINGULAR", ENOCONV: "CCLQ
 EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set_device", "cclqr_mech_create", "cclqr_mech_destroy",
            "cclqr_ctrl_create", "cclqr_ctrl_create_lqr_batch", "cclqr_ctrl_destroy", "cclqr_linearize", "cclqr_linearize_projected", "cclqr_riccati", "cclqr_riccati_tv", "cclqr_riccati_tracking", "cclqr_rollout",
            "cclqr_rollout_dev", "cclqr_rollout_ex", "cclqr_rollout_host_ex", "cclqr_ctrl_reserve_noise", "cclqr_riccati_ex", "cclqr_riccati_tracking_ex",
-           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout", "cclqr_rollout_lanes_per_link"]
+           "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout", "cclqr_rollout_lanes_per_link", "cclqr_rollout_instances_per_wavefront"]
 ABI_VERSION = 201     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header (verified field by field against cclqr_abi_layout at load time)
 ROLLOUT_NO_ALLOC = 1  # cclqr_rollout_opts.flags: the call may neither allocate nor synchronise (a hipGraph capture is open on the device)
+ROLLOUT_PACK_WAVEFRONTS = 2  # ... every wavefront of a chain launch full, whatever the batch size (many launches sharing the device at once)
 PHILOX_INKERNEL_STEPS = 8
 NEWTON_MAXIT = 100      # newtonIter of ConstrainedDynamics' newton!: |status| of an instance that hit the cap
 
@@ -172,6 +173,12 @@ class MechHandle:
         check(lib().cclqr_rollout_lanes_per_link(self.ptr, C.byref(kl), C.byref(nl)))
         return kl.value, nl.value
 
+    def instances_per_wavefront(self, n_inst, steps, flags=0):
+        """instances one wavefront of such a launch holds (chains: a small batch is spread over more wavefronts unless ROLLOUT_PACK_WAVEFRONTS)"""
+        v = C.c_int32(0)
+        check(lib().cclqr_rollout_instances_per_wavefront(self.ptr, C.c_int64(int(n_inst)), C.c_int32(int(steps)), C.c_int32(int(flags)), C.byref(v)))
+        return v.value
+
     def close(self):
         if self.ptr:
             lib().cclqr_mech_destroy(self.ptr)
@@ -268,7 +275,7 @@ class BatchLqrHandle:
             pass
 
 
-def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instance=0, newton_mode=0, newton_eps_alone=0.0):
+def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instance=0, newton_mode=0, newton_eps_alone=0.0, flags=0):
     """host-pointer rollout: returns (zT, traj or None, status)"""
     nb = mech.tables.nb
     z0 = f64(z0).reshape(-1, nb, 13)
@@ -277,7 +284,7 @@ def rollout(mech, ctrl, z0, steps, k0=1, noise=None, record=False, first_instanc
     zT = np.zeros_like(z0)
     status = np.zeros(n, dtype=np.int32)
     noise = None if noise is None else f64(noise).reshape(n, steps)
-    o = RolloutOpts(int(first_instance), None, 0, None, 0, int(newton_mode), 0, float(newton_eps_alone))
+    o = RolloutOpts(int(first_instance), None, 0, None, 0, int(newton_mode), int(flags), float(newton_eps_alone))
     check(lib().cclqr_rollout_host_ex(mech.ptr, ctrl.ptr, C.c_int64(n), C.c_int32(steps), C.c_int32(k0), _d(z0), _d(noise), _d(traj), _d(zT),
                                       _i(status), C.byref(o)))
     return zT, traj, status
@@ -287,7 +294,7 @@ def rollout_dev(mech, ctrl, n_inst, steps, k0, z0_ptr, lam_ptr, noise_ptr, noise
                 first_instance=None, pid_state=None, noise_ws=None, noise_ws_len=0, newton_mode=0, newton_eps_alone=0.0, flags=0):
     """device-pointer rollout (integers are raw device addresses, e.g. torch.Tensor.data_ptr()); asynchronous.
     Options (cclqr_rollout_opts): first_instance, pid_state = device address of [n_inst][joints][2] doubles, noise_ws / noise_ws_len = caller's
-    Philox workspace, newton_mode, flags (ROLLOUT_NO_ALLOC: what a caller with a hipGraph capture open passes); none given: cclqr_rollout_dev
+    Philox workspace, newton_mode, flags (ROLLOUT_NO_ALLOC: what a caller with a hipGraph capture open passes; ROLLOUT_PACK_WAVEFRONTS); none given: cclqr_rollout_dev
     (= NULL options)"""
     vp = lambda p: C.c_void_p(int(p)) if p else None
     if first_instance is None and pid_state is None and noise_ws is None and not newton_mode and not flags:

@@ -341,6 +341,14 @@ extern "C" int cclqr_rollout_lanes_per_link(const cclqr_mech* m, int32_t* lanes_
     return CCLQR_OK;
 }
 
+extern "C" int cclqr_rollout_instances_per_wavefront(const cclqr_mech* m, int64_t n_inst, int32_t steps, int32_t flags, int32_t* instances) {
+    if (!m || !instances) return fail(CCLQR_EINVAL, "null argument");
+    if (m->host.loop) *instances = 1;
+    else if (m->host.tree) *instances = spread_instances_per_wavefront(64 / treereg_lanes(m->nb, m->host.tree), n_inst, steps, (flags & CCLQR_ROLLOUT_PACK_WAVEFRONTS) != 0);
+    else *instances = chain_instances_per_wavefront(m->nb, n_inst, steps, (flags & CCLQR_ROLLOUT_PACK_WAVEFRONTS) != 0);
+    return CCLQR_OK;
+}
+
 extern "C" int cclqr_rollout_geometry(const cclqr_mech* m, int32_t* lanes, int32_t* lds_bytes) {
     if (!m) return fail(CCLQR_EINVAL, "null argument");
     if (m->host.loop) { if (lanes) *lanes = 64; if (lds_bytes) *lds_bytes = (int32_t)loop_lds_bytes(m->nb, m->nj); return CCLQR_OK; }
@@ -376,7 +384,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     // which only ever grows OUTSIDE stream capture: hipMalloc / hipFree are illegal while a stream is being captured, so a captured
     // launch needs the workspace sized beforehand (cclqr_ctrl_reserve_noise) or passed in.
     const bool use_noise = H.noise_scale != 0.0 && H.mu > 0;
-    if (opts && (opts->flags & ~CCLQR_ROLLOUT_NO_ALLOC)) return fail(CCLQR_EINVAL, "unknown bit in cclqr_rollout_opts.flags");
+    if (opts && (opts->flags & ~(CCLQR_ROLLOUT_NO_ALLOC | CCLQR_ROLLOUT_PACK_WAVEFRONTS))) return fail(CCLQR_EINVAL, "unknown bit in cclqr_rollout_opts.flags");
     const bool no_alloc = opts && (opts->flags & CCLQR_ROLLOUT_NO_ALLOC);
     // launches of a few steps on forests of chains (the step-per-launch form a hipGraph replays, BASELINE configs[4]) generate their samples inside the
     // rollout kernel (rollout_chain_kernel<.., 3>): one kernel per step instead of two, and no workspace that could have to grow
@@ -416,6 +424,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     RolloutArgs a;
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
+    a.ipw = (opts && (opts->flags & CCLQR_ROLLOUT_PACK_WAVEFRONTS)) ? 1 : 0;
     const int newton_mode = opts ? opts->newton_mode : 0;
     a.eps_alone = (opts && opts->newton_eps_alone > 0.0) ? opts->newton_eps_alone : 1e-10;
     if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");

@@ -24,6 +24,8 @@ struct RolloutArgs {
     double* zT;           // [n_inst][nb][13]
     int* status;          // [n_inst] or null
     double eps_alone;     // measured-error Newton mode (RELAX kernels only): a solve also stops when ||f|| falls below this
+    int ipw;              // chain and tree kernels: instances per wavefront, 1 .. 64 / lanes per instance (lane groups beyond it hold no instance).  The caller of
+                          // launch_rollout_chain / launch_rollout_treereg passes 0 (the launch chooses: chain_instances_per_wavefront) or nonzero = pack every wavefront full
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) instead of once per launch: remembers the largest size set so
@@ -36,6 +38,8 @@ int chain_lanes_per_instance(int nb);
 int chain_layout_links(int nb);
 int chain_lanes_per_link(int nb);
 size_t chain_lds_bytes(int nb);
+int chain_instances_per_wavefront(int nb, int64_t n_inst, int steps, bool packed);
+int spread_instances_per_wavefront(int full, int64_t n_inst, int steps, bool packed);      // the rule itself (rollout_chain.hip); full = 64 / lanes per instance
 hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream);
 // closed-loop mechanisms (rollout_loop.hip)
 size_t loop_lds_bytes(int nb, int nj);

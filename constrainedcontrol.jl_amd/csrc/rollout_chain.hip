@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     const int w = KL > 1 ? t / NL : 0;                      // sub-lane of the lane's link
     const int tl = KL > 1 ? t - NL * w : t;                 // the link the lane works for (LDS slots, tables)
     const int tc = KL > 1 ? (w < KL ? tl : -2) : t;         // ... for comparisons with a link number (no match on a lane without a link)
-    const int64_t inst = (int64_t)blockIdx.x * (64 / G) + grp;
+    const int64_t inst = (int64_t)blockIdx.x * a.ipw + grp;
     const MechDev* M = a.M;
     const CtrlDev* C = a.C;
     const int nb = M->nb;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     SubSel Q;
     if (KL > 1) sub_setup<KL>(c, w < KL ? w : 0, Q);
     if (EXTRA && C->has_fric && c.on()) { c.fric = C->fric[tl]; if (c.fric != 0.0) c.flags |= LinkC::FRIC; }
-    c.set_valid(inst < a.n_inst);
+    c.set_valid(grp < a.ipw && inst < a.n_inst);
 #if defined(CHAIN_DIAG_EXIT) && CHAIN_DIAG_EXIT == 3
     if (a.steps == 0) { if (t == 0 && c.valid()) a.status[inst] = (int)(c.m + c.J[8] + c.sxa + c.qoc[3] + c.V12[5] + c.p1[2] + c.p2[2] + c.axis[2]); return; }      // (diagnostic: link constants only)
 #endif
@@ -771,6 +771,32 @@ int chain_lanes_per_instance(int nb) { return nb <= 4 ? 8 : (nb <= 8 ? 16 : (nb 
 // links the LDS image is laid out for: the instantiations below (17 = the headline mechanism: exactly four workgroups per CU)
 int chain_layout_links(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : (nb == 17 ? 17 : (nb <= 32 ? 32 : 64)))); }
 
+// Instances per wavefront of a launch.  A wavefront's step is latency -- a chain of dependent 5 x 5 stages -- not lanes, and a lane group without an
+// instance is not idle: it evaluates further step lengths of its neighbours' line searches (group_assist / the partner group).  So a batch that would
+// leave SIMDs without a wavefront when packed 64 / G to a wavefront is spread: the fewest instances per wavefront that still fit the batch into
+// `slots` wavefronts -- slots = every SIMD of the device for a persistent launch (steps >= 8: it has the device to itself), a quarter of them for
+// short launches (step-per-launch chains run several to a device, bench.py::_graph_captured_steps: spreading each over the whole device would
+// queue them behind one another).  Measured (tools/gpu_batch_density.py, ms per 1000 steps, packed -> spread): 256 tracking triple cartpoles
+// 43.7 -> 34.7, 256 cartpoles 24.6 -> 21.5, 256 17-body chains (300 steps) 22.0 -> 20.2, 4096 cartpoles (configs[1]) 24.9 -> 24.0; a batch that
+// fills the device is packed as before.  Same arithmetic in the same order either way: results are bitwise those of the packed launch
+// (tests/test_gpu_rollout.py::test_spread_and_packed_launches_agree_bitwise).  packed: CCLQR_ROLLOUT_PACK_WAVEFRONTS.  `full` = 64 / lanes per
+// instance; the branching-tree kernel (rollout_treereg.hip) spreads by the same rule.
+int spread_instances_per_wavefront(int full, int64_t n_inst, int steps, bool packed) {
+    if (packed || full == 1) return full;
+    static int simds = 0;
+    if (simds == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        simds = 4 * cus;
+    }
+    const int64_t slots = steps >= 8 ? simds : simds / 4;
+    const int64_t ipw = (n_inst + slots - 1) / slots;
+    return ipw < 1 ? 1 : (ipw > full ? full : (int)ipw);
+}
+int chain_instances_per_wavefront(int nb, int64_t n_inst, int steps, bool packed) {
+    return spread_instances_per_wavefront(64 / chain_lanes_per_instance(nb), n_inst, steps, packed);
+}
+
 size_t chain_lds_bytes(int nb) { return (size_t)(64 / chain_lanes_per_instance(nb)) * make_chain_layout(chain_layout_links(nb)).total * sizeof(double); }
 
 template <int G, int NBP, int KL = 1, int NL = G>
@@ -806,10 +832,11 @@ int chain_lanes_per_link(int nb) {
 #endif
 }
 
-hipError_t launch_rollout_chain(const RolloutArgs& a, int nb, int extra, int newton_mode, hipStream_t stream) {
-    const int G = chain_lanes_per_instance(nb);
-    const int per_wg = 64 / G;
+hipError_t launch_rollout_chain(const RolloutArgs& a_in, int nb, int extra, int newton_mode, hipStream_t stream) {
+    const int per_wg = chain_instances_per_wavefront(nb, a_in.n_inst, a_in.steps, a_in.ipw != 0);
     const size_t lds = chain_lds_bytes(nb);
+    RolloutArgs a = a_in;
+    a.ipw = per_wg;
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;
     {   // the reduction level's back substitution reads DL / R of one link past the chain and selects the value away (cclqr_chain.h cr_back): that

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x, t = lane % G, grp = lane / G;
     const int gb4 = 4 * (lane - t);
-    const int64_t inst = (int64_t)blockIdx.x * (64 / G) + grp;
+    const int64_t inst = (int64_t)blockIdx.x * a.ipw + grp;      // (a.ipw instances per wavefront: cclqr_internal.h)
     const MechDev* M = a.M;
     const TreeRegDev* R = treereg_of(M);
     const CtrlDev* C = a.C;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
     const int pa4 = gb4 + 4 * T.par;
     if (T.nchild > 0) c.flags |= 4;          // "has a child link" (link_load_consts reads the chains' single-child table)
     if (EXTRA && C->has_fric && c.on()) { c.fric = C->fric[t]; if (c.fric != 0.0) c.flags |= LinkC::FRIC; }
-    c.set_valid(inst < a.n_inst);
+    c.set_valid(grp < a.ipw && inst < a.n_inst);
     const long long ginst = a.inst0 + inst;
     const int ut = c.on() ? M->perm[t] : 0;
 
@@ -559,9 +559,11 @@ static hipError_t launch_treereg_one(const RolloutArgs& a, int extra, int newton
 }
 
 // a.M must be the device image [MechDev | TreeRegDev] of capi.hip (treereg_of)
-hipError_t launch_rollout_treereg(const RolloutArgs& a, int nb, int tree8, int npairs, int extra, int newton_mode, hipStream_t stream) {
+hipError_t launch_rollout_treereg(const RolloutArgs& a_in, int nb, int tree8, int npairs, int extra, int newton_mode, hipStream_t stream) {
     const int G = treereg_lanes(nb, tree8), nbp = treereg_layout_links(nb, tree8);
-    const int per_wg = 64 / G;
+    const int per_wg = spread_instances_per_wavefront(64 / G, a_in.n_inst, a_in.steps, a_in.ipw != 0);
+    RolloutArgs a = a_in;
+    a.ipw = per_wg;
     const size_t lds = treereg_lds_bytes(nb, tree8, npairs);
     const unsigned grid = (unsigned)((a.n_inst + per_wg - 1) / per_wg);
     if (grid == 0) return hipSuccess;

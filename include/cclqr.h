@@ -243,8 +243,15 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *                   stream it is issued on).  A launch that would have to grow the handle's Philox workspace is then refused with
  *                   CCLQR_EINVAL (the message names cclqr_ctrl_reserve_noise) before anything is touched, whether or not `stream` itself is
  *                   capturing; without the flag the library still refuses on a capturing `stream` (it can see that one) and grows otherwise;
+ *                   CCLQR_ROLLOUT_PACK_WAVEFRONTS: forests of chains and branching trees: 64 / lanes-per-instance instances in every wavefront whatever the batch
+ *                   size.  Without it a batch too small to give every SIMD a wavefront that way is spread over more wavefronts (the spare lane
+ *                   groups take part in their neighbours' line searches: up to 20 % less time per step at a few hundred instances; a persistent
+ *                   launch, steps >= 8, spreads over the whole device, a shorter one over a quarter of it) -- bitwise the same results.  Set it
+ *                   when MANY launches share the device at once (more than four concurrent step-per-launch chains, several processes on one
+ *                   GPU): spread launches then queue behind one another;
  *   newton_eps_alone  threshold of mode 1 (<= 0: 1e-10, the rule's own eps: stop on the residual alone). */
 #define CCLQR_ROLLOUT_NO_ALLOC 1
+#define CCLQR_ROLLOUT_PACK_WAVEFRONTS 2
 #define CCLQR_PHILOX_INKERNEL_STEPS 8
 typedef struct {
     int64_t first_instance;
@@ -297,6 +304,9 @@ int cclqr_rollout_layout_links(const cclqr_mech *m, int32_t *links);
  * the constraint rows of an evaluation to them at unchanged occupancy; 1 and the lane count for longer chains, branching trees and closed loops.  Bookkeeping
  * for bench.py like the two above (no counterpart in the reference's simulate!, examples/lqr_cartpole.jl:44). */
 int cclqr_rollout_lanes_per_link(const cclqr_mech *m, int32_t *lanes_per_link, int32_t *links_per_group);
+/* instances a launch of n_inst instances x steps steps with these cclqr_rollout_opts.flags puts into one wavefront (fewer than 64 / lanes-per-instance
+ * when the batch is spread, see CCLQR_ROLLOUT_PACK_WAVEFRONTS; closed loops: always 1).  Bookkeeping. */
+int cclqr_rollout_instances_per_wavefront(const cclqr_mech *m, int64_t n_inst, int32_t steps, int32_t flags, int32_t *instances);
 
 #ifdef __cplusplus
 }

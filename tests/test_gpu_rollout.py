@@ -681,9 +681,58 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
     with pytest.raises(capi.CclqrError):
         capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20 - 1)
     with pytest.raises(capi.CclqrError):        # unknown flag bits are refused
-        capi.rollout_dev(mech, ctrl, n, 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), flags=2)
+        capi.rollout_dev(mech, ctrl, n, 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), flags=4)
     zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0[:16], 20)
     assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
+
+
+@pytest.mark.parametrize("n_links,ninst,steps,extra", [(1, 37, 120, False), (3, 21, 100, True), (7, 9, 80, False), (16, 5, 60, False), (22, 3, 40, False)])
+def test_spread_and_packed_launches_agree_bitwise(cclqr, n_links, ninst, steps, extra):
+    """A batch too small to give every SIMD a wavefront is spread over more wavefronts (rollout_chain.hip::chain_instances_per_wavefront: the lane
+    groups without an instance work on their neighbours' line searches); CCLQR_ROLLOUT_PACK_WAVEFRONTS packs 64 / lanes-per-instance instances
+    into every wavefront as a device-filling batch is.  Same arithmetic in the same order: trajectories, final states and Newton counts are
+    bitwise equal -- so every small parity test of this suite, which runs spread, also stands for the packed layout of the full-size ones.
+    Both a persistent launch and single-step launches (whose spreading target is a quarter of the device)."""
+    import torch
+    capi = cclqr._capi
+    rng = np.random.default_rng(40 + n_links)
+    if extra:
+        ex = cclqr.examples.triple_cartpole()
+        z0 = np.tile(ex["mech"].state(), (ninst, 1, 1))
+    else:
+        ex = cclqr.examples.cartpole_n(n_links)
+        phi = rng.uniform(-0.3, 0.3, (ninst, n_links))
+        phi[:, 0] += np.pi
+        z0 = cclqr.examples.cartpole_states(n_links, rng.uniform(-0.5, 0.5, ninst), phi)
+    t = ex["mech"].tables()
+    mech = capi.MechHandle(t)
+    kw = dict(K=rng.normal(size=(steps + 5, 1, 12 * t.nb)) * 0.05, N=steps + 6, zd=z0[0], Fd=np.array([[0.3]]))
+    if extra:
+        kw.update(fric=ex["fric"], noise_scale=0.5, noise_seed=77)
+    ctrl = capi.CtrlHandle(mech, [0], **kw)
+    full = 64 // mech.geometry()[0]
+    assert mech.instances_per_wavefront(ninst, steps) == 1 and mech.instances_per_wavefront(ninst, steps, capi.ROLLOUT_PACK_WAVEFRONTS) == full
+    assert mech.instances_per_wavefront(4096, 1000) == min(4, full) and mech.instances_per_wavefront(4096, 1) == full       # (1024 SIMDs; short launches: a quarter)
+    a = capi.rollout(mech, ctrl, z0, steps, record=True)
+    b = capi.rollout(mech, ctrl, z0, steps, record=True, flags=capi.ROLLOUT_PACK_WAVEFRONTS)
+    assert (a[2] > 0).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for flags in (0, capi.ROLLOUT_PACK_WAVEFRONTS):
+        z = torch.from_numpy(z0).to(dev)
+        zn = torch.empty_like(z)
+        lam = torch.zeros((ninst, 5 * t.ne), dtype=torch.float64, device=dev)
+        s = torch.zeros(ninst, dtype=torch.int32, device=dev)
+        for k in range(1, 11):
+            capi.rollout_dev(mech, ctrl, ninst, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), s.data_ptr(), 0, flags=flags)
+            z, zn = zn, z
+        torch.cuda.synchronize()
+        outs.append((z.cpu().numpy(), lam.cpu().numpy(), s.cpu().numpy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs[0][0], a[1][:, 10])         # ten single-step launches = the first ten steps of the persistent one (traj[:, k] = the state after k steps)
 
 
 def test_lanes_per_link_of_the_chain_instantiations(cclqr):

@@ -179,3 +179,25 @@ def test_whole_sawyer_robot_lqr_pipeline(cclqr, orc):
     _, traj, sto = orc.rollout(t, oc, z0, 150, record=True)
     assert (sto > 0).all() and np.array_equal(st.status > 0, sto > 0)
     assert np.abs(st.z - traj).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["dual_cartpole", "deep"])
+def test_tree_spread_and_packed_launches_agree_bitwise(cclqr, name):
+    """the tree kernel spreads a small batch over more wavefronts by the chain kernels' rule (rollout_chain.hip::spread_instances_per_wavefront);
+    CCLQR_ROLLOUT_PACK_WAVEFRONTS packs them as a device-filling batch is: bitwise the same trajectories and Newton counts"""
+    capi = cclqr._capi
+    ex = build(cclqr, name)
+    t = ex["mech"].tables()
+    rng = np.random.default_rng(9)
+    z0 = _starts(cclqr, ex, rng, 7)
+    steps, cj = 50, [0, t.ne - 1]
+    h = capi.MechHandle(t)
+    full = 64 // h.geometry()[0]
+    assert h.instances_per_wavefront(7, steps) == 1 and h.instances_per_wavefront(7, steps, capi.ROLLOUT_PACK_WAVEFRONTS) == full
+    assert h.instances_per_wavefront(10 ** 6, steps) == full
+    ctrl = capi.CtrlHandle(h, cj, K=rng.normal(size=(steps + 5, 2, 12 * t.nb)) * 0.05, N=steps + 6, zd=z0[0], Fd=rng.normal(size=(1, 2)) * 0.3)
+    a = capi.rollout(h, ctrl, z0, steps, record=True)
+    b = capi.rollout(h, ctrl, z0, steps, record=True, flags=capi.ROLLOUT_PACK_WAVEFRONTS)
+    assert (a[2] > 0).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

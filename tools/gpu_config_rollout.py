@@ -36,6 +36,7 @@ else:
     raise SystemExit("unknown config " + cfg)
 r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=reps, kernel=kern if cfg == "deltabot" else bench.kernel_name(mh, extra))
 lanes, lds = mh.geometry()
-r.update(config=cfg, lanes_per_instance=lanes, instances_per_wavefront=64 // lanes, wavefronts=(len(z0) + 64 // lanes - 1) // (64 // lanes),
+ipw = mh.instances_per_wavefront(len(z0), steps)
+r.update(config=cfg, lanes_per_instance=lanes, instances_per_wavefront=ipw, wavefronts=(len(z0) + ipw - 1) // ipw,
          lds_bytes_per_workgroup=lds, workgroups_per_cu_by_lds=int(160 * 1024 // lds))
 print(json.dumps(r))
