@@ -456,14 +456,14 @@ def roofline_fp64(f_step, n, steps, kernel_ms, kernel):
             "flops_per_instance_step_counted_by_oracle": f_step, "kernel": kernel, "kernel_ms": kernel_ms}
 
 
-def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_failed=False, f_step=None, kernel=None):
+def _timed_rollout(capi, torch, dev, mh, ctrl, z0, steps, record, reps=3, allow_failed=False, f_step=None, kernel=None, flags=0):
     n, nb = z0.shape[0], z0.shape[1]
     z0_d = torch.from_numpy(np.ascontiguousarray(z0)).to(dev)
     zT_d = torch.empty_like(z0_d)
     st_d = torch.zeros(n, dtype=torch.int32, device=dev)
     traj_d = torch.empty((n, steps, nb, 13), dtype=torch.float64, device=dev) if record else None
     stream = torch.cuda.current_stream().cuda_stream
-    run = lambda: capi.rollout_dev(mh, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(), st_d.data_ptr(), stream)
+    run = lambda: capi.rollout_dev(mh, ctrl, n, steps, 1, z0_d.data_ptr(), 0, 0, 0, traj_d.data_ptr() if record else 0, zT_d.data_ptr(), st_d.data_ptr(), stream, flags=flags)
     run()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]

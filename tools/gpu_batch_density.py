@@ -1,5 +1,7 @@
 """diagnostic (not a test): instances per wavefront against the batch size -- the chain kernels at batches that leave SIMDs without a wavefront when every
-wavefront is packed full (64 / lanes-per-instance instances), with CCLQR_IPW forcing the density.  python tools/gpu_batch_density.py"""
+wavefront is packed full (64 / lanes-per-instance instances): the launch as shipped (spread by rollout_chain.hip::spread_instances_per_wavefront) against
+CCLQR_ROLLOUT_PACK_WAVEFRONTS.  (profiles/r05/batch_density.txt came from an experiment build whose density an environment variable forced: every density per batch size.)
+python tools/gpu_batch_density.py"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,13 +13,12 @@ dev = torch.device("cuda", 0)
 out = {}
 
 
-def run(tag, mh, ctrl, z0, steps, extra, ipws):
+def run(tag, mh, ctrl, z0, steps, extra, ipws=None):
     for n in sorted({min(len(z0), m) for m in (64, 256, 1024, 2048, 4096, 8192)}):
         row = {}
-        for ipw in ipws:
-            os.environ["CCLQR_IPW"] = str(ipw)
-            r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0[:n], steps, False, reps=2, kernel=bench.kernel_name(mh, extra))
-            row[ipw] = round(r["ms_per_rollout"], 3)
+        for name, flags in (("spread", 0), ("packed", capi.ROLLOUT_PACK_WAVEFRONTS)):
+            r = bench._timed_rollout(capi, torch, dev, mh, ctrl, z0[:n], steps, False, reps=2, kernel=bench.kernel_name(mh, extra), flags=flags)
+            row["%s (%d per wavefront)" % (name, mh.instances_per_wavefront(n, steps, flags))] = round(r["ms_per_rollout"], 3)
         out.setdefault(tag, {})[n] = row
         print(tag, n, row, flush=True)
 
