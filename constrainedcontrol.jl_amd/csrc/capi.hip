@@ -125,6 +125,7 @@ extern "C" int cclqr_mech_create(const cclqr_mech_desc* d, cclqr_mech** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->dev, image.size());
     if (e == hipSuccess) e = hipMemcpy(m->dev, image.data(), image.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete m; return fail(CCLQR_EHIP, std::string("mechanism upload: ") + hipGetErrorString(e)); }
+    (void)spread_instances_per_wavefront(2, 1, 8, false);      // (reads the device's compute-unit count once, here: never inside a caller's hipGraph capture)
     *out = m;
     return CCLQR_OK;
 }
