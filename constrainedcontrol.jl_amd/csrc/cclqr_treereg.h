@@ -23,8 +23,8 @@ namespace cclqr {
 #ifndef TR_G16_MAXLINKS
 #define TR_G16_MAXLINKS 8      // (experiment switch: 16 = four instances of a 9..16-link tree per wavefront)
 #endif
-#define TR_MAXSTEP 32      // steps of a schedule (<= links)
-#define TR_LANES 32        // lanes per instance at most
+#define TR_MAXSTEP 64      // steps of a schedule (<= links)
+#define TR_LANES 64        // lanes per instance at most (33 .. 64 links: the whole wavefront is one instance, round 5)
 // what one lane does in one step of the elimination / of the back substitution (all LDS offsets relative to the instance's image):
 //   elimination, lane (group g of link l, column c < 5):  z = S_ll^-1 S_{l,x_g}[:, c];  S_{x_g', x_g}[:, c] -= S_{x_g', l} z for every g';  z -> S_{l,x_g}[:, c]
 //                lane (group 0, c == 5):                  y = S_ll^-1 r_l;               r_{x_g'} -= S_{x_g', l} y;                          y -> r_l
@@ -214,8 +214,9 @@ HD void tr_back(const TrRec& K, double* L) {
 
 // lanes per instance and links of the image the kernel is instantiated for: 16 lanes when the mechanism has at most 8 links and no link
 // with more than two neighbours left at its elimination (tree8 = 8 x the largest neighbour count, MechDev::tree), else 32
-HD int treereg_lanes(int nb, int tree8) { return (nb <= TR_G16_MAXLINKS && tree8 <= 16) ? 16 : 32; }
+HD int treereg_lanes(int nb, int tree8) { return nb > 32 ? 64 : ((nb <= TR_G16_MAXLINKS && tree8 <= 16) ? 16 : 32); }
 HD int treereg_layout_links(int nb, int tree8) {
+    if (nb > 32) return nb <= 48 ? 48 : 64;
     const int n = nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? (nb + 1) / 2 * 2 : (nb <= 24 ? 24 : 32)));       // 10, 12, 14, 16: a 14-link image lets four workgroups share a CU
     return (treereg_lanes(nb, tree8) == 32 && n < 8) ? 8 : n;       // the instantiations of rollout_treereg.hip
 }

@@ -575,6 +575,7 @@ hipError_t launch_rollout_treereg(const RolloutArgs& a_in, int nb, int tree8, in
 #endif
         return nbp == 4 ? launch_treereg_one<16, 4>(a, extra, newton_mode, grid, lds, stream) : launch_treereg_one<16, 8>(a, extra, newton_mode, grid, lds, stream);
     }
+    if (G == 64) return nbp == 48 ? launch_treereg_one<64, 48>(a, extra, newton_mode, grid, lds, stream) : launch_treereg_one<64, 64>(a, extra, newton_mode, grid, lds, stream);
     switch (nbp) {
         case 8: return launch_treereg_one<32, 8>(a, extra, newton_mode, grid, lds, stream);
         case 10: return launch_treereg_one<32, 10>(a, extra, newton_mode, grid, lds, stream);

@@ -27,7 +27,7 @@ extern "C" {
 #define CCLQR_ESINGULAR -2    /* G*Bl or M singular        (LAPACK exception from lqr.jl:151,160) */
 #define CCLQR_ENOCONV -3      /* soft: Newton / Riccati did not converge (lqr.jl:41 `@info`) */
 #define CCLQR_EHIP -4         /* HIP runtime error; cclqr_last_error() has the text */
-#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (> 4 child joints on a body, nb > 64 -- branching trees: nb > 32 --, loop mechanisms beyond 8 bodies / 12 joints) */
+#define CCLQR_EUNSUPPORTED -5 /* valid for the reference, outside this build's scope (> 4 child joints on a body, nb > 64, loop mechanisms beyond 8 bodies / 12 joints) */
 
 /* ABI version = cclqr_version().  A shim built against another header must refuse to run: the structs below are passed by pointer and
  * read in full.  200: cclqr_ctrl_desc.n_ctrl, cclqr_rollout_opts {noise_ws_dev, noise_ws_len, newton_mode}, cclqr_riccati_opts.keep_last,
@@ -43,7 +43,7 @@ extern "C" {
 
 /* Mechanism(origin, bodies, eqconstraints; g, Δt) -- examples/lqr_cartpole.jl:32.
  * A tree of nb bodies, each hung off its parent (or the origin, -1) by one 1-DoF joint (ne == nb); a body may carry up to 4 child joints.
- * Forests of chains: up to 64 bodies (one lane of a wavefront per link); trees with a branching body: up to 32.
+ * Forests of chains and trees with branching bodies: up to 64 bodies (one lane of a wavefront per link).
  * Closed kinematic loops (examples/lqr_deltabot.jl:25-33: ne > nb, or a body that is the child of two joints, or a FixedOrientation
  * constraint; up to 8 bodies and 12 joints): cclqr_rollout* run them (LQR / TrackingLQR law with joint friction and noise, PID; one instance per wavefront, multipliers lam
  * [n_inst][5*ne]); cclqr_linearize returns their A, Bu, Bλ, G (ml = 5*ne rows, a FixedOrientation contributing two null rows), but G*Bλ

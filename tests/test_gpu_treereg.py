@@ -135,6 +135,51 @@ def test_every_image_size_up_to_32_links(cclqr, orc, nb, seed):
     assert np.abs(traj - traj_o).max() < TOL
 
 
+@pytest.mark.parametrize("nb,seed", [(33, 1), (41, 2), (48, 3), (57, 4), (64, 5)])
+def test_trees_of_33_to_64_links(cclqr, orc, nb, seed):
+    """round 5: a branching tree of 33 .. 64 bodies is one instance per wavefront on rollout_treereg_kernel<64, 48 | 64, law> (eight lane groups for the
+    scheduled elimination), as chains of that size have been since round 4; 65 bodies are refused (CCLQR_MAXL)"""
+    capi = cclqr._capi
+    rng = np.random.default_rng(6000 + seed)
+    parents = _random_parents(rng, nb)
+    if not any(parents.count(a) > 1 for a in set(parents) if a >= 0):
+        parents[-1] = parents[-2] if parents[-2] >= 0 else 0
+    prism = tuple(int(i) for i in range(nb) if rng.uniform() < 0.15)
+    ex = cclqr.examples.tree_mechanism(parents, seed=seed, prismatic=prism, g=-9.81 if seed % 2 else 0.0)
+    t = ex["mech"].tables()
+    z0 = _starts(cclqr, ex, rng, 3)
+    steps = 10
+    cj = sorted(set(int(j) for j in rng.integers(0, t.ne, 2)))
+    K = rng.normal(size=(steps + 3, len(cj), 12 * t.nb)) * 0.02
+    kw = dict(K=K, N=steps + 4, zd=z0[0], Fd=rng.normal(size=(1, len(cj))) * 0.2, fric=rng.uniform(0, 0.05, t.ne))
+    zo, traj_o, st_o = orc.rollout(t, orc.ctrl_desc(t.nb, cj, **kw), z0, steps, record=True)
+    h = capi.MechHandle(t)
+    lanes, lds = h.geometry()
+    assert lanes == 64 and lds <= 160 * 1024 and h.layout_links() == (48 if nb <= 48 else 64)
+    assert h.instances_per_wavefront(10 ** 6, steps) == 1
+    zT, traj, st = capi.rollout(h, capi.CtrlHandle(h, cj, **kw), z0, steps, record=True)
+    assert (st_o > 0).all() and np.array_equal(st, st_o)
+    assert np.abs(traj - traj_o).max() < TOL and np.abs(zT - zo).max() < TOL
+    # chained single-step launches continue bit for bit (multipliers through HBM)
+    import torch
+    dev = torch.device("cuda", 0)
+    z = torch.from_numpy(z0).to(dev)
+    zn = torch.empty_like(z)
+    lam = torch.zeros((len(z0), 5 * t.ne), dtype=torch.float64, device=dev)
+    s = torch.zeros(len(z0), dtype=torch.int32, device=dev)
+    ctrl = capi.CtrlHandle(h, cj, **kw)
+    for k in range(1, 4):
+        capi.rollout_dev(h, ctrl, len(z0), 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), s.data_ptr(), 0)
+        z, zn = zn, z
+    torch.cuda.synchronize()
+    assert np.array_equal(z.cpu().numpy(), traj[:, 3])
+    if nb <= 41:        # linearsystem on the big tree (its LDS-resident kernel holds ~3 KB per link: up to ~50 links with sibling blocks)
+        A, Bu, Bl, G = capi.linearize(h, z0[:1], cj, np.zeros((1, len(cj))))
+        Ao, Buo, Blo, Go = orc.linearize(t, z0[0], cj, np.zeros(len(cj)))
+        for x, y in ((A[0], Ao), (Bu[0], Buo), (Bl[0], Blo), (G[0], Go)):
+            assert np.abs(x - y).max() < 1e-8 * max(1.0, np.abs(y).max())
+
+
 def test_tree_launch_geometry(cclqr):
     """two instances of the 14-body tree per wavefront in an image that lets four workgroups share a CU's 160 KB (the LDS-resident kernel of
     rounds 1-3: one instance per wavefront); four instances of the dual-pole cart per wavefront"""

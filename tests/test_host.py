@@ -552,7 +552,7 @@ def test_tree_rollout_kernel_resources(tmp_path):
     resolve puts them into scratch: 128 bytes in the first cut) -- and without vector-register spills to memory; the plain-LQR and
     friction/noise instantiations spill no scalar register, the PID ones a few (atan2 constants)"""
     kernels = _kernel_resources(tmp_path, "rollout_treereg.hip", "rollout_treereg_kernel")
-    assert len(kernels) == 36, sorted(kernels)          # {(16,4), (16,8), (32,8), (32,10), (32,12), (32,14), (32,16), (32,24), (32,32)} x 4
+    assert len(kernels) == 44, sorted(kernels)          # {(16,4), (16,8), (32,8), (32,10), (32,12), (32,14), (32,16), (32,24), (32,32), (64,48), (64,64)} x 4
     for name, k in kernels.items():
         assert k["vgpr"] <= 512 and k["lds"] == 0, (name, k)      # all LDS is dynamic (one instance image per lane group)
         assert k["scratch"] == 0 and k["vgpr_spill"] <= 8, (name, k)

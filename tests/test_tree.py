@@ -121,6 +121,25 @@ def test_emulated_register_resident_tree_rollout_matches_oracle(cclqr, orc, emu,
     assert np.abs(zT - zo).max() < 1e-9
 
 
+@pytest.mark.parametrize("nb,seed", [(40, 1), (64, 4)])
+def test_emulated_trees_of_33_to_64_links(cclqr, orc, emu, nb, seed):
+    """the 64-lane tree tables (cclqr_treereg_tables.h: eight lane groups, schedules of up to 64 steps) and phase functions against the oracle on
+    random forests of 40 and 64 bodies -- the CPU side of tests/test_gpu_treereg.py::test_trees_of_33_to_64_links"""
+    rng = np.random.default_rng(7000 + seed)
+    parents = _random_parents(rng, nb)
+    prism = tuple(int(i) for i in range(nb) if rng.uniform() < 0.15)
+    ex = cclqr.examples.tree_mechanism(parents, seed=seed, prismatic=prism, g=-9.81 if seed % 2 else 0.0)
+    t = ex["mech"].tables()
+    z0 = ex["mech"].state()[None]
+    steps = 8
+    cj = sorted(set(int(j) for j in rng.integers(0, t.ne, 2)))
+    oc = orc.ctrl_desc(t.nb, cj, K=rng.normal(size=(steps + 3, len(cj), 12 * t.nb)) * 0.02, N=steps + 4, zd=z0[0], Fd=rng.normal(size=(1, len(cj))) * 0.2)
+    zo, traj_o, st_o = orc.rollout(t, oc, z0, steps, record=True)
+    zT, traj, st = emu_treereg_rollout(emu, orc, t, oc, z0, steps)
+    assert (st_o > 0).all() and np.array_equal(st, st_o)
+    assert np.abs(traj - traj_o).max() < 1e-10
+
+
 def test_emulated_whole_sawyer_robot(cclqr, orc, emu):
     """examples_files/sawyer.urdf with its fixed joints lumped (tests/golden/sawyer_full_tables.json): eight bodies, the head and the arm both on
     the first link -- a real robot that branches, under gravity, through the register-resident tree kernel's phases"""
