@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     // What the Newton phases read before they have written it is the multiplier block only (tests/emu/emu_chain.cpp runs every phase function on an
     // LDS image poisoned with signalling NaNs but for LAM): zero, or the caller's warm start.  Everything else in the image is discarded by a
     // select wherever a phase reads past what was produced (ck_tri_back / cr_back), so it is not cleared: at one step per launch (configs[4]'s
-    // graph mode) clearing 601 doubles per instance was 2.3 of the launch's 6.5 us (profiles/r05/launch_overhead.json).
+    // graph mode) clearing 601 doubles per instance was 2.3 of the launch's 6.5 us (profiles/r05/launch_overhead.txt).
     if (c.on() && (KL == 1 || c.prim())) {
         const bool warm = c.live() && a.lam && a.k0 > 1;
 #pragma unroll
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     prof.flush();
 #endif
     // ---------------- final state, multipliers, status
-#ifdef CHAIN_DIRECT_FINAL_STORE
+#ifdef CHAIN_DIRECT_FINAL_STORE      // (rejected variant, kept buildable for A/B: 13 one-double stores per lane straight from registers; 0-step launch 4.75 -> 5.23 us)
     asm volatile("" : "+s"(ap));
     LINK_FLAGS_FRESH(c);
     if (c.live() && (KL == 1 || c.prim())) {

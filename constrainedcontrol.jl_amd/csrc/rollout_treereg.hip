@@ -185,11 +185,12 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
     if (EXTRA >= 2 && a.pid_state && a.k0 > 1 && c.live()) { pid_int = a.pid_state[(inst * nb + t) * 2]; pid_last = a.pid_state[(inst * nb + t) * 2 + 1]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) { S.cd[i] = 0.0; S.d[i] = 0.0; S.ds[i] = 0.0; }
-    for (int e = t; e < total; e += G) L[e] = 0.0;
-    __syncthreads();
-    if (c.live() && a.lam && a.k0 > 1) {
+    // as in rollout_chain.hip: the multiplier block is all a Newton phase reads before writing it (tests/emu/emu_treereg.cpp poisons the rest of the image with
+    // signalling NaNs; on the hardware tests/test_gpu_lds_poison.py does), so the image is not cleared -- zero, or the caller's warm start
+    if (c.on()) {
+        const bool warm = c.live() && a.lam && a.k0 > 1;
 #pragma unroll
-        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = a.lam[inst * 5 * nb + 5 * t + i];
+        for (int i = 0; i < 5; i++) L[Y.LAM + 5 * t + i] = warm ? a.lam[inst * 5 * nb + 5 * t + i] : 0.0;
     }
 
 #ifdef CCLQR_PROFILE

@@ -92,10 +92,15 @@ def _chain_case(cclqr, n_links, ninst, steps, extra=False):
     return run
 
 
-def _tree_case(cclqr, name):
-    from test_tree import build
+def _tree_case(cclqr, name, nb=0):
+    from test_tree import build, _random_parents
     capi = cclqr._capi
-    ex = build(cclqr, name)
+    if nb:          # a random forest of nb bodies (33 .. 64: the tree kernel's 64-lane instantiations)
+        r = np.random.default_rng(nb)
+        ex = cclqr.examples.tree_mechanism(_random_parents(r, nb), seed=nb, prismatic=(0, 5))
+        ex["joints"] = ex["mech"].eqconstraints
+    else:
+        ex = build(cclqr, name)
     mech_py = ex["mech"]
     t = mech_py.tables()
     rng = np.random.default_rng(3)
@@ -115,6 +120,8 @@ def _tree_case(cclqr, name):
         zT, traj, st = capi.rollout(h, ctrl, z0, steps, record=True)
         assert (st > 0).all()
         prep()
+        if nb:
+            return [zT, traj, st]
         A, Bu, Bl, G = capi.linearize(h, z0[:2], cj, np.zeros((2, 2)))
         return [zT, traj, st, A, Bu, Bl, G]
     return run
@@ -172,6 +179,7 @@ CASES = {
     "40 links (64 lanes)": lambda c: _chain_case(c, 40, 3, 20),
     "tree: dual cartpole": lambda c: _tree_case(c, "dual_cartpole"),
     "tree: deep": lambda c: _tree_case(c, "deep"),
+    "tree: 40 bodies (64 lanes)": lambda c: _tree_case(c, None, nb=40),
     "closed loops: deltabot": _loop_case,
     "riccati resident + tiled": _riccati_case,
 }
