@@ -634,6 +634,10 @@ def other_configs(pkg, capi, torch, dev, count=True):
         out["triple_cartpole_tracking_cfg5"]["host_closure_controlfunction"] = _host_closure_rate(pkg, capi, torch, mech, tl, ex, np.tile(z00, (16384, 1, 1)), 100)
     except Exception as e:
         out["triple_cartpole_tracking_cfg5"]["host_closure_controlfunction"] = {"error": repr(e)}
+    try:
+        out["triple_cartpole_tracking_cfg5"]["device_closure_controlfunction"] = _device_closure_rate(pkg, capi, torch, mech, tl, ex, np.tile(z00, (16384, 1, 1)), 1000)
+    except Exception as e:
+        out["triple_cartpole_tracking_cfg5"]["device_closure_controlfunction"] = {"error": repr(e)}
     return out
 
 
@@ -735,6 +739,40 @@ def _host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps):
     return {"instances": int(z0.shape[0]), "sim_steps": steps, "value": (z0.shape[0] * steps / dt) if ok else None, "unit": "instance-steps/s", "s_per_run": dt,
             "what": "host closure controlfunction(batch, controller, k) = control_trackinglqr! + joint friction in numpy, one launch per step, states D2H and inputs H2D "
                     "every step through cclqr_ctrl_set_feedforward (PCIe and host arithmetic inside the time)"}
+
+
+def _device_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps):
+    """the same hook as a DEVICE closure (cclqr.on_device: lqr.py::_simulate_device_closure): the script's law -- control_trackinglqr! + friction on every
+    joint -- written in torch on the batch's state tensor in HBM; single-step launches, the closure's inputs handed over device to device on the same
+    stream, no host round trip per step.  No noise (the closure owns the law)."""
+    import copy
+    fric = torch.tensor(np.asarray(ex["fric"], dtype=np.float64), device="cuda")
+    t = mech.tables()
+    parent, child = [int(x) for x in t.parent], [int(x) for x in t.child]
+    typ = [int(x) for x in t.type]
+    fr = [float(x) for x in ex["fric"]]
+
+    @pkg.on_device
+    def law(batch, ctrl, k):
+        pkg.control_lqr(batch, ctrl, k)
+        for j in range(len(fr)):
+            if fr[j] == 0.0:
+                continue
+            comp = (batch.v, 1) if typ[j] == 1 else (batch.ω, 0)
+            rel = comp[0][:, child[j], comp[1]] - (comp[0][:, parent[j], comp[1]] if parent[j] >= 0 else 0.0)
+            prev = batch.u.get(j)
+            batch.u[j] = (prev if prev is not None else 0.0) - fr[j] * rel
+    tc = copy.copy(tl)
+    tc.controlfunction = law
+    pkg.simulate(mech, 5 * mech.Δt, tc, record=False, z0=z0)          # warm-up: the tables go to the device once
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = pkg.simulate(mech, steps * mech.Δt, tc, record=False, z0=z0)
+    dt = time.perf_counter() - t0
+    ok = bool((st.status > 0).all())
+    return {"instances": int(z0.shape[0]), "sim_steps": steps, "value": (z0.shape[0] * steps / dt) if ok else None, "unit": "instance-steps/s", "s_per_run": dt,
+            "what": "device closure (cclqr.on_device) controlfunction(batch, controller, k) = control_trackinglqr! + joint friction in torch on the state tensor in HBM, "
+                    "one launch per step, inputs handed over device to device (wall time of simulate incl. the upload of the states and the final download)"}
 
 
 def build_native_oracle():

@@ -9,4 +9,4 @@ from .mechanism import (Body, Box, EqualityConstraint, FixedOrientation, MechTab
 from . import examples
 from . import _capi
 from . import dist
-from .lqr import LQR, PID, BatchState, Controller, OpenLoop, Storage, TrackingLQR, control_lqr, setForce, simulate, state_error
+from .lqr import LQR, PID, BatchState, Controller, OpenLoop, Storage, TrackingLQR, control_lqr, on_device, setForce, simulate, state_error

@@ -279,6 +279,7 @@ class BatchState:
         self.mechanism, self.z, self.k = mechanism, z, int(k)
         self.n_inst = z.shape[0]
         self.u = {}
+        self.on_device = not isinstance(z, np.ndarray)          # a torch tensor in HBM: the closure was registered with on_device()
 
     x = property(lambda self: self.z[:, :, 0:3])
     q = property(lambda self: self.z[:, :, 3:7])
@@ -287,14 +288,85 @@ class BatchState:
     w = ω
 
 
+def on_device(controlfunction):
+    """Marks a `controlfunction(batch, controller, k)` as a DEVICE closure: simulate then hands it the batch's states as a torch tensor in HBM
+    (batch.z [n_inst][nb][13], batch.x / .q / .v / .ω views of it) and expects its inputs as tensors (setForce), so the whole loop -- the
+    closure's torch kernels, the hand-over of its inputs (cclqr_ctrl_set_feedforward, device to device) and the single-step launch -- runs on
+    one stream with no host round trip per step.  control_lqr, state_error and setForce work on either kind of batch."""
+    controlfunction.on_device = True
+    return controlfunction
+
+
 def setForce(batch, eqc, u):
     """setForce!(mechanism, eqconstraint, u) on a batch: u a scalar, [n_inst] or [n_inst][1]; eqc an EqualityConstraint or its id"""
     j = batch.mechanism.joint_index(getattr(eqc, "id", eqc))
+    if batch.on_device:
+        import torch
+        u = torch.as_tensor(u, dtype=torch.float64, device=batch.z.device).reshape(-1)
+        batch.u[j] = u.expand(batch.n_inst) if u.numel() == 1 else u
+        return
     batch.u[j] = np.broadcast_to(np.asarray(u, dtype=np.float64).reshape(-1), (batch.n_inst,)).copy()
+
+
+def _device_tables(controller, device):
+    """the controller's gain / setpoint / feed-forward tables as torch tensors on `device` (made once per controller and device)"""
+    import torch
+    cache = controller.__dict__.setdefault("_torch_tables", {})
+    key = str(device)
+    if key not in cache:
+        cache[key] = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device) for a in (controller.K, controller.zd, controller.Fd))
+    return cache[key]
+
+
+def _fused_gain_tables(lqr, device):
+    """G [nK][mu][13 nb], h [nK][mu] with u_k = h_k - G_k z (z the state as stored, 13 numbers per body): K_k folded with the affine map z -> Δz of
+    the step's setpoint (state_error: identity blocks for x, v, ω, the 3 x 4 matrix of qd' (x) . for the quaternion part)"""
+    import torch
+    cache = lqr.__dict__.setdefault("_torch_fused", {})
+    key = str(device)
+    if key not in cache:
+        K = np.asarray(lqr.K, dtype=np.float64)
+        nK, mu = K.shape[0], K.shape[1]
+        nb = K.shape[2] // 12
+        Kb = K.reshape(nK, mu, nb, 12)
+        zd, Fd = np.asarray(lqr.zd, dtype=np.float64), np.asarray(lqr.Fd, dtype=np.float64)
+        d = zd[np.minimum(np.arange(nK), zd.shape[0] - 1)] if zd.shape[0] > 1 else np.repeat(zd[:1], nK, 0)        # setpoint of table row i (step i + 1)
+        fd = Fd[np.minimum(np.arange(nK), Fd.shape[0] - 1)] if Fd.shape[0] > 1 else np.repeat(Fd[:1], nK, 0)
+        G = np.zeros((nK, mu, nb, 13))
+        G[..., 0:3] = Kb[..., 0:3]                   # x
+        G[..., 7:10] = Kb[..., 3:6]                  # v
+        G[..., 10:13] = Kb[..., 9:12]                # ω
+        s0, ax, ay, az = d[:, None, :, 3], -d[:, None, :, 4], -d[:, None, :, 5], -d[:, None, :, 6]
+        kx, ky, kz = Kb[..., 6], Kb[..., 7], Kb[..., 8]
+        # qe = M (s1, bx, by, bz)' with rows (ax, s0, -az, ay), (ay, az, s0, -ax), (az, -ay, ax, s0): the quaternion columns of G are K_q M
+        G[..., 3] = kx * ax + ky * ay + kz * az
+        G[..., 4] = kx * s0 + ky * az - kz * ay
+        G[..., 5] = -kx * az + ky * s0 + kz * ax
+        G[..., 6] = kx * ay - ky * ax + kz * s0
+        c = np.zeros((nK, nb, 12))
+        c[..., 0:3], c[..., 3:6], c[..., 9:12] = d[..., 0:3], d[..., 7:10], d[..., 10:13]
+        h = fd + np.einsum("kmbj,kbj->km", Kb, c)
+        cache[key] = (torch.from_numpy(G.reshape(nK, mu, 13 * nb)).to(device), torch.from_numpy(np.ascontiguousarray(h)).to(device))
+    return cache[key]
+
+
+def _state_error_device(batch, controller, k):
+    """state_error on a device batch: the same expressions in torch"""
+    import torch
+    _, zd, _ = _device_tables(controller, batch.z.device)
+    d = zd[min(k - 1, zd.shape[0] - 1)] if zd.shape[0] > 1 else zd[0]
+    z = batch.z
+    s0, a = d[None, :, 3:4], -d[None, :, 4:7]                    # qd' = (s0, a): the conjugate of the setpoint's quaternion
+    s1, b = z[:, :, 3:4], z[:, :, 4:7]
+    qe = s0 * b + s1 * a + torch.cross(a.expand_as(b), b, dim=2)
+    dz = torch.cat([z[:, :, 0:3] - d[None, :, 0:3], z[:, :, 7:10] - d[None, :, 7:10], qe, z[:, :, 10:13] - d[None, :, 10:13]], dim=2)
+    return dz.reshape(z.shape[0], -1)
 
 
 def state_error(batch, controller, k):
     """Δz [n_inst][12 nb] of lqr.jl:92-103 / lqr_tracking.jl:49-62 about the controller's setpoint of step k (bodies in mechanism order)"""
+    if getattr(batch, "on_device", False):
+        return _state_error_device(batch, controller, k)
     zd = controller.zd
     d = zd[min(k - 1, zd.shape[0] - 1)] if zd.shape[0] > 1 else zd[0]
     zt = batch.z.transpose(1, 2, 0)             # [nb][13][n_inst]
@@ -317,6 +389,19 @@ def control_lqr(batch, lqr, k):
     """control_lqr! (lqr.jl:89-139) / control_trackinglqr! (lqr_tracking.jl:46-71) on the host for a batch: u = Fτd - K[k] Δz on the
     controller's joints, gated by k < N; sets the forces and returns u [n_inst][mu] -- the building block of a custom controlfunction"""
     mu = len(lqr.eqcids)
+    if getattr(batch, "on_device", False):
+        import torch
+        if not (lqr.N <= 0 or k < lqr.N):
+            return torch.zeros((batch.n_inst, mu), dtype=torch.float64, device=batch.z.device)
+        # Δz is affine in z for a fixed setpoint (the vector part of qd \ q is linear in q), so u = Fd - K Δz = h_k - z G_k' with one row G_k = K_k T_k
+        # per input and step, folded on the host once per controller: the whole law is ONE product on the device (a closure's step is bound by
+        # the number of torch launches, not by their arithmetic)
+        G, h = _fused_gain_tables(lqr, batch.z.device)
+        i = 0 if lqr.N <= 0 else min(k - 1, G.shape[0] - 1)
+        u = h[i][None, :] - batch.z.reshape(batch.n_inst, -1) @ G[i].T
+        for j, e in enumerate(lqr.eqcids):
+            setForce(batch, e, u[:, j])
+        return u
     u = np.zeros((batch.n_inst, mu))
     if lqr.N <= 0 or k < lqr.N:                                  # LQR{T,Inf}: always; finite: k < N (lqr.jl:106)
         dz = state_error(batch, lqr, k)
@@ -398,6 +483,60 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     return zT, traj, np.where(bad, -worst, worst).astype(np.int32)
 
 
+def _simulate_device_closure(mechanism, steps, controller, record, z0):
+    """simulate! with a DEVICE closure (on_device): as _simulate_hosted, but nothing leaves HBM between the steps -- the closure reads a torch view of
+    the state and returns tensors, its inputs reach the controller's feed-forward table device to device on the launch's stream, and the lost-instance
+    bookkeeping (freeze at the last pose, at rest; status) is torch arithmetic on the device.  One synchronisation, at the end."""
+    import torch
+    t = mechanism.tables()
+    nb, n = t.nb, z0.shape[0]
+    dev = _device_mech(mechanism)
+    joints = [j for j in range(t.ne) if int(t.type[j]) in (0, 1)]
+    slot = {j: i for i, j in enumerate(joints)}
+    ctrl = _capi.CtrlHandle(dev, joints, K=None, N=0, Fd=np.zeros((n, len(joints))), n_ctrl=n)
+    td = torch.device("cuda", torch.cuda.current_device())
+    z = torch.from_numpy(np.ascontiguousarray(z0)).to(td)
+    zn = torch.empty_like(z)
+    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
+    st = torch.zeros(n, dtype=torch.int32, device=td)
+    traj = torch.empty((n, steps, nb, 13), dtype=torch.float64, device=td) if record else None
+    worst = torch.zeros(n, dtype=torch.int32, device=td)
+    bad = torch.zeros(n, dtype=torch.bool, device=td)
+    live = torch.ones(n, dtype=torch.bool, device=td)
+    live3 = live[:, None, None]                                         # (a view: follows the in-place updates of `live`)
+    zdead = torch.zeros_like(z)
+    U = torch.zeros((n, len(joints)), dtype=torch.float64, device=td)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for k in range(1, steps + 1):
+            if record:
+                traj[:, k - 1] = z
+            batch = BatchState(mechanism, z, k)
+            controller.controlfunction(batch, controller, k)
+            U.zero_()
+            for j, u in batch.u.items():
+                if j not in slot:
+                    raise ValueError("setForce on a constraint without a degree of freedom")
+                U[:, slot[j]] = u
+            ctrl.set_feedforward(dev_ptr=U.data_ptr(), length=U.numel(), stream=stream)
+            _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
+            z, zn = zn, z
+            # (a handful of small torch launches per step: the loop is bound by their count, so the bookkeeping is kept to in-place integer / mask arithmetic)
+            failed = (st <= 0) & live
+            lost = failed & (st > -_capi.NEWTON_MAXIT)                  # stopped early = left the integrator's domain
+            z = torch.where(live3, z, zdead)                            # a lost instance stays frozen (its launch simulated it again from the frozen pose)
+            zdead = torch.where(lost[:, None, None], z, zdead)
+            bad |= failed
+            torch.maximum(worst, st.abs() * live, out=worst)
+            live &= ~lost
+        zT = z.cpu().numpy()
+        status = torch.where(bad, -worst, worst).to(torch.int32).cpu().numpy()
+        trajh = traj.cpu().numpy() if record else np.zeros((n, 0, nb, 13))
+    finally:
+        ctrl.close()
+    return zT, trajh, status
+
+
 def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None, noise_seed=None,
              first_instance=0):
     """simulate!(mechanism, tend::Real | storage::Storage, controller; record)  -> Storage
@@ -420,7 +559,8 @@ def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=
         # a custom controlfunction (lqr.jl:14): the closure owns the whole law, as in the reference -- the built-in extras do not apply on top of it
         if fric is not None or noise is not None or noise_seed is not None:
             raise ValueError("fric / noise are options of the built-in laws; a custom controlfunction computes its own inputs")
-        zT, traj, status = _simulate_hosted(mechanism, steps, controller, record, z0)
+        hosted = _simulate_device_closure if getattr(controller.controlfunction, "on_device", False) else _simulate_hosted
+        zT, traj, status = hosted(mechanism, steps, controller, record, z0)
     else:
         ctrl = controller._ctrl_handle(dev, fric=fric, noise_scale=0.0 if noise_scale is None else noise_scale, noise_seed=noise_seed)
         try:

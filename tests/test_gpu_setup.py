@@ -249,6 +249,68 @@ def test_custom_controlfunction_closure(cclqr, orc):
         cclqr.simulate(mech, 0.1, lqr_host, z0=z0, fric=fric)
 
 
+def test_device_closure_controlfunction(cclqr, orc):
+    """cclqr.on_device(controlfunction): the same closure hook with the batch's states as a torch tensor in HBM and the inputs as tensors -- nothing
+    leaves the device between the steps.  (i) control_lqr as a device closure reproduces the fused rollout, the host closure and the oracle (1e-9,
+    same Newton counts); (ii) the script's friction law written in torch equals simulate's built-in `fric=`; (iii) an instance poisoned with a NaN
+    input at step 5 is lost and frozen exactly as the fused rollout freezes it, the others are untouched bit for bit"""
+    import torch
+    ex = cclqr.examples.cartpole_n(1)
+    mech = ex["mech"]
+    ids = [cclqr.getid(b) for b in ex["bodies"]]
+    rng = np.random.default_rng(5)
+    z0 = cclqr.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, 16), rng.uniform(0.0, 0.3, (16, 1)))
+    seen = []
+
+    @cclqr.on_device
+    def law(batch, lqr, k):
+        assert batch.on_device and batch.z.is_cuda and batch.z.shape == (16, 2, 13)
+        seen.append(k)
+        cclqr.control_lqr(batch, lqr, k)
+
+    def law_host(batch, lqr, k):
+        cclqr.control_lqr(batch, lqr, k)
+
+    mk = lambda f: cclqr.LQR(mech, ids, [cclqr.getid(ex["ctrl"][0])], ex["Q"], ex["R"], 10.0, xd=ex["xd"], controlfunction=f)
+    fused, dev, host = cclqr.simulate(mech, 3.0, mk(None), z0=z0), cclqr.simulate(mech, 3.0, mk(law), z0=z0), cclqr.simulate(mech, 3.0, mk(law_host), z0=z0)
+    assert seen == list(range(1, 301))
+    assert (dev.status > 0).all() and np.array_equal(dev.status, fused.status) and np.array_equal(dev.status, host.status)
+    assert np.abs(dev.z - fused.z).max() < 1e-9 and np.abs(dev.zT - fused.zT).max() < 1e-9 and np.abs(dev.z - host.z).max() < 1e-9
+    t = mech.tables()
+    lq = mk(None)
+    _, trajo, _ = orc.rollout(t, orc.ctrl_desc(2, [0], K=lq.K, N=lq.N, zd=lq.zd), z0, 300, record=True)
+    assert np.abs(dev.z - trajo).max() < 1e-9
+    fric = np.array([0.3, 0.05])
+    axes = [torch.tensor(np.asarray(e.joint.axis, dtype=np.float64) / np.linalg.norm(e.joint.axis), device="cuda") for e in mech.eqconstraints]
+
+    @cclqr.on_device
+    def law_fric(batch, lqr, k):
+        u = cclqr.control_lqr(batch, lqr, k)[:, 0]
+        cart_v = batch.v[:, 0] @ axes[0]
+        pole_w = (batch.ω[:, 1] - batch.ω[:, 0]) @ axes[1]
+        cclqr.setForce(batch, mech.eqconstraints[0], u - fric[0] * cart_v)
+        cclqr.setForce(batch, mech.eqconstraints[1], -fric[1] * pole_w)
+
+    df = cclqr.simulate(mech, 2.0, mk(law_fric), z0=z0)
+    ff = cclqr.simulate(mech, 2.0, mk(None), z0=z0, fric=fric)
+    assert (df.status > 0).all() and np.abs(df.z - ff.z).max() < 1e-9
+
+    @cclqr.on_device
+    def law_poisoned(batch, lqr, k):
+        u = cclqr.control_lqr(batch, lqr, k)[:, 0].clone()
+        if k == 5:
+            u[3] = float("nan")
+        cclqr.setForce(batch, mech.eqconstraints[0], u)
+
+    clean, lost = cclqr.simulate(mech, 0.4, mk(law), z0=z0), cclqr.simulate(mech, 0.4, mk(law_poisoned), z0=z0)
+    others = [i for i in range(16) if i != 3]
+    assert np.array_equal(lost.z[others], clean.z[others]) and np.array_equal(lost.status[others], clean.status[others])
+    assert lost.status[3] < 0 and (clean.status > 0).all()
+    for k in range(5, 40):
+        assert np.array_equal(lost.z[3, k, :, 0:7], lost.z[3, 4, :, 0:7]) and not lost.z[3, k, :, 7:].any()
+    assert np.array_equal(lost.zT[3, :, 0:7], lost.z[3, 4, :, 0:7]) and not lost.zT[3, :, 7:].any()
+
+
 def test_custom_controlfunction_keeps_a_lost_instance_frozen(cclqr, orc):
     """the fused rollout freezes an instance whose step ended on a non-finite residual (at its last pose, at rest, flagged) for the rest of the
     horizon; the step-per-launch path of a host `controlfunction` forgets that flag between launches, so lqr.py carries it: the lost instance's frozen

@@ -581,4 +581,18 @@ def test_controlfunction_helpers_on_the_host(cclqr, orc):
     cclqr.setForce(batch, mech.eqconstraints[1], 2.0)
     cclqr.setForce(batch, cclqr.getid(mech.eqconstraints[0]), np.arange(5.0))
     assert sorted(batch.u) == [0, 1] and np.array_equal(batch.u[1], np.full(5, 2.0)) and np.array_equal(batch.u[0], np.arange(5.0))
+    # the same helpers on a torch batch (what a closure registered with cclqr.on_device is handed; here the tensors simply live on the CPU):
+    # state_error / control_lqr in torch equal the numpy forms, setForce takes tensors and scalars
+    import torch
+    c.K = rng.normal(size=(7, 1, 36)); c.Fd = rng.normal(size=(7, 1)); c.N = 8; c.eqcids = [cclqr.getid(mech.eqconstraints[0])]
+    c.zd = np.repeat(zd, 7, 0) + rng.normal(size=(7, 3, 13)) * 0.01
+    tb = cclqr.BatchState(mech, torch.from_numpy(z.copy()), 3)
+    assert tb.on_device and not batch.on_device
+    assert np.abs(cclqr.state_error(tb, c, 3).numpy() - cclqr.state_error(batch, c, 3)).max() < 1e-15
+    un = cclqr.control_lqr(cclqr.BatchState(mech, z, 3), c, 3)
+    ut = cclqr.control_lqr(tb, c, 3)
+    assert np.abs(ut.numpy() - un).max() < 1e-13 and np.abs(tb.u[0].numpy() - un[:, 0]).max() < 1e-13
+    cclqr.setForce(tb, mech.eqconstraints[1], 2.0)
+    assert tb.u[1].shape == (5,) and float(tb.u[1][4]) == 2.0
+    assert cclqr.control_lqr(cclqr.BatchState(mech, torch.from_numpy(z.copy()), 8), c, 8).abs().max() == 0.0      # k < N gate (lqr.jl:106)
 

@@ -13,6 +13,8 @@ mech, tl, ex, octrl5, setup, z00 = bench.tracking_cfg5_workload(pkg)
 z0 = np.tile(z00, (16384, 1, 1))
 bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, 5)          # warm-up
 r = bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps)
+rd = bench._device_closure_rate(pkg, capi, torch, mech, tl, ex, z0, 1000)
+print("device closure:", json.dumps({k: rd[k] for k in ("instances", "sim_steps", "value", "s_per_run")}))
 print(json.dumps({k: r[k] for k in ("instances", "sim_steps", "value", "s_per_run")}))
 cProfile.run("bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps)", "/tmp/host_closure.prof")
 pstats.Stats("/tmp/host_closure.prof").sort_stats("tottime").print_stats(14)
