@@ -770,9 +770,25 @@ def _device_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps):
     st = pkg.simulate(mech, steps * mech.Δt, tc, record=False, z0=z0)
     dt = time.perf_counter() - t0
     ok = bool((st.status > 0).all())
-    return {"instances": int(z0.shape[0]), "sim_steps": steps, "value": (z0.shape[0] * steps / dt) if ok else None, "unit": "instance-steps/s", "s_per_run": dt,
-            "what": "device closure (cclqr.on_device) controlfunction(batch, controller, k) = control_trackinglqr! + joint friction in torch on the state tensor in HBM, "
-                    "one launch per step, inputs handed over device to device (wall time of simulate incl. the upload of the states and the final download)"}
+    out = {"instances": int(z0.shape[0]), "sim_steps": steps, "value": (z0.shape[0] * steps / dt) if ok else None, "unit": "instance-steps/s", "s_per_run": dt,
+           "what": "device closure (cclqr.on_device) controlfunction(batch, controller, k) = control_trackinglqr! + joint friction in torch on the state tensor in HBM, "
+                   "one launch per step, inputs handed over device to device (wall time of simulate incl. the upload of the states and the final download)"}
+    # the same closure with graph=True: the horizon captured by the first call, replayed by the second (what a sweep over initial states pays per batch)
+    tg = copy.copy(tl)
+    tg.__dict__.pop("_device_closure_runs", None)
+    tg.controlfunction = pkg.on_device(lambda b, c, k: law(b, c, k), graph=True)
+    t0 = time.perf_counter()
+    s0 = pkg.simulate(mech, steps * mech.Δt, tg, record=False, z0=z0)
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s1 = pkg.simulate(mech, steps * mech.Δt, tg, record=False, z0=z0)
+    t_replay = time.perf_counter() - t0
+    same = bool(np.array_equal(s1.zT, st.zT) and np.array_equal(s0.zT, st.zT))
+    out["captured_in_a_hip_graph"] = {"value": (z0.shape[0] * steps / t_replay) if (ok and same) else None, "unit": "instance-steps/s", "s_per_replayed_run": t_replay,
+                                      "s_first_run_with_capture": t_first, "same_bits_as_the_eager_loop": same}
+    for r in tg.__dict__.get("_device_closure_runs", {}).values():
+        r.close()
+    return out
 
 
 def build_native_oracle():

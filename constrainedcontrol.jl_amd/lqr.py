@@ -288,13 +288,19 @@ class BatchState:
     w = ω
 
 
-def on_device(controlfunction):
+def on_device(controlfunction=None, graph=False):
     """Marks a `controlfunction(batch, controller, k)` as a DEVICE closure: simulate then hands it the batch's states as a torch tensor in HBM
     (batch.z [n_inst][nb][13], batch.x / .q / .v / .ω views of it) and expects its inputs as tensors (setForce), so the whole loop -- the
     closure's torch kernels, the hand-over of its inputs (cclqr_ctrl_set_feedforward, device to device) and the single-step launch -- runs on
-    one stream with no host round trip per step.  control_lqr, state_error and setForce work on either kind of batch."""
-    controlfunction.on_device = True
-    return controlfunction
+    one stream with no host round trip per step.  control_lqr, state_error and setForce work on either kind of batch.
+    graph=True (@on_device(graph=True)): the whole horizon is captured into a hipGraph by the first simulate call and REPLAYED by every later call
+    with the same batch size and horizon -- the closure then runs once, at capture time: it must be capturable (no host synchronisation, no
+    .item() / .cpu(), the same tensor shapes for every k) and a pure function of (batch, controller, k)."""
+    def mark(f):
+        f.on_device = True
+        f.capture = bool(graph)
+        return f
+    return mark if controlfunction is None else mark(controlfunction)
 
 
 def setForce(batch, eqc, u):
@@ -483,43 +489,56 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     return zT, traj, np.where(bad, -worst, worst).astype(np.int32)
 
 
-def _simulate_device_closure(mechanism, steps, controller, record, z0):
-    """simulate! with a DEVICE closure (on_device): as _simulate_hosted, but nothing leaves HBM between the steps -- the closure reads a torch view of
-    the state and returns tensors, its inputs reach the controller's feed-forward table device to device on the launch's stream, and the lost-instance
-    bookkeeping (freeze at the last pose, at rest; status) is torch arithmetic on the device.  One synchronisation, at the end."""
-    import torch
-    t = mechanism.tables()
-    nb, n = t.nb, z0.shape[0]
-    dev = _device_mech(mechanism)
-    joints = [j for j in range(t.ne) if int(t.type[j]) in (0, 1)]
-    slot = {j: i for i, j in enumerate(joints)}
-    ctrl = _capi.CtrlHandle(dev, joints, K=None, N=0, Fd=np.zeros((n, len(joints))), n_ctrl=n)
-    td = torch.device("cuda", torch.cuda.current_device())
-    z = torch.from_numpy(np.ascontiguousarray(z0)).to(td)
-    zn = torch.empty_like(z)
-    lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
-    st = torch.zeros(n, dtype=torch.int32, device=td)
-    traj = torch.empty((n, steps, nb, 13), dtype=torch.float64, device=td) if record else None
-    worst = torch.zeros(n, dtype=torch.int32, device=td)
-    bad = torch.zeros(n, dtype=torch.bool, device=td)
-    live = torch.ones(n, dtype=torch.bool, device=td)
-    live3 = live[:, None, None]                                         # (a view: follows the in-place updates of `live`)
-    zdead = torch.zeros_like(z)
-    U = torch.zeros((n, len(joints)), dtype=torch.float64, device=td)
-    stream = torch.cuda.current_stream().cuda_stream
-    try:
-        for k in range(1, steps + 1):
-            if record:
-                traj[:, k - 1] = z
-            batch = BatchState(mechanism, z, k)
-            controller.controlfunction(batch, controller, k)
+class _DeviceClosureRun:
+    """One (controller, batch size, horizon) instance of the device-closure loop: its buffers in HBM, the per-instance feed-forward controller, and --
+    for a closure registered with on_device(f, graph=True) -- the whole horizon captured once into a hipGraph and replayed by every later simulate
+    call with the same shape (a Monte-Carlo sweep, an MPC loop over the same horizon): the replay costs no host time per step at all."""
+
+    def __init__(self, mechanism, steps, controller, record, n):
+        import torch
+        self.torch = torch
+        t = mechanism.tables()
+        self.mechanism, self.controller, self.steps, self.record, self.n, self.nb, self.ne = mechanism, controller, steps, record, n, t.nb, t.ne
+        self.dev = _device_mech(mechanism)
+        self.joints = [j for j in range(t.ne) if int(t.type[j]) in (0, 1)]
+        self.slot = {j: i for i, j in enumerate(self.joints)}
+        self.ctrl = _capi.CtrlHandle(self.dev, self.joints, K=None, N=0, Fd=np.zeros((n, len(self.joints))), n_ctrl=n)
+        td = self.td = torch.device("cuda", torch.cuda.current_device())
+        self.z0 = torch.empty((n, t.nb, 13), dtype=torch.float64, device=td)
+        self.lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
+        self.st = torch.zeros(n, dtype=torch.int32, device=td)
+        self.traj = torch.empty((n, steps, t.nb, 13), dtype=torch.float64, device=td) if record else None
+        self.worst = torch.zeros(n, dtype=torch.int32, device=td)
+        self.bad = torch.zeros(n, dtype=torch.bool, device=td)
+        self.live = torch.ones(n, dtype=torch.bool, device=td)
+        self.U = torch.zeros((n, len(self.joints)), dtype=torch.float64, device=td)
+        self.graph = None
+        self.zT = None
+
+    def close(self):
+        self.graph = None
+        self.ctrl.close()
+
+    def _steps(self, flags):
+        """the horizon on the current stream, from self.z0; leaves the final state in self.zT"""
+        torch, n = self.torch, self.n
+        stream = torch.cuda.current_stream().cuda_stream
+        live, bad, worst, st, lam, U = self.live, self.bad, self.worst, self.st, self.lam, self.U
+        live.fill_(True); bad.fill_(False); worst.zero_(); lam.zero_()
+        live3 = live[:, None, None]                                         # (a view: follows the in-place updates of `live`)
+        z, zn, zdead = self.z0.clone(), torch.empty_like(self.z0), torch.zeros_like(self.z0)
+        for k in range(1, self.steps + 1):
+            if self.record:
+                self.traj[:, k - 1] = z
+            batch = BatchState(self.mechanism, z, k)
+            self.controller.controlfunction(batch, self.controller, k)
             U.zero_()
             for j, u in batch.u.items():
-                if j not in slot:
+                if j not in self.slot:
                     raise ValueError("setForce on a constraint without a degree of freedom")
-                U[:, slot[j]] = u
-            ctrl.set_feedforward(dev_ptr=U.data_ptr(), length=U.numel(), stream=stream)
-            _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
+                U[:, self.slot[j]] = u
+            self.ctrl.set_feedforward(dev_ptr=U.data_ptr(), length=U.numel(), stream=stream)
+            _capi.rollout_dev(self.dev, self.ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream, flags=flags)
             z, zn = zn, z
             # (a handful of small torch launches per step: the loop is bound by their count, so the bookkeeping is kept to in-place integer / mask arithmetic)
             failed = (st <= 0) & live
@@ -529,12 +548,54 @@ def _simulate_device_closure(mechanism, steps, controller, record, z0):
             bad |= failed
             torch.maximum(worst, st.abs() * live, out=worst)
             live &= ~lost
-        zT = z.cpu().numpy()
-        status = torch.where(bad, -worst, worst).to(torch.int32).cpu().numpy()
-        trajh = traj.cpu().numpy() if record else np.zeros((n, 0, nb, 13))
-    finally:
-        ctrl.close()
-    return zT, trajh, status
+        self.zT = z
+
+    def run(self, z0):
+        torch = self.torch
+        self.z0.copy_(torch.from_numpy(np.ascontiguousarray(z0)))
+        if getattr(self.controller.controlfunction, "capture", False):
+            if self.graph is None:
+                # one step outside the capture first: what the closure builds lazily (device copies of its tables) must exist before a capture opens
+                self.controller.controlfunction(BatchState(self.mechanism, self.z0, 1), self.controller, 1)
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    graph.capture_begin()
+                    self._steps(_capi.ROLLOUT_NO_ALLOC)
+                    graph.capture_end()
+                torch.cuda.current_stream().wait_stream(side)
+                self.graph = graph
+            self.graph.replay()
+        else:
+            self._steps(0)
+        zT = self.zT.cpu().numpy()
+        status = torch.where(self.bad, -self.worst, self.worst).to(torch.int32).cpu().numpy()
+        trajh = self.traj.cpu().numpy() if self.record else np.zeros((self.n, 0, self.nb, 13))
+        return zT, trajh, status
+
+
+def _simulate_device_closure(mechanism, steps, controller, record, z0):
+    """simulate! with a DEVICE closure (on_device): as _simulate_hosted, but nothing leaves HBM between the steps -- the closure reads a torch view of
+    the state and returns tensors, its inputs reach the controller's feed-forward table device to device on the launch's stream, and the lost-instance
+    bookkeeping (freeze at the last pose, at rest; status) is torch arithmetic on the device.  One synchronisation, at the end.  With graph=True the
+    run (buffers + captured graph) is kept on the controller and replayed by later calls of the same shape."""
+    n = z0.shape[0]
+    if not getattr(controller.controlfunction, "capture", False):
+        run = _DeviceClosureRun(mechanism, steps, controller, record, n)
+        try:
+            return run.run(z0)
+        finally:
+            run.close()
+    cache = controller.__dict__.setdefault("_device_closure_runs", {})
+    key = (id(mechanism), id(controller.controlfunction), n, steps, bool(record))
+    if key not in cache:
+        for old in cache.values():          # one captured horizon per controller: a new shape replaces it
+            old.close()
+        cache.clear()
+        cache[key] = _DeviceClosureRun(mechanism, steps, controller, record, n)
+    return cache[key].run(z0)
 
 
 def simulate(mechanism, tend_or_storage, controller, record=True, z0=None, fric=None, noise=None, noise_scale=None, noise_seed=None,

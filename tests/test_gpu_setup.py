@@ -302,6 +302,24 @@ def test_device_closure_controlfunction(cclqr, orc):
             u[3] = float("nan")
         cclqr.setForce(batch, mech.eqconstraints[0], u)
 
+    # graph=True: the horizon is captured once and replayed for every later batch of the same shape -- the closure itself runs at capture time only
+    ran = []
+
+    @cclqr.on_device(graph=True)
+    def law_graph(batch, lqr, k):
+        ran.append(k)
+        cclqr.control_lqr(batch, lqr, k)
+
+    lg = mk(law_graph)
+    z1 = cclqr.examples.cartpole_states(1, rng.uniform(-0.5, 0.5, 16), rng.uniform(0.0, 0.3, (16, 1)))
+    g0 = cclqr.simulate(mech, 3.0, lg, z0=z0)
+    n_first = len(ran)
+    g1 = cclqr.simulate(mech, 3.0, lg, z0=z1)
+    assert n_first == 301 and len(ran) == 301                                   # (one warm-up call + the 300 captured steps; the replay calls nothing)
+    assert np.array_equal(g0.z, dev.z) and np.array_equal(g0.zT, dev.zT) and np.array_equal(g0.status, dev.status)
+    e1 = cclqr.simulate(mech, 3.0, mk(law), z0=z1)
+    assert np.array_equal(g1.z, e1.z) and np.array_equal(g1.status, e1.status) and np.abs(g1.z - g0.z).max() > 1e-3
+
     clean, lost = cclqr.simulate(mech, 0.4, mk(law), z0=z0), cclqr.simulate(mech, 0.4, mk(law_poisoned), z0=z0)
     others = [i for i in range(16) if i != 3]
     assert np.array_equal(lost.z[others], clean.z[others]) and np.array_equal(lost.status[others], clean.status[others])

@@ -14,7 +14,7 @@ z0 = np.tile(z00, (16384, 1, 1))
 bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, 5)          # warm-up
 r = bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps)
 rd = bench._device_closure_rate(pkg, capi, torch, mech, tl, ex, z0, 1000)
-print("device closure:", json.dumps({k: rd[k] for k in ("instances", "sim_steps", "value", "s_per_run")}))
+print("device closure:", json.dumps({k: rd[k] for k in ("instances", "sim_steps", "value", "s_per_run", "captured_in_a_hip_graph")}))
 print(json.dumps({k: r[k] for k in ("instances", "sim_steps", "value", "s_per_run")}))
 cProfile.run("bench._host_closure_rate(pkg, capi, torch, mech, tl, ex, z0, steps)", "/tmp/host_closure.prof")
 pstats.Stats("/tmp/host_closure.prof").sort_stats("tottime").print_stats(14)
