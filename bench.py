@@ -676,7 +676,7 @@ def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne, branches=(1
                 src, dst = za, zb
                 for k in range(1, steps + 1):
                     capi.rollout_dev(mh, ctrl, cnt, 1, k, src.data_ptr() + lo * nb13, lam.data_ptr() + lo * 5 * ne * 8, 0, 0, 0, dst.data_ptr() + lo * nb13,
-                                     st.data_ptr() + lo * 4, subs[b].cuda_stream, first_instance=lo, flags=capi.ROLLOUT_NO_ALLOC)
+                                     st.data_ptr() + lo * 4, subs[b].cuda_stream, first_instance=lo, flags=capi.ROLLOUT_NO_ALLOC | capi.ROLLOUT_CARRY_STATUS)
                     src, dst = dst, src
             if B > 1:
                 for b in range(B):
@@ -688,20 +688,22 @@ def _graph_captured_steps(capi, torch, dev, mh, ctrl, z0, steps, ne, branches=(1
         for _ in range(3):
             za.copy_(z0_d)
             lam.zero_()
+            st.zero_()                  # (CCLQR_ROLLOUT_CARRY_STATUS: the array carries every instance's status through the captured launches)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             graph.replay()
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         dt = min(times[1:])
-        # The captured launches all write the same status buffer, so what is left there only speaks for the LAST step, and the freeze of a lost
-        # instance is not carried from launch to launch.  A rate is therefore claimed only when the persistent launch of the same
-        # horizon lost nobody AND the graph's final state equals its final state bit for bit -- then no step of the graph can have failed either.
+        # The captured launches carry the status array from step to step (CCLQR_ROLLOUT_CARRY_STATUS, round 5): what is left there speaks for the whole
+        # horizon and a lost instance stays frozen, as in the persistent launch.  A rate is claimed only when nobody failed AND the graph's final state
+        # equals the persistent launch's bit for bit.
         same = bool(torch.equal(src, ref))
-        ok = same and failed_fused == 0
+        failed_graph = int((st <= 0).sum().item())
+        ok = same and failed_fused == 0 and failed_graph == 0
         res[B] = {"value": (n * steps / dt) if ok else None, "ms_per_rollout": 1e3 * dt, "attempted_instance_steps_per_s": n * steps / dt, "capture_s": capture_s,
                   "graph_nodes": "%d chain(s) x %d launches of one step (Philox samples generated in the step kernel: no fill launches)" % (B, steps),
-                  "same_bits_as_one_persistent_launch": same, "failed_instances_last_step": int((st <= 0).sum().item())}
+                  "same_bits_as_one_persistent_launch": same, "failed_instances_over_the_horizon": failed_graph}
         del graph
     best = max(res, key=lambda b: res[b]["attempted_instance_steps_per_s"])
     out = {"instances": n, "sim_steps": steps, "record": False, "unit": "instance-steps/s", "failed_instances_of_the_persistent_launch_of_the_same_horizon": failed_fused}

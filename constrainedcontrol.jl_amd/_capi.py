@@ -21,6 +21,7 @@ EXPORTS = ["cclqr_last_error", "cclqr_version", "cclqr_device_count", "cclqr_set
            "cclqr_release_workspaces", "cclqr_rollout_geometry", "cclqr_rollout_layout_links", "cclqr_ctrl_set_feedforward", "cclqr_abi_layout", "cclqr_rollout_lanes_per_link", "cclqr_rollout_instances_per_wavefront"]
 ABI_VERSION = 201     # include/cclqr.h CCLQR_ABI_VERSION: the structs below mirror that header (verified field by field against cclqr_abi_layout at load time)
 ROLLOUT_NO_ALLOC = 1  # cclqr_rollout_opts.flags: the call may neither allocate nor synchronise (a hipGraph capture is open on the device)
+ROLLOUT_CARRY_STATUS = 4  # ... `status` is read and written: an instance lost in an earlier launch stays frozen, the others merge this launch's result into it
 ROLLOUT_PACK_WAVEFRONTS = 2  # ... every wavefront of a chain launch full, whatever the batch size (many launches sharing the device at once)
 PHILOX_INKERNEL_STEPS = 8
 NEWTON_MAXIT = 100      # newtonIter of ConstrainedDynamics' newton!: |status| of an instance that hit the cap

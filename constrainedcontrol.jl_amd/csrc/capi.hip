@@ -5,6 +5,8 @@
 #include "cclqr_internal.h"
 #include "cclqr_tables.h"
 #include "cclqr_treereg_tables.h"
+#include "cclqr_newton.h"
+static_assert(CCLQR_NEWTON_MAXIT == NEWTON_MAXIT, "include/cclqr.h and cclqr_newton.h disagree on the Newton iteration cap");
 #include "cclqr_wscache.h"
 #include <math.h>
 #include <stdio.h>
@@ -385,7 +387,8 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     // which only ever grows OUTSIDE stream capture: hipMalloc / hipFree are illegal while a stream is being captured, so a captured
     // launch needs the workspace sized beforehand (cclqr_ctrl_reserve_noise) or passed in.
     const bool use_noise = H.noise_scale != 0.0 && H.mu > 0;
-    if (opts && (opts->flags & ~(CCLQR_ROLLOUT_NO_ALLOC | CCLQR_ROLLOUT_PACK_WAVEFRONTS))) return fail(CCLQR_EINVAL, "unknown bit in cclqr_rollout_opts.flags");
+    if (opts && (opts->flags & ~(CCLQR_ROLLOUT_NO_ALLOC | CCLQR_ROLLOUT_PACK_WAVEFRONTS | CCLQR_ROLLOUT_CARRY_STATUS))) return fail(CCLQR_EINVAL, "unknown bit in cclqr_rollout_opts.flags");
+    if (opts && (opts->flags & CCLQR_ROLLOUT_CARRY_STATUS) && !status) return fail(CCLQR_EINVAL, "CCLQR_ROLLOUT_CARRY_STATUS needs the status array (it is read and written)");
     const bool no_alloc = opts && (opts->flags & CCLQR_ROLLOUT_NO_ALLOC);
     // launches of a few steps on forests of chains (the step-per-launch form a hipGraph replays, BASELINE configs[4]) generate their samples inside the
     // rollout kernel (rollout_chain_kernel<.., 3>): one kernel per step instead of two, and no workspace that could have to grow
@@ -426,6 +429,7 @@ extern "C" int cclqr_rollout_ex(const cclqr_mech* m, const cclqr_ctrl* c, int64_
     a.M = m->dev; a.C = c->dev; a.n_inst = n_inst; a.steps = steps; a.k0 = k0; a.z0 = z0; a.lam = lam; a.noise = use_noise ? noise : nullptr;
     a.noise_stride = noise_stride; a.traj = traj; a.zT = zT; a.status = status; a.inst0 = first; a.pid_state = pid_state;
     a.ipw = (opts && (opts->flags & CCLQR_ROLLOUT_PACK_WAVEFRONTS)) ? 1 : 0;
+    a.carry = (opts && (opts->flags & CCLQR_ROLLOUT_CARRY_STATUS)) ? 1 : 0;
     const int newton_mode = opts ? opts->newton_mode : 0;
     a.eps_alone = (opts && opts->newton_eps_alone > 0.0) ? opts->newton_eps_alone : 1e-10;
     if (newton_mode != 0 && newton_mode != 1) return fail(CCLQR_EINVAL, "newton_mode must be 0 (exact rule) or 1 (residual-only stop)");

@@ -24,6 +24,8 @@ struct RolloutArgs {
     double* zT;           // [n_inst][nb][13]
     int* status;          // [n_inst] or null
     double eps_alone;     // measured-error Newton mode (RELAX kernels only): a solve also stops when ||f|| falls below this
+    int carry;            // CCLQR_ROLLOUT_CARRY_STATUS: `status` comes in with the instance's status of the launches before (0: none): an instance that was lost stays
+                          // frozen and keeps its status, the others merge this launch's Newton count / failure into it
     int ipw;              // chain and tree kernels: instances per wavefront, 1 .. 64 / lanes per instance (lane groups beyond it hold no instance).  The caller of
                           // launch_rollout_chain / launch_rollout_treereg passes 0 (the launch chooses: chain_instances_per_wavefront) or nonzero = pack every wavefront full
 };

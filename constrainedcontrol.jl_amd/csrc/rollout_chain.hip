@@ -307,6 +307,12 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     int worst = 0;
     // "bad" (a step did not converge) and "dead" (a step produced a non-finite residual; the instance is frozen from then on) are
     // bits of the lane flags, not 64-bit lane masks held in scalar registers through the launch
+    if (a.carry && a.status && c.valid()) {      // CCLQR_ROLLOUT_CARRY_STATUS: the launches before this one count (step-per-launch chains)
+        const int carried = a.status[inst];
+        worst = carried < 0 ? -carried : carried;
+        if (carried < 0) c.flags |= LinkC::BAD;
+        if (carried < 0 && carried > -NEWTON_MAXIT) c.flags |= LinkC::DEAD;      // lost in an earlier launch (stopped before NEWTON_MAXIT): it stays frozen
+    }
     // Launch arguments that are only needed once per step or at the end are read from the kernel-argument segment where they are
     // used, through a pointer the optimiser cannot see through, instead of sitting in scalar registers for the whole launch.
     typedef const __attribute__((address_space(4))) RolloutArgs* KernArgs;
@@ -722,7 +728,8 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
     }
     if (c.valid()) {
         int* status = ap->status;
-        if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
+        // (carried statuses mark a lost instance by a count below NEWTON_MAXIT: one that had also failed to converge earlier reports NEWTON_MAXIT - 1)
+        if (status && t == 0) status[inst] = c.bad() ? -((ap->carry && c.dead() && worst >= NEWTON_MAXIT) ? NEWTON_MAXIT - 1 : worst) : worst;
     }
 #else
     __syncthreads();
@@ -739,7 +746,8 @@ __global__ __launch_bounds__(64) void rollout_chain_kernel(RolloutArgs a) {
         double* zT = ap->zT;
         int* status = ap->status;
         for (int e = t; e < nz; e += G) zT[inst * nz + e] = L[Y.Z + e];
-        if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
+        // (carried statuses mark a lost instance by a count below NEWTON_MAXIT: one that had also failed to converge earlier reports NEWTON_MAXIT - 1)
+        if (status && t == 0) status[inst] = c.bad() ? -((ap->carry && c.dead() && worst >= NEWTON_MAXIT) ? NEWTON_MAXIT - 1 : worst) : worst;
     }
 #endif
     if (c.live() && (KL == 1 || c.prim())) {

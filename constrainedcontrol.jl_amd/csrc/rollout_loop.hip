@@ -169,6 +169,12 @@ __global__ __launch_bounds__(64, 2) void rollout_loop_kernel(RolloutArgs a, int 
 #endif
     int worst = 0;
     bool bad = false, dead = false;
+    if (a.carry && a.status) {                    // CCLQR_ROLLOUT_CARRY_STATUS (rollout_chain.hip)
+        const int carried = a.status[inst];
+        worst = carried < 0 ? -carried : carried;
+        bad = carried < 0;
+        dead = carried < 0 && carried > -NEWTON_MAXIT;
+    }
     const long long ginst = a.inst0 + inst;
     for (int kk = 0; kk < a.steps; kk++) {
         const int k = a.k0 + kk;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(64, 2) void rollout_loop_kernel(RolloutArgs a, int 
     }
     for (int e = t; e < nz; e += 64) a.zT[inst * nz + e] = L[Y.Z + e];
     if (a.lam) for (int e = t; e < 5 * nj; e += 64) a.lam[inst * 5 * nj + e] = L[Y.LAM + e];
-    if (a.status && t == 0) a.status[inst] = bad ? -worst : worst;
+    if (a.status && t == 0) a.status[inst] = bad ? -((a.carry && dead && worst >= NEWTON_MAXIT) ? NEWTON_MAXIT - 1 : worst) : worst;
     if (a.pid_state && t < nj) { a.pid_state[(inst * nj + t) * 2] = r.pid_int; a.pid_state[(inst * nj + t) * 2 + 1] = r.pid_last; }
 #ifdef CCLQR_PROFILE
     prof.stamp(PF_IO);

@@ -198,6 +198,12 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
     prof.start();
 #endif
     int worst = 0;
+    if (a.carry && a.status && c.valid()) {      // CCLQR_ROLLOUT_CARRY_STATUS (rollout_chain.hip)
+        const int carried = a.status[inst];
+        worst = carried < 0 ? -carried : carried;
+        if (carried < 0) c.flags |= LinkC::BAD;
+        if (carried < 0 && carried > -NEWTON_MAXIT) c.flags |= LinkC::DEAD;
+    }
     typedef const __attribute__((address_space(4))) RolloutArgs* KernArgs;
     KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int k0 = a.k0;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(64) void rollout_treereg_kernel(RolloutArgs a) {
         double* zT = ap->zT;
         int* status = ap->status;
         for (int e = t; e < nz; e += G) zT[inst * nz + e] = L[Y.Z + e];
-        if (status && t == 0) status[inst] = c.bad() ? -worst : worst;
+        if (status && t == 0) status[inst] = c.bad() ? -((ap->carry && c.dead() && worst >= NEWTON_MAXIT) ? NEWTON_MAXIT - 1 : worst) : worst;
     }
     if (c.live()) {
         const int nbT = ap->M->nb;

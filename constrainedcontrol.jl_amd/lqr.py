@@ -435,12 +435,9 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
     st = torch.zeros(n, dtype=torch.int32, device=td)
     traj = np.zeros((n, steps if record else 0, nb, 13))
-    worst, bad = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=bool)
     # an instance whose step ended on a non-finite residual is LOST: the fused rollout freezes it at its last pose, at rest, for the rest of
-    # the horizon (rollout_chain.hip, LinkC::DEAD).  A launch per step forgets that flag between launches, so it is carried here: a lost
-    # instance's frozen state is written back after every later launch (the closure still sees it, as it sees the frozen pose in the fused run)
-    dead = np.zeros(n, dtype=bool)
-    zdead = None                      # device copy of the lost instances' frozen states, made when the first one is lost
+    # the horizon (rollout_chain.hip, LinkC::DEAD).  A launch per step keeps that through CCLQR_ROLLOUT_CARRY_STATUS: the status array travels from
+    # launch to launch on the device, a lost instance is not stepped again (the closure still sees it, frozen, as it would in the fused run)
     stream = torch.cuda.current_stream().cuda_stream
     # The states reach the closure through one page-locked buffer, transposed on the device to one [n_inst] plane per state component: BatchState.z
     # is a [n_inst][nb][13] VIEW of it (valid during the call: the next step overwrites it), so that a closure's numpy slices z[:, b, i] are contiguous
@@ -450,7 +447,6 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
     za_pinned = torch.empty(z.shape, dtype=torch.float64, pin_memory=True) if record else None
     U_pinned = torch.zeros((n, len(joints)), dtype=torch.float64, pin_memory=True)
     U, U_dev = U_pinned.numpy(), torch.zeros((n, len(joints)), dtype=torch.float64, device=td)
-    st_pinned = torch.zeros(n, dtype=torch.int32, pin_memory=True)
     try:
         for k in range(1, steps + 1):
             zt_pinned.copy_(z.permute(1, 2, 0))     # (synchronises the stream: the previous launch no longer reads the feed-forward table set_feedforward rewrites below)
@@ -464,29 +460,16 @@ def _simulate_hosted(mechanism, steps, controller, record, z0):
                 if j not in slot:
                     raise ValueError("setForce on a constraint without a degree of freedom")
                 U[:, slot[j]] = u
-            U_dev.copy_(U_pinned, non_blocking=True)      # (page-locked -> device on the launch's stream; the table is replaced device to device behind it)
+            U_dev.copy_(U_pinned, non_blocking=True)      # (page-locked -> device on the launch's stream; the table is replaced device to device behind it;
+                                                          #  U_pinned is rewritten only after the next step's blocking copy of the states has drained the stream)
             ctrl.set_feedforward(dev_ptr=U_dev.data_ptr(), length=U_dev.numel(), stream=stream)
-            _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream)
+            _capi.rollout_dev(dev, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream, flags=_capi.ROLLOUT_CARRY_STATUS)
             z, zn = zn, z
-            st_pinned.copy_(st)                            # (waits for the step: U_pinned may be rewritten after this)
-            s = st_pinned.numpy()
-            live = ~dead                                                                       # (a lost instance is not stepped any more: its status stands)
-            lost = live & (s <= 0) & (np.abs(s) < _capi.NEWTON_MAXIT)                          # stopped early = left the integrator's domain
-            if dead.any():
-                idx = torch.from_numpy(np.flatnonzero(dead)).to(td)
-                z[idx] = zdead[idx]
-            if lost.any():
-                if zdead is None:
-                    zdead = torch.zeros_like(z)
-                idx = torch.from_numpy(np.flatnonzero(lost)).to(td)
-                zdead[idx] = z[idx]
-                dead |= lost
-            bad |= live & (s <= 0)
-            worst = np.where(live, np.maximum(worst, np.abs(s)), worst)
+        zT = z.cpu().numpy()
+        status = st.cpu().numpy()
     finally:
         ctrl.close()
-    zT = z.cpu().numpy()
-    return zT, traj, np.where(bad, -worst, worst).astype(np.int32)
+    return zT, traj, status
 
 
 class _DeviceClosureRun:
@@ -508,9 +491,6 @@ class _DeviceClosureRun:
         self.lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=td)
         self.st = torch.zeros(n, dtype=torch.int32, device=td)
         self.traj = torch.empty((n, steps, t.nb, 13), dtype=torch.float64, device=td) if record else None
-        self.worst = torch.zeros(n, dtype=torch.int32, device=td)
-        self.bad = torch.zeros(n, dtype=torch.bool, device=td)
-        self.live = torch.ones(n, dtype=torch.bool, device=td)
         self.U = torch.zeros((n, len(self.joints)), dtype=torch.float64, device=td)
         self.graph = None
         self.zT = None
@@ -523,10 +503,9 @@ class _DeviceClosureRun:
         """the horizon on the current stream, from self.z0; leaves the final state in self.zT"""
         torch, n = self.torch, self.n
         stream = torch.cuda.current_stream().cuda_stream
-        live, bad, worst, st, lam, U = self.live, self.bad, self.worst, self.st, self.lam, self.U
-        live.fill_(True); bad.fill_(False); worst.zero_(); lam.zero_()
-        live3 = live[:, None, None]                                         # (a view: follows the in-place updates of `live`)
-        z, zn, zdead = self.z0.clone(), torch.empty_like(self.z0), torch.zeros_like(self.z0)
+        st, lam, U = self.st, self.lam, self.U
+        st.zero_(); lam.zero_()            # (CCLQR_ROLLOUT_CARRY_STATUS: the status array carries every instance's status from launch to launch -- a lost one stays frozen)
+        z, zn = self.z0.clone(), torch.empty_like(self.z0)
         for k in range(1, self.steps + 1):
             if self.record:
                 self.traj[:, k - 1] = z
@@ -538,16 +517,9 @@ class _DeviceClosureRun:
                     raise ValueError("setForce on a constraint without a degree of freedom")
                 U[:, self.slot[j]] = u
             self.ctrl.set_feedforward(dev_ptr=U.data_ptr(), length=U.numel(), stream=stream)
-            _capi.rollout_dev(self.dev, self.ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream, flags=flags)
+            _capi.rollout_dev(self.dev, self.ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), st.data_ptr(), stream,
+                              flags=flags | _capi.ROLLOUT_CARRY_STATUS)
             z, zn = zn, z
-            # (a handful of small torch launches per step: the loop is bound by their count, so the bookkeeping is kept to in-place integer / mask arithmetic)
-            failed = (st <= 0) & live
-            lost = failed & (st > -_capi.NEWTON_MAXIT)                  # stopped early = left the integrator's domain
-            z = torch.where(live3, z, zdead)                            # a lost instance stays frozen (its launch simulated it again from the frozen pose)
-            zdead = torch.where(lost[:, None, None], z, zdead)
-            bad |= failed
-            torch.maximum(worst, st.abs() * live, out=worst)
-            live &= ~lost
         self.zT = z
 
     def run(self, z0):
@@ -571,7 +543,7 @@ class _DeviceClosureRun:
         else:
             self._steps(0)
         zT = self.zT.cpu().numpy()
-        status = torch.where(self.bad, -self.worst, self.worst).to(torch.int32).cpu().numpy()
+        status = self.st.cpu().numpy()
         trajh = self.traj.cpu().numpy() if self.record else np.zeros((self.n, 0, self.nb, 13))
         return zT, trajh, status
 
@@ -579,7 +551,7 @@ class _DeviceClosureRun:
 def _simulate_device_closure(mechanism, steps, controller, record, z0):
     """simulate! with a DEVICE closure (on_device): as _simulate_hosted, but nothing leaves HBM between the steps -- the closure reads a torch view of
     the state and returns tensors, its inputs reach the controller's feed-forward table device to device on the launch's stream, and the lost-instance
-    bookkeeping (freeze at the last pose, at rest; status) is torch arithmetic on the device.  One synchronisation, at the end.  With graph=True the
+    bookkeeping (freeze at the last pose, at rest; status) is the library's (CCLQR_ROLLOUT_CARRY_STATUS).  One synchronisation, at the end.  With graph=True the
     run (buffers + captured graph) is kept on the controller and replayed by later calls of the same shape."""
     n = z0.shape[0]
     if not getattr(controller.controlfunction, "capture", False):

@@ -205,7 +205,8 @@ int cclqr_riccati_tracking(const cclqr_mech *m, int32_t mu, const int32_t *ctrl_
  * example's last line (e.g. examples/lqr_cartpole.jl:44) with control_lqr! (lqr.jl:89-139) / control_trackinglqr!
  * (lqr_tracking.jl:46-71) fused in.  Step indices run k0 .. k0+steps-1 (1-based like the reference).
  * HOST pointers; traj may be NULL (record=false); noise [n_inst][steps] standard-normal samples or NULL;
- * status[n_inst] = max Newton iterations used, negative if a step hit the 100-iteration cap. */
+ * status[n_inst] = max Newton iterations used, negative if a step failed: -CCLQR_NEWTON_MAXIT when a solve hit the iteration cap, a smaller magnitude when a
+ * step ended on a non-finite residual (the instance is LOST: frozen at its last pose, at rest, for the rest of the launch). */
 int cclqr_rollout(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, int32_t steps, int32_t k0, const double *z0,
                   const double *noise, double *traj, double *zT, int32_t *status);
 
@@ -249,9 +250,18 @@ int cclqr_rollout_dev(const cclqr_mech *m, const cclqr_ctrl *c, int64_t n_inst, 
  *                   launch, steps >= 8, spreads over the whole device, a shorter one over a quarter of it) -- bitwise the same results.  Set it
  *                   when MANY launches share the device at once (more than four concurrent step-per-launch chains, several processes on one
  *                   GPU): spread launches then queue behind one another;
+ *                   CCLQR_ROLLOUT_CARRY_STATUS: `status` is read as well as written -- it carries an instance's status ACROSS launches, for callers who
+ *                   step a batch one launch (or a few steps) at a time (k0 continuation: the `controlfunction` loops, MPC, a hipGraph of step
+ *                   launches).  Zero it before the first launch.  An instance that comes in lost (-CCLQR_NEWTON_MAXIT < status < 0: an earlier step ended on
+ *                   a non-finite residual) is not stepped: it stays frozen at its last pose, at rest, as it would inside ONE launch over the whole
+ *                   horizon, and keeps its status; for the others this launch's result is merged in (largest Newton count so far, negative once any
+ *                   step failed).  A lost instance that had ALSO failed to converge earlier reports -(CCLQR_NEWTON_MAXIT - 1), so that "lost" stays
+ *                   readable from the number.  Without the flag every launch reports on its own steps only and forgets what came before;
  *   newton_eps_alone  threshold of mode 1 (<= 0: 1e-10, the rule's own eps: stop on the residual alone). */
+#define CCLQR_NEWTON_MAXIT 100        /* newton!'s iteration cap */
 #define CCLQR_ROLLOUT_NO_ALLOC 1
 #define CCLQR_ROLLOUT_PACK_WAVEFRONTS 2
+#define CCLQR_ROLLOUT_CARRY_STATUS 4
 #define CCLQR_PHILOX_INKERNEL_STEPS 8
 typedef struct {
     int64_t first_instance;

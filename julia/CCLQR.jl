@@ -46,6 +46,7 @@ struct RolloutOpts         # cclqr_rollout_opts
     newton_eps_alone::Float64
 end
 const ROLLOUT_NO_ALLOC = Int32(1)
+const ROLLOUT_CARRY_STATUS = Int32(4)      # `status` carries an instance's status across launches: a lost instance stays frozen (step-per-launch loops)
 const ROLLOUT_PACK_WAVEFRONTS = Int32(2)   # every wavefront of a chain launch full whatever the batch size (many launches sharing the device at once)
 
 struct RiccatiOpts         # cclqr_riccati_opts

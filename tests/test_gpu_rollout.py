@@ -681,7 +681,7 @@ def test_graph_captured_steps_with_friction_and_philox_noise(cclqr, orc):
     with pytest.raises(capi.CclqrError):
         capi.rollout_dev(mech, ctrl, n, 20, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), noise_ws=ws.data_ptr(), noise_ws_len=n * 20 - 1)
     with pytest.raises(capi.CclqrError):        # unknown flag bits are refused
-        capi.rollout_dev(mech, ctrl, n, 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), flags=4)
+        capi.rollout_dev(mech, ctrl, n, 1, 1, z0_d.data_ptr(), 0, 0, 0, 0, out.data_ptr(), st.data_ptr(), flags=8)
     zo, _, _ = orc.rollout(t, orc.ctrl_desc(t.nb, [0], **kw), z0[:16], 20)
     assert np.abs(ref[:16].cpu().numpy() - zo).max() < TOL
 
@@ -777,3 +777,58 @@ def test_newton_mode_residual_only_is_a_measured_error_option(cclqr, orc):
     with pytest.raises(capi.CclqrError) as e:
         capi.rollout(mech, cf, z0[:2], 3, newton_mode=1)
     assert e.value.code == capi.EUNSUPPORTED
+
+
+def _mechanism_for(cclqr, kind):
+    """(tables, initial state, controlled joints) of a chain, a branching tree or the closed-loop deltabot"""
+    if kind == "chain":
+        ex = cclqr.examples.cartpole_n(2)
+        return ex["mech"].tables(), cclqr.examples.cartpole_states(2, [0.1], [[0.2, -0.1]])[0], [0]
+    if kind == "tree":
+        ex = cclqr.examples.dual_cartpole()
+        return ex["mech"].tables(), ex["mech"].state(), [0]
+    ex = cclqr.examples.deltabot()
+    return ex["mech"].tables(), ex["mech"].state(), [ex["mech"].joint_index(e) for e in ex["eqcids"]]
+
+
+@pytest.mark.parametrize("kind", ["chain", "tree", "loop"])
+def test_carried_status_keeps_a_lost_instance_frozen_across_launches(cclqr, kind):
+    """CCLQR_ROLLOUT_CARRY_STATUS: `status` is read and written, so a batch stepped one launch at a time behaves like ONE launch over the horizon -- an instance
+    that a non-finite input loses at step 5 stays frozen at its pose of knot 5, at rest, through every later launch and keeps its (negative) status; the
+    others carry their largest Newton count along.  Final states, multipliers and statuses of twelve chained single-step launches equal the persistent
+    launch's bit for bit; without the flag every launch steps the lost instance again (here it is lost again at once: its multipliers are NaN) and the status
+    array only speaks for the last step."""
+    import torch
+    capi = cclqr._capi
+    t, z00, cj = _mechanism_for(cclqr, kind)
+    n, T = 6, 12
+    rng = np.random.default_rng(8)
+    Fd = rng.normal(size=(n, T, len(cj))) * 0.2
+    Fd[3, 4] = np.nan                                            # instance 3, step 5
+    zd = np.tile(z00, (n, T, 1, 1))
+    mech = capi.MechHandle(t)
+    ctrl = capi.CtrlHandle(mech, cj, K=None, N=0, zd=zd, Fd=Fd, n_ctrl=n)
+    z0 = np.tile(z00, (n, 1, 1))
+    zT, traj, st = capi.rollout(mech, ctrl, z0, T, record=True)
+    assert st[3] < 0 and abs(st[3]) < capi.NEWTON_MAXIT and (np.delete(st, 3) > 0).all()
+    assert np.array_equal(zT[3, :, 0:7], traj[3, 4, :, 0:7]) and not zT[3, :, 7:].any()
+    dev = torch.device("cuda", 0)
+    out = {}
+    for flags in (capi.ROLLOUT_CARRY_STATUS, 0):
+        z = torch.from_numpy(z0).to(dev)
+        zn = torch.empty_like(z)
+        lam = torch.zeros((n, 5 * t.ne), dtype=torch.float64, device=dev)
+        s = torch.zeros(n, dtype=torch.int32, device=dev)
+        for k in range(1, T + 1):
+            capi.rollout_dev(mech, ctrl, n, 1, k, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), s.data_ptr(), 0, flags=flags)
+            z, zn = zn, z
+        torch.cuda.synchronize()
+        out[flags] = (z.cpu().numpy(), s.cpu().numpy())
+    zc, sc = out[capi.ROLLOUT_CARRY_STATUS]
+    assert np.array_equal(zc, zT) and np.array_equal(sc, st)
+    z_plain, s_plain = out[0]
+    others = [i for i in range(n) if i != 3]
+    assert np.array_equal(z_plain[others], zT[others])
+    assert (s_plain[others] <= sc[others]).all()                             # (without the flag the array only speaks for the last launch's step)
+    with pytest.raises(capi.CclqrError):                                     # the flag needs the status array
+        capi.rollout_dev(mech, ctrl, n, 1, 1, z.data_ptr(), lam.data_ptr(), 0, 0, 0, zn.data_ptr(), 0, 0, flags=capi.ROLLOUT_CARRY_STATUS)
