@@ -285,12 +285,13 @@ end
 "Device-pointer rollout with explicit options (cclqr_rollout_ex): all pointers are device addresses (e.g. from AMDGPU.jl), the launch is
  asynchronous on `stream`.  first_instance = global index of instance 1 of this shard (noise stream and per-instance controller table),
  pid_state = device buffer n_inst x Nb x 2 carrying the PID integrators between launches (C_NULL: none), noise_ws = device workspace of
- n_inst x steps doubles for the Philox samples (C_NULL: the controller handle's own; see reserve_noise!), newton_mode 0 = exact rule."
+ n_inst x steps doubles for the Philox samples (C_NULL: the controller handle's own; see reserve_noise!), newton_mode 0 = exact rule,
+ flags = ROLLOUT_NO_ALLOC | ROLLOUT_PACK_WAVEFRONTS | ROLLOUT_CARRY_STATUS (include/cclqr.h)."
 function rollout_dev!(h::MechHandle, c::CtrlHandle, n::Integer, steps::Integer, k0::Integer, z0::Ptr{Float64}, lam::Ptr{Float64},
                       traj::Ptr{Float64}, zT::Ptr{Float64}, status::Ptr{Int32}; noise::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_stride = 0,
                       first_instance = 0, pid_state::Ptr{Float64} = Ptr{Float64}(C_NULL), noise_ws::Ptr{Float64} = Ptr{Float64}(C_NULL),
-                      newton_mode = 0, newton_eps_alone = 0.0, stream::Ptr{Cvoid} = C_NULL)
-    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2, noise_ws, noise_ws == C_NULL ? 0 : n * steps, newton_mode, 0, newton_eps_alone)
+                      newton_mode = 0, newton_eps_alone = 0.0, flags = Int32(0), stream::Ptr{Cvoid} = C_NULL)
+    o = RolloutOpts(first_instance, pid_state, pid_state == C_NULL ? 0 : n * h.nb * 2, noise_ws, noise_ws == C_NULL ? 0 : n * steps, newton_mode, Int32(flags), newton_eps_alone)
     check(ccall((:cclqr_rollout_ex, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
                  Ref{RolloutOpts}, Ptr{Cvoid}),
@@ -301,7 +302,8 @@ end
 reserve_noise!(c::CtrlHandle, n::Integer, steps::Integer) = check(ccall((:cclqr_ctrl_reserve_noise, lib), Cint, (Ptr{Cvoid}, Int64, Int32), c.ptr, n, steps))
 
 "The `controlfunction` hook (lqr.jl:14, :56) with the closure on the host: U (mu x nsp x n_ctrl, as given to CtrlHandle) are the joint inputs the
-closure computed for the next single-step launch (cclqr_ctrl_set_feedforward; host array, copied synchronously)."
+closure computed for the next single-step launch (cclqr_ctrl_set_feedforward; host array, copied synchronously).  Step the batch with
+`rollout_dev!(...; flags = ROLLOUT_CARRY_STATUS)` and a zeroed status array: an instance lost in an earlier launch then stays frozen, as in one launch over the horizon."
 set_feedforward!(c::CtrlHandle, U::Array{Float64}) =
     check(ccall((:cclqr_ctrl_set_feedforward, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32, Ptr{Cvoid}), c.ptr, U, length(U), 0, C_NULL))
 
