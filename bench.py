@@ -185,7 +185,9 @@ def main():
         sys.exit(3)
     z0_d = torch.from_numpy(z0).to(dev)
     zT_d = torch.empty_like(z0_d)
-    st_d = torch.zeros((chunks, n_inst), dtype=torch.int32, device=dev)
+    # one status per instance for the whole rollout: chunk 0 writes it, the later chunks carry it (CCLQR_ROLLOUT_CARRY_STATUS: an instance lost in one chunk
+    # stays frozen in the next, as in one launch over the horizon)
+    st_d = torch.zeros(n_inst, dtype=torch.int32, device=dev)
     lam_d = torch.zeros((n_inst, ml), dtype=torch.float64, device=dev) if chunks > 1 else None
     collect = gather_traj and (world > 1 or chunks > 1)          # trajectories leave the rank (or are re-assembled) chunk by chunk
     tg = pkg.dist.TrajectoryGather(rank, world, n_inst, T, nb, chunks, dev) if collect else None
@@ -208,7 +210,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             capi.rollout_dev(mh, ctrl, n_inst, Tc, c * Tc + 1, (z0_d if c == 0 else zT_d).data_ptr(), lam_d.data_ptr() if lam_d is not None else 0,
-                             0, 0, traj_ptr, zT_d.data_ptr(), st_d[c].data_ptr(), stream)
+                             0, 0, traj_ptr, zT_d.data_ptr(), st_d.data_ptr(), stream, flags=(capi.ROLLOUT_CARRY_STATUS if c > 0 else 0))
             if timed:
                 e1.record()
                 kern_ev.append((e0, e1))
@@ -238,8 +240,8 @@ def main():
     kern_ms_launch = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) if kern_ev else float("nan")   # average launch
     kern_ms = kern_ms_launch * chunks                                                                      # kernel time of one rollout
     status = st_d.cpu().numpy()
-    n_bad = int((status <= 0).any(axis=0).sum())
-    status = np.abs(status).max(axis=0)
+    n_bad = int((status <= 0).sum())
+    status = np.abs(status)
     gathered = tg.bytes_gathered / max(1, args.steps + args.warmup) if tg is not None else 0
 
     backend_name = dist.get_backend() if world > 1 else None

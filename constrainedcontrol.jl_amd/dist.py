@@ -193,7 +193,7 @@ def collection_plan(rank, world, n_local, T, nb, chunks, record, collect, n_tota
     sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
     nmax = max(sizes) if sizes else 0
     row = nb * 13 * itemsize
-    plan = {"initial + final states, status, multipliers": (2 * n_local * row + 4 * chunks * n_local + (5 * nb * itemsize * n_local if chunks > 1 else 0))}
+    plan = {"initial + final states, status, multipliers": (2 * n_local * row + 4 * n_local + (5 * nb * itemsize * n_local if chunks > 1 else 0))}
     gathering = record and collect == "trajectory" and (world > 1 or chunks > 1)
     if record and not gathering:
         plan["own recorded trajectory [n_local][T][nb][13]"] = n_local * T * row
